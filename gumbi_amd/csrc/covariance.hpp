@@ -1,0 +1,390 @@
+// covariance.hpp -- pairwise-distance covariance tiles (RBF / Matern family, ARD), the linear
+// and coregion terms Gumbi multiplies in, the white-noise diagonal, and the reductions that turn
+// the solved cross-covariance into posterior mean / variance.
+//
+// Restates what PyMC evaluates for the model Gumbi declares
+// (gumbi/regression/pymc/GP.py:389-414 continuous kernel, :449-455 linear, :457-464 coregion,
+//  :560-569 noise, :711-729 composition; prediction :845-847):
+//   k_cont = eta^2 * f(r),  r^2 = sum_k ((x_k - x'_k) / ls_k)^2,  r = sqrt(r^2 + 1e-12)
+//   ExpQuad exp(-r^2/2) | Matern52 (1+sqrt5 r+5r^2/3)exp(-sqrt5 r) | Matern32 (1+sqrt3 r)exp(-sqrt3 r)
+//   Matern12 exp(-r) | Exponential exp(-r/2)
+//   K = (k_cont + tau * <x_l - c, x'_l - c>) * prod_t B_t[cat_t(x), cat_t(x')]
+//   Sigma = K + diag(sigma^2 * nmult[cat_out(x)]) + jitter * I
+// r^2 is formed from scaled differences directly (PyMC expands it as -2XX'^T+|X|^2+|X'|^2 and
+// clips; the two agree to O(1e-16 |x|^2), see oracle/gp_oracle.py square_dist).
+//
+// HBM-bound: each covariance entry is written once (8 B) and never re-read by this kernel; the
+// inputs of a 128 x 128 tile (2 x 128 points) are staged once in LDS.  Lanes run along the
+// contiguous (row) index, so every wave store is one 512 B segment.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f64.hpp"
+
+namespace gmb {
+
+constexpr int MAX_TABS = 5;     // GMB_MAX_COREG + output coregion
+constexpr int MAX_LIN = 8;      // GMB_MAX_LIN
+
+// Pre-processed coordinates of a point set (structure-of-arrays, padded length `npad`):
+//   xs[k*npad + i]  continuous dims scaled by 1/ls_k (zero for padded dims / points)
+//   xl[k*npad + i]  linear dims minus c_k
+//   cat[t*npad + i] category index per coregion table
+struct PointSet {
+  const double* xs;
+  const double* xl;
+  const int32_t* cat;
+  int64_t n;     // real points
+  int64_t npad;  // allocated / padded length (multiple of 128)
+};
+
+struct CovParams {
+  int32_t kind;
+  int32_t n_lin;
+  int32_t n_tab;
+  int32_t tab_levels[MAX_TABS];
+  int32_t tab_off[MAX_TABS];  // offset of table t in `tabs`
+  const double* tabs;         // B tables, row-major L x L each
+  double eta2, tau;
+  double sigma2, jitter;
+  int32_t noise_tab;          // index into cat[] giving the output level for noise, or -1
+  const double* noise_mult;   // diag(B_noise) per output level (device), used if noise_tab >= 0
+};
+
+template <int KIND>
+__device__ __forceinline__ double stationary(double r2) {
+  if constexpr (KIND == 0) {
+    return exp(-0.5 * r2);
+  } else {
+    const double r = sqrt(r2 + 1e-12);
+    if constexpr (KIND == 1) {
+      const double s5 = 2.23606797749978969641;
+      return (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp(-s5 * r);
+    } else if constexpr (KIND == 2) {
+      const double s3 = 1.73205080756887729353;
+      return (1.0 + s3 * r) * exp(-s3 * r);
+    } else if constexpr (KIND == 3) {
+      return exp(-r);
+    } else {
+      return exp(-0.5 * r);
+    }
+  }
+}
+
+// d k / d r2 (for the NLML gradient)
+template <int KIND>
+__device__ __forceinline__ double stationary_dr2(double r2) {
+  if constexpr (KIND == 0) {
+    return -0.5 * exp(-0.5 * r2);
+  } else {
+    const double r = sqrt(r2 + 1e-12);
+    if constexpr (KIND == 1) {
+      const double s5 = 2.23606797749978969641;
+      return -(5.0 / 6.0) * (1.0 + s5 * r) * exp(-s5 * r);
+    } else if constexpr (KIND == 2) {
+      const double s3 = 1.73205080756887729353;
+      return -1.5 * exp(-s3 * r);
+    } else if constexpr (KIND == 3) {
+      return -exp(-r) / (2.0 * r);
+    } else {
+      return -0.25 * exp(-0.5 * r) / r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// point preparation: raw row-major X (n x D) -> PointSet arrays
+// ---------------------------------------------------------------------------------------------
+struct PrepArgs {
+  const double* X;
+  int64_t n, ldx, npad;
+  int32_t nc, nc_pad;            // real / padded continuous dims
+  int32_t idx_cont[16];
+  double inv_ls[16];
+  int32_t n_lin;
+  int32_t idx_lin[MAX_LIN];
+  double c_lin[MAX_LIN];
+  int32_t n_tab;
+  int32_t tab_col[MAX_TABS];
+  int32_t tab_levels[MAX_TABS];
+  double* xs;
+  double* xl;
+  int32_t* cat;
+};
+
+__global__ void prep_points_kernel(PrepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.npad) return;
+  const bool real = i < a.n;
+  const double* row = a.X + i * a.ldx;
+  for (int k = 0; k < a.nc_pad; ++k) {
+    double v = 0.0;
+    if (real && k < a.nc) v = row[a.idx_cont[k]] * a.inv_ls[k];
+    a.xs[(int64_t)k * a.npad + i] = v;
+  }
+  for (int k = 0; k < a.n_lin; ++k)
+    a.xl[(int64_t)k * a.npad + i] = real ? row[a.idx_lin[k]] - a.c_lin[k] : 0.0;
+  for (int t = 0; t < a.n_tab; ++t) {
+    int c = 0;
+    if (real) {
+      c = (int)row[a.tab_col[t]];  // PyMC Coregion casts the coordinate to int32
+      c = c < 0 ? 0 : (c >= a.tab_levels[t] ? a.tab_levels[t] - 1 : c);
+    }
+    a.cat[(int64_t)t * a.npad + i] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// covariance tile kernel
+// ---------------------------------------------------------------------------------------------
+enum CovMode : int { COV_TRAIN = 0, COV_CROSS = 1 };
+
+struct CovTileArgs {
+  CovParams p;
+  PointSet rows;   // fast (contiguous) index of the output
+  PointSet cols;   // slow index
+  double* out;     // out[(i - i0) + (j - j0) * ldo]
+  int64_t ldo;
+  int64_t i0, j0;  // global offsets of the region (multiples of 128)
+  int32_t ti, tj;  // tile counts
+  int32_t mode;    // CovMode
+  int32_t lower_only;   // COV_TRAIN: skip tiles strictly above the diagonal
+  const double* y;      // COV_TRAIN: observations, written into row n (the "y row")
+};
+
+template <int KIND, int NC>
+__global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
+  __shared__ double xj[NC][TILE];
+  __shared__ double lj[MAX_LIN][TILE];
+  __shared__ double li[MAX_LIN][TILE];
+  __shared__ int32_t cj[MAX_TABS][TILE];
+  __shared__ int32_t ci[MAX_TABS][TILE];
+
+  const int nwg = a.ti * a.tj;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int tjx = wg / a.ti;
+  const int tix = wg - tjx * a.ti;
+  const int64_t gi0 = a.i0 + (int64_t)tix * TILE;
+  const int64_t gj0 = a.j0 + (int64_t)tjx * TILE;
+  if (a.mode == COV_TRAIN && a.lower_only && gi0 + TILE - 1 < gj0) return;
+
+  const int tid = threadIdx.x;
+  const int il = tid & (TILE - 1);
+  const int jh = tid >> 7;  // which half of the tile's columns
+  const int64_t gi = gi0 + il;
+  const CovParams& p = a.p;
+
+  // stage the tile's column points
+  for (int idx = tid; idx < NC * TILE; idx += 256) {
+    const int k = idx / TILE, j = idx - k * TILE;
+    xj[k][j] = a.cols.xs[(int64_t)k * a.cols.npad + gj0 + j];
+  }
+  for (int idx = tid; idx < p.n_lin * TILE; idx += 256) {
+    const int k = idx / TILE, j = idx - k * TILE;
+    lj[k][j] = a.cols.xl[(int64_t)k * a.cols.npad + gj0 + j];
+    li[k][j] = a.rows.xl[(int64_t)k * a.rows.npad + gi0 + j];
+  }
+  for (int idx = tid; idx < p.n_tab * TILE; idx += 256) {
+    const int t = idx / TILE, j = idx - t * TILE;
+    cj[t][j] = a.cols.cat[(int64_t)t * a.cols.npad + gj0 + j];
+    ci[t][j] = a.rows.cat[(int64_t)t * a.rows.npad + gi0 + j];
+  }
+  // this thread's row point in registers
+  double xi[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) xi[k] = a.rows.xs[(int64_t)k * a.rows.npad + gi];
+  __syncthreads();
+
+  const bool row_real = gi < a.rows.n;
+  double* outp = a.out + (gi - a.i0) + (gj0 - a.j0 + jh * (TILE / 2)) * a.ldo;
+  double ndiag = 0.0;
+  if (a.mode == COV_TRAIN && row_real) {
+    ndiag = p.sigma2;
+    if (p.noise_tab >= 0) ndiag *= p.noise_mult[ci[p.noise_tab][il]];
+    ndiag += p.jitter;
+  }
+
+  for (int jj = 0; jj < TILE / 2; ++jj) {
+    const int j = jh * (TILE / 2) + jj;
+    const int64_t gj = gj0 + j;
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const double d = xi[k] - xj[k][j];
+      r2 = fma(d, d, r2);
+    }
+    double v = p.eta2 * stationary<KIND>(r2);
+    if (p.n_lin > 0) {
+      double s = 0.0;
+      for (int k = 0; k < p.n_lin; ++k) s = fma(li[k][il], lj[k][j], s);
+      v = fma(p.tau, s, v);
+    }
+    for (int t = 0; t < p.n_tab; ++t)
+      v *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
+    const bool col_real = gj < a.cols.n;
+    if (a.mode == COV_TRAIN) {
+      if (!col_real) {
+        v = (gi == gj) ? 1.0 : 0.0;  // identity padding keeps the padded factor trivial
+      } else if (!row_real) {
+        v = (gi == a.rows.n) ? a.y[gj] : 0.0;  // appended y row: the factor's row n becomes L^-1 y
+      } else if (gi == gj) {
+        v += ndiag;
+      }
+      if (gi >= gj) outp[(int64_t)jj * a.ldo] = v;  // lower triangle only
+    } else {
+      outp[(int64_t)jj * a.ldo] = (row_real && col_real) ? v : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prior variance + noise at the test points:  kss[m] = diag K(x*_m, x*_m) (+ noise)
+// ---------------------------------------------------------------------------------------------
+struct KssArgs {
+  CovParams p;
+  PointSet pts;
+  int32_t with_noise;
+  double* kss;
+};
+
+__global__ void kss_kernel(KssArgs a) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= a.pts.npad) return;
+  const CovParams& p = a.p;
+  double v = p.eta2;  // stationary diag is exactly 1 (pm.gp.cov.Stationary.diag)
+  if (p.n_lin > 0) {
+    double s = 0.0;
+    for (int k = 0; k < p.n_lin; ++k) {
+      const double x = a.pts.xl[(int64_t)k * a.pts.npad + m];
+      s = fma(x, x, s);
+    }
+    v = fma(p.tau, s, v);
+  }
+  for (int t = 0; t < p.n_tab; ++t) {
+    const int c = a.pts.cat[(int64_t)t * a.pts.npad + m];
+    v *= p.tabs[p.tab_off[t] + c * p.tab_levels[t] + c];
+  }
+  if (a.with_noise) {
+    double nz = p.sigma2;
+    if (p.noise_tab >= 0) nz *= p.noise_mult[a.pts.cat[(int64_t)p.noise_tab * a.pts.npad + m]];
+    v += nz;
+  }
+  a.kss[m] = (m < a.pts.n) ? v : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// posterior reductions over the solved cross-covariance V (m fast, ldz):
+//   part_mu[c][m] = sum_{i in chunk c} V[m + i*ldz] * v[i],  part_s[c][m] = sum V^2
+// then  mean = sum_c part_mu,  var = kss - sum_c part_s   (deterministic two-stage sum)
+// ---------------------------------------------------------------------------------------------
+constexpr int RED_CHUNK = 256;
+
+__global__ __launch_bounds__(256) void predict_partial_kernel(const double* __restrict__ V,
+                                                              int64_t ldz,
+                                                              const double* __restrict__ v,
+                                                              int64_t n, double* part_mu,
+                                                              double* part_s, int64_t mpad) {
+  __shared__ double vs[RED_CHUNK];
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.y * RED_CHUNK;
+  const int64_t i1 = (i0 + RED_CHUNK < n) ? i0 + RED_CHUNK : n;
+  if (i0 + threadIdx.x < n) vs[threadIdx.x] = v[i0 + threadIdx.x];
+  __syncthreads();
+  double am = 0.0, as = 0.0;
+  const double* col = V + m + i0 * ldz;
+  for (int64_t i = i0; i < i1; ++i) {
+    const double x = *col;
+    am = fma(x, vs[i - i0], am);
+    as = fma(x, x, as);
+    col += ldz;
+  }
+  part_mu[(int64_t)blockIdx.y * mpad + m] = am;
+  part_s[(int64_t)blockIdx.y * mpad + m] = as;
+}
+
+__global__ void predict_final_kernel(const double* part_mu, const double* part_s, int nchunk,
+                                     int64_t mpad, const double* kss, int64_t M, double* mean,
+                                     double* var) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double am = 0.0, as = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    am += part_mu[(int64_t)c * mpad + m];
+    as += part_s[(int64_t)c * mpad + m];
+  }
+  mean[m] = am;
+  var[m] = kss[m] - as;
+}
+
+// v[i] = L[n + i*ld] (the y row of the factor), and |v|^2
+__global__ __launch_bounds__(256) void extract_v_kernel(const double* L, int64_t ld, int64_t n,
+                                                        double* v, double* vnorm2) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double x = L[n + i * ld];
+    v[i] = x;
+    acc = fma(x, x, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(vnorm2, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pairwise-distance extrema for the lengthscale prior (gumbi/utils/gp_utils.py:34-46)
+// ---------------------------------------------------------------------------------------------
+// pts: SoA [ncols][npad]; group g covers columns [g*gw, (g+1)*gw).  Results are bit patterns of
+// non-negative doubles, so unsigned-integer atomic min / max order them correctly.
+__global__ __launch_bounds__(256) void ls_limits_kernel(const double* pts, int64_t n, int64_t npad,
+                                                        int32_t gw, unsigned long long* mn,
+                                                        unsigned long long* mx, int32_t tiles) {
+  __shared__ double xj[16][TILE];
+  const int g = blockIdx.y;
+  // decode lower-triangle tile pair (ti >= tj) from blockIdx.x
+  int tjx = 0, rem = blockIdx.x;
+  while (rem >= tiles - tjx) {
+    rem -= tiles - tjx;
+    ++tjx;
+  }
+  const int tix = tjx + rem;
+  const int tid = threadIdx.x;
+  const int il = tid & (TILE - 1), jh = tid >> 7;
+  const int64_t gi = (int64_t)tix * TILE + il, gj0 = (int64_t)tjx * TILE;
+  for (int idx = tid; idx < gw * TILE; idx += 256) {
+    const int k = idx / TILE, j = idx - k * TILE;
+    xj[k][j] = pts[(int64_t)(g * gw + k) * npad + gj0 + j];
+  }
+  __syncthreads();
+  double lo = 1.0e300, hi = 0.0;
+  if (gi < n) {
+    for (int jj = 0; jj < TILE / 2; ++jj) {
+      const int j = jh * (TILE / 2) + jj;
+      const int64_t gj = gj0 + j;
+      if (gj >= gi) continue;  // strictly lower pairs, each once
+      double r2 = 0.0;
+      for (int k = 0; k < gw; ++k) {
+        const double d = pts[(int64_t)(g * gw + k) * npad + gi] - xj[k][j];
+        r2 = fma(d, d, r2);
+      }
+      if (r2 > 0.0) {
+        lo = fmin(lo, r2);
+        hi = fmax(hi, r2);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_down(lo, off));
+    hi = fmax(hi, __shfl_down(hi, off));
+  }
+  if ((tid & 63) == 0) {
+    if (lo < 1.0e300) atomicMin(&mn[g], (unsigned long long)__double_as_longlong(lo));
+    if (hi > 0.0) atomicMax(&mx[g], (unsigned long long)__double_as_longlong(hi));
+  }
+}
+
+}  // namespace gmb

@@ -1,0 +1,1182 @@
+// engine.hip -- host side of libgumbi_hip.so: the C ABI of include/gumbi_hip.h.
+//
+// One engine = one HIP device + one stream + the resident state of one GP:
+//   raw inputs X (N x D), y; prepared coordinates (scaled / shifted / categorical, SoA);
+//   the covariance / factor buffer A (column-major, (N+1 rounded up to 128) rows x (N rounded up
+//   to 128) columns) whose row N carries y and, after factorisation, v = L^-1 y;
+//   inv(L_kk) for every 128 x 128 diagonal block; predict workspaces.
+//
+// Cholesky: recursive over block columns -- chol(c0,c1) = chol(c0,mid); trailing update
+// A[mid:END, mid:c1] -= L[mid:END, c0:mid] L[mid:c1, c0:mid]^T on f64 MFMA; chol(mid,c1).
+// Most flops land in GEMMs with k >= N/4, so the update is MFMA- rather than HBM-bound.
+// Leaves: potrf_leaf (factor + invert a diagonal block) then the panel solve as a GEMM with
+// inv(L_kk).  Predict: V = K(X*,X) L^-T by the same recursion on V's columns.
+//
+// There is no CPU fallback anywhere in this file: without a HIP device every entry point
+// returns GMB_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gumbi_hip.h"
+#include "covariance.hpp"
+#include "gemm_f64.hpp"
+#include "gradient.hpp"
+#include "potrf_leaf.hpp"
+
+using namespace gmb;
+
+namespace {
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct EventPair {
+  hipEvent_t a, b;
+  int kind;  // 0 chol gemm, 1 leaf, 2 trsm, 3 predict gemm, 4 grad gemm
+  double flops;
+};
+
+}  // namespace
+
+struct gmb_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // data
+  int64_t N = 0, Np = 0, Nr = 0, ld = 0;
+  int32_t D = 0;
+  double* dX = nullptr;
+  double* dy = nullptr;
+  double* dA = nullptr;
+  double* dInv = nullptr;
+  int64_t cap_A = 0, cap_inv = 0;
+
+  // kernel + parameters
+  gmb_kernel_spec spec{};
+  bool have_spec = false, have_theta = false;
+  std::vector<double> theta;
+  int nc_pad = 1;
+  double* xs = nullptr;
+  double* xl = nullptr;
+  int32_t* cat = nullptr;
+  int64_t cap_pts = 0;
+  double* dtabs = nullptr;
+  double* dnoise = nullptr;
+  CovParams cp{};
+  PrepArgs prep_proto{};
+  std::vector<double> htabs;  // host copies (gradient chain rule)
+  std::vector<double> hnoise;
+
+  // factorisation results
+  double* dscal = nullptr;  // [0] logdet, [1] |v|^2, [2..] gradient partials
+  int32_t* dinfo = nullptr;
+  double* dv = nullptr;
+  bool factored = false;
+  bool factor_consumed = false;  // Sigma^-1 has overwritten the factor (gradient call)
+  int64_t notpd = -1;
+  double logdet = 0.0, vnorm2 = 0.0;
+
+  // predict workspace
+  int64_t Mt_cap = 0;
+  double* dV = nullptr;
+  double* dXs = nullptr;
+  double* txs = nullptr;
+  double* txl = nullptr;
+  int32_t* tcat = nullptr;
+  double* dkss = nullptr;
+  double* dpart = nullptr;
+  double* dmean = nullptr;
+  double* dvar = nullptr;
+  int64_t cap_part = 0;
+
+  // gradient workspace
+  double* dW = nullptr;  // Np x Np column-major: L^-1 then Sigma^-1
+  int64_t cap_W = 0;
+  double* dalpha = nullptr;
+  int64_t cap_pts_alpha = 0;
+  double* dgpart = nullptr;
+  int64_t cap_gpart = 0;
+
+  // timing
+  bool profiling = false;
+  gmb_timings tm{};
+  std::vector<EventPair> evs;
+  bool naive_leaf = false;
+};
+
+namespace {
+
+int fail(gmb_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                              \
+  do {                                                                                \
+    hipError_t _s = (call);                                                           \
+    if (_s != hipSuccess)                                                             \
+      return fail(e, GMB_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_s), \
+                  __FILE__, __LINE__);                                                \
+  } while (0)
+
+template <typename T>
+int ensure(gmb_engine* e, T** p, int64_t* cap, int64_t need) {
+  if (*cap >= need && *p) return GMB_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  hipError_t s = hipMalloc((void**)p, (size_t)need * sizeof(T));
+  if (s != hipSuccess)
+    return fail(e, GMB_ENOMEM, "hipMalloc of %lld bytes failed: %s", (long long)(need * sizeof(T)),
+                hipGetErrorString(s));
+  *cap = need;
+  return GMB_OK;
+}
+
+template <typename T>
+int alloc(gmb_engine* e, T** p, int64_t need) {
+  int64_t cap = 0;
+  if (*p) {
+    (void)hipFree(*p);
+    *p = nullptr;
+  }
+  return ensure(e, p, &cap, need);
+}
+
+int pick_nc(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 16; }
+
+// ---- timing helpers -----------------------------------------------------------------------
+struct PhaseTimer {
+  gmb_engine* e;
+  hipEvent_t a = nullptr, b = nullptr;
+  explicit PhaseTimer(gmb_engine* e_) : e(e_) {
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, e->stream);
+  }
+  void stop() { (void)hipEventRecord(b, e->stream); }
+  double ms() {  // caller has synchronised the stream
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, a, b);
+    return (double)t;
+  }
+  ~PhaseTimer() {
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  }
+};
+
+void ev_begin(gmb_engine* e, int kind, double flops) {
+  if (!e->profiling) return;
+  EventPair p;
+  (void)hipEventCreate(&p.a);
+  (void)hipEventCreate(&p.b);
+  p.kind = kind;
+  p.flops = flops;
+  (void)hipEventRecord(p.a, e->stream);
+  e->evs.push_back(p);
+}
+void ev_end(gmb_engine* e) {
+  if (!e->profiling) return;
+  (void)hipEventRecord(e->evs.back().b, e->stream);
+}
+void ev_collect(gmb_engine* e) {  // stream already synchronised
+  for (auto& p : e->evs) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, p.a, p.b);
+    switch (p.kind) {
+      case 0:
+        e->tm.chol_gemm_ms += t;
+        e->tm.chol_gemm_flops += p.flops;
+        e->tm.chol_gemm_launches += 1;
+        break;
+      case 1: e->tm.chol_leaf_ms += t; break;
+      case 2: e->tm.chol_trsm_ms += t; break;
+      case 3:
+        e->tm.predict_gemm_ms += t;
+        e->tm.predict_gemm_flops += p.flops;
+        e->tm.predict_gemm_launches += 1;
+        break;
+      case 4:
+        e->tm.grad_gemm_ms += t;
+        e->tm.grad_gemm_flops += p.flops;
+        break;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  e->evs.clear();
+}
+
+// ---- kernel launch helpers ----------------------------------------------------------------
+int launch_gemm(gmb_engine* e, const GemmArgs& g, int ev_kind) {
+  if (g.mt <= 0 || g.nt <= 0 || g.k <= 0) return GMB_OK;
+  ev_begin(e, ev_kind, e->profiling ? gemm_flops(g) : 0.0);
+  const dim3 grid(g.mt * g.nt), block(256);
+  if (g.ta && g.tb)
+    hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, e->stream, g);
+  else if (g.ta)
+    hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, e->stream, g);
+  else if (g.tb)
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, e->stream, g);
+  else
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, e->stream, g);
+  ev_end(e);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+int launch_leaf(gmb_engine* e, const LeafArgs& a) {
+  ev_begin(e, 1, 0.0);
+  if (e->naive_leaf)
+    hipLaunchKernelGGL(potrf_leaf_naive_kernel, dim3(1), dim3(256), 0, e->stream, a);
+  else
+    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(256), 0, e->stream, a);
+  ev_end(e);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+template <int KIND>
+int launch_cov_nc(gmb_engine* e, const CovTileArgs& a, int nc) {
+  const dim3 grid(a.ti * a.tj), block(256);
+  switch (nc) {
+    case 1: hipLaunchKernelGGL((cov_tile_kernel<KIND, 1>), grid, block, 0, e->stream, a); break;
+    case 2: hipLaunchKernelGGL((cov_tile_kernel<KIND, 2>), grid, block, 0, e->stream, a); break;
+    case 4: hipLaunchKernelGGL((cov_tile_kernel<KIND, 4>), grid, block, 0, e->stream, a); break;
+    case 8: hipLaunchKernelGGL((cov_tile_kernel<KIND, 8>), grid, block, 0, e->stream, a); break;
+    default: hipLaunchKernelGGL((cov_tile_kernel<KIND, 16>), grid, block, 0, e->stream, a); break;
+  }
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+int launch_cov(gmb_engine* e, const CovTileArgs& a) {
+  if (a.ti <= 0 || a.tj <= 0) return GMB_OK;
+  switch (a.p.kind) {
+    case GMB_EXPQUAD: return launch_cov_nc<0>(e, a, e->nc_pad);
+    case GMB_MATERN52: return launch_cov_nc<1>(e, a, e->nc_pad);
+    case GMB_MATERN32: return launch_cov_nc<2>(e, a, e->nc_pad);
+    case GMB_MATERN12: return launch_cov_nc<3>(e, a, e->nc_pad);
+    case GMB_EXPONENTIAL: return launch_cov_nc<4>(e, a, e->nc_pad);
+  }
+  return fail(e, GMB_EINVAL, "unknown kernel kind %d", a.p.kind);
+}
+
+int spec_ntab(const gmb_kernel_spec& s) { return s.n_coreg + (s.out_col >= 0 ? 1 : 0); }
+
+int validate_spec(gmb_engine* e, const gmb_kernel_spec& s, int D) {
+  if (s.kind < 0 || s.kind > 4) return fail(e, GMB_EINVAL, "kernel kind %d out of range", s.kind);
+  if (s.n_cont < 1 || s.n_cont > GMB_MAX_DIMS)
+    return fail(e, GMB_EINVAL, "n_cont=%d must be in [1,%d]", s.n_cont, GMB_MAX_DIMS);
+  if (s.n_lin < 0 || s.n_lin > GMB_MAX_LIN)
+    return fail(e, GMB_EINVAL, "n_lin=%d must be in [0,%d]", s.n_lin, GMB_MAX_LIN);
+  if (s.n_coreg < 0 || s.n_coreg > GMB_MAX_COREG)
+    return fail(e, GMB_EINVAL, "bad n_coreg=%d", s.n_coreg);
+  for (int k = 0; k < s.n_cont; ++k)
+    if (s.idx_cont[k] < 0 || (D > 0 && s.idx_cont[k] >= D))
+      return fail(e, GMB_EINVAL, "idx_cont[%d]=%d outside the %d columns of X", k, s.idx_cont[k], D);
+  for (int k = 0; k < s.n_lin; ++k)
+    if (s.idx_lin[k] < 0 || (D > 0 && s.idx_lin[k] >= D))
+      return fail(e, GMB_EINVAL, "idx_lin[%d]=%d outside the %d columns of X", k, s.idx_lin[k], D);
+  for (int t = 0; t < s.n_coreg; ++t) {
+    if (s.coreg_col[t] < 0 || (D > 0 && s.coreg_col[t] >= D))
+      return fail(e, GMB_EINVAL, "coreg_col[%d]=%d outside X", t, s.coreg_col[t]);
+    if (s.coreg_levels[t] < 1 || s.coreg_levels[t] > GMB_MAX_LEVELS)
+      return fail(e, GMB_EINVAL, "coreg_levels[%d]=%d must be in [1,%d]", t, s.coreg_levels[t],
+                  GMB_MAX_LEVELS);
+  }
+  if (s.out_col >= 0) {
+    if (D > 0 && s.out_col >= D) return fail(e, GMB_EINVAL, "out_col=%d outside X", s.out_col);
+    if (s.n_out < 1 || s.n_out > GMB_MAX_LEVELS)
+      return fail(e, GMB_EINVAL, "n_out=%d must be in [1,%d]", s.n_out, GMB_MAX_LEVELS);
+  }
+  if (!(s.jitter >= 0.0)) return fail(e, GMB_EINVAL, "jitter must be >= 0");
+  return GMB_OK;
+}
+
+// Fill PrepArgs / CovParams from spec + theta and upload the coregion tables.
+int apply_theta(gmb_engine* e) {
+  const gmb_kernel_spec& s = e->spec;
+  const double* th = e->theta.data();
+  int k = 0;
+  const int n_ls = s.ard ? s.n_cont : 1;
+  PrepArgs& pa = e->prep_proto;
+  pa = PrepArgs{};
+  pa.nc = s.n_cont;
+  pa.nc_pad = e->nc_pad;
+  for (int i = 0; i < s.n_cont; ++i) {
+    const double ls = th[s.ard ? i : 0];
+    if (!(ls > 0.0)) return fail(e, GMB_EINVAL, "lengthscale %d = %g must be positive", i, ls);
+    pa.idx_cont[i] = s.idx_cont[i];
+    pa.inv_ls[i] = 1.0 / ls;
+  }
+  k += n_ls;
+  const double eta = th[k], sigma = th[k + 1];
+  k += 2;
+  CovParams& cp = e->cp;
+  cp = CovParams{};
+  cp.kind = s.kind;
+  cp.eta2 = eta * eta;
+  cp.sigma2 = sigma * sigma;
+  cp.jitter = s.jitter;
+  cp.n_lin = s.n_lin;
+  pa.n_lin = s.n_lin;
+  if (s.n_lin > 0) {
+    for (int i = 0; i < s.n_lin; ++i) {
+      pa.idx_lin[i] = s.idx_lin[i];
+      pa.c_lin[i] = th[k + i];
+    }
+    cp.tau = th[k + s.n_lin];
+    k += s.n_lin + 1;
+  }
+  // coregion tables: B = W W^T + diag(kappa)
+  const int ntab = spec_ntab(s);
+  cp.n_tab = ntab;
+  pa.n_tab = ntab;
+  e->htabs.clear();
+  int off = 0;
+  for (int t = 0; t < ntab; ++t) {
+    const bool is_out = (t == s.n_coreg);
+    const int L = is_out ? s.n_out : s.coreg_levels[t];
+    const double* W = th + k;
+    const double* kap = th + k + 2 * L;
+    cp.tab_levels[t] = L;
+    cp.tab_off[t] = off;
+    pa.tab_col[t] = is_out ? s.out_col : s.coreg_col[t];
+    pa.tab_levels[t] = L;
+    for (int a = 0; a < L; ++a)
+      for (int b = 0; b < L; ++b)
+        e->htabs.push_back(W[2 * a] * W[2 * b] + W[2 * a + 1] * W[2 * b + 1] + (a == b ? kap[a] : 0.0));
+    off += L * L;
+    k += 3 * L;
+  }
+  cp.noise_tab = -1;
+  e->hnoise.clear();
+  if (s.out_col >= 0 && s.hetero_noise) {
+    const int P = s.n_out;
+    const double* W = th + k;
+    const double* kap = th + k + 2 * P;
+    for (int a = 0; a < P; ++a) e->hnoise.push_back(W[2 * a] * W[2 * a] + W[2 * a + 1] * W[2 * a + 1] + kap[a]);
+    cp.noise_tab = s.n_coreg;  // the output table's category index
+    k += 3 * P;
+  }
+  if (k != (int)e->theta.size()) return fail(e, GMB_EINVAL, "internal: theta packing mismatch");
+  if (!e->dtabs) {
+    int rc = alloc(e, &e->dtabs, (int64_t)MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS);
+    if (rc) return rc;
+    rc = alloc(e, &e->dnoise, (int64_t)GMB_MAX_LEVELS);
+    if (rc) return rc;
+  }
+  if (!e->htabs.empty())
+    HIP_TRY(e, hipMemcpyAsync(e->dtabs, e->htabs.data(), e->htabs.size() * sizeof(double),
+                              hipMemcpyHostToDevice, e->stream));
+  if (!e->hnoise.empty())
+    HIP_TRY(e, hipMemcpyAsync(e->dnoise, e->hnoise.data(), e->hnoise.size() * sizeof(double),
+                              hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));  // host vectors may be rewritten by the caller
+  cp.tabs = e->dtabs;
+  cp.noise_mult = e->dnoise;
+  return GMB_OK;
+}
+
+int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int64_t npad, double* xs,
+                double* xl, int32_t* cat) {
+  PrepArgs a = e->prep_proto;
+  a.X = dXraw;
+  a.n = n;
+  a.ldx = ldx;
+  a.npad = npad;
+  a.xs = xs;
+  a.xl = xl;
+  a.cat = cat;
+  hipLaunchKernelGGL(prep_points_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, a);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+PointSet train_set(const gmb_engine* e) { return PointSet{e->xs, e->xl, e->cat, e->N, e->Nr}; }
+
+// ---- Cholesky recursion -------------------------------------------------------------------
+int chol_leaf(gmb_engine* e, int c) {
+  LeafArgs a;
+  a.A = e->dA + (int64_t)c * TILE + (int64_t)c * TILE * e->ld;
+  a.lda = e->ld;
+  a.nvalid = (int)std::min<int64_t>(TILE, e->N - (int64_t)c * TILE);
+  a.invL = e->dInv + (int64_t)c * TILE * TILE;
+  a.logdet = e->dscal;
+  a.info = e->dinfo;
+  a.row0 = (int64_t)c * TILE;
+  int rc = launch_leaf(e, a);
+  if (rc) return rc;
+  // panel rows below the diagonal block:  P <- P inv(L_cc)^T   (in place, one row tile per block)
+  GemmArgs g{};
+  g.C = e->dA + (int64_t)(c + 1) * TILE + (int64_t)c * TILE * e->ld;
+  g.ldc = e->ld;
+  g.A = a.invL;
+  g.lda = TILE;
+  g.B = g.C;
+  g.ldb = e->ld;
+  g.mt = 1;
+  g.nt = (int)(e->Nr / TILE) - (c + 1);
+  g.k = TILE;
+  g.alpha = 1.0;
+  g.beta = 0.0;
+  return launch_gemm(e, g, 2);
+}
+
+int chol_cols(gmb_engine* e, int c0, int c1) {
+  if (c1 - c0 == 1) return chol_leaf(e, c0);
+  const int mid = c0 + (c1 - c0 + 1) / 2;
+  int rc = chol_cols(e, c0, mid);
+  if (rc) return rc;
+  GemmArgs g{};
+  g.C = e->dA + (int64_t)mid * TILE + (int64_t)mid * TILE * e->ld;
+  g.ldc = e->ld;
+  g.A = e->dA + (int64_t)mid * TILE + (int64_t)c0 * TILE * e->ld;
+  g.lda = e->ld;
+  g.B = g.A;
+  g.ldb = e->ld;
+  g.mt = c1 - mid;
+  g.nt = (int)(e->Nr / TILE) - mid;
+  g.k = (mid - c0) * TILE;
+  g.alpha = -1.0;
+  g.beta = 1.0;
+  g.tri = 1;
+  g.tri_shift = 0;
+  rc = launch_gemm(e, g, 0);
+  if (rc) return rc;
+  return chol_cols(e, mid, c1);
+}
+
+// ---- predict recursion: V <- W L^-T over column blocks [c0, c1) ------------------------------
+int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1) {
+  if (c1 - c0 == 1) {
+    GemmArgs g{};
+    g.C = V + (int64_t)c0 * TILE * ldz;
+    g.ldc = ldz;
+    g.A = e->dInv + (int64_t)c0 * TILE * TILE;
+    g.lda = TILE;
+    g.B = g.C;
+    g.ldb = ldz;
+    g.mt = 1;
+    g.nt = ntm;
+    g.k = TILE;
+    g.alpha = 1.0;
+    g.beta = 0.0;
+    return launch_gemm(e, g, 3);
+  }
+  const int mid = c0 + (c1 - c0 + 1) / 2;
+  int rc = trsm_cols(e, V, ldz, ntm, c0, mid);
+  if (rc) return rc;
+  GemmArgs g{};
+  g.C = V + (int64_t)mid * TILE * ldz;
+  g.ldc = ldz;
+  g.A = e->dA + (int64_t)mid * TILE + (int64_t)c0 * TILE * e->ld;
+  g.lda = e->ld;
+  g.B = V + (int64_t)c0 * TILE * ldz;
+  g.ldb = ldz;
+  g.mt = c1 - mid;
+  g.nt = ntm;
+  g.k = (mid - c0) * TILE;
+  g.alpha = -1.0;
+  g.beta = 1.0;
+  rc = launch_gemm(e, g, 3);
+  if (rc) return rc;
+  return trsm_cols(e, V, ldz, ntm, mid, c1);
+}
+
+// ---- NLML gradient ---------------------------------------------------------------------------
+// W = L^-1 by recursive block inversion into e->dW (lower triangle; the mirrored upper region is
+// scratch for the intermediate products):  [[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]].
+int winv_cols(gmb_engine* e, int c0, int c1) {
+  const int64_t ldw = e->Np;
+  double* W = e->dW;
+  if (c1 - c0 == 1) {
+    HIP_TRY(e, hipMemcpy2DAsync(W + (int64_t)c0 * TILE + (int64_t)c0 * TILE * ldw, ldw * sizeof(double),
+                                e->dInv + (int64_t)c0 * TILE * TILE, TILE * sizeof(double),
+                                TILE * sizeof(double), TILE, hipMemcpyDeviceToDevice, e->stream));
+    return GMB_OK;
+  }
+  const int mid = c0 + (c1 - c0 + 1) / 2;
+  int rc;
+  if ((rc = winv_cols(e, c0, mid))) return rc;
+  if ((rc = winv_cols(e, mid, c1))) return rc;
+  const int n1 = mid - c0, n2 = c1 - mid;
+  {  // T^T[j][r] = sum_{k>=j} Wa[k][j] * B[r][k]   -> scratch at W[c0.., mid..]
+    GemmArgs g{};
+    g.C = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;
+    g.ldc = ldw;
+    g.A = e->dA + (int64_t)mid * TILE + (int64_t)c0 * TILE * e->ld;  // B = L21, k-major
+    g.lda = e->ld;
+    g.B = W + (int64_t)c0 * TILE + (int64_t)c0 * TILE * ldw;          // Wa, contraction on rows
+    g.ldb = ldw;
+    g.tb = 1;
+    g.mt = n2;
+    g.nt = n1;
+    g.k = n1 * TILE;
+    g.klo_n = 1;
+    g.alpha = 1.0;
+    g.beta = 0.0;
+    if ((rc = launch_gemm(e, g, 4))) return rc;
+  }
+  {  // W21[r][j] = -sum_{s<=r} Wc[r][s] * T^T[j][s]
+    GemmArgs g{};
+    g.C = W + (int64_t)mid * TILE + (int64_t)c0 * TILE * ldw;
+    g.ldc = ldw;
+    g.A = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;   // T^T, k-major
+    g.lda = ldw;
+    g.B = W + (int64_t)mid * TILE + (int64_t)mid * TILE * ldw;  // Wc, k-major
+    g.ldb = ldw;
+    g.mt = n1;
+    g.nt = n2;
+    g.k = n2 * TILE;
+    g.khi_n = 1;
+    g.alpha = -1.0;
+    g.beta = 0.0;
+    if ((rc = launch_gemm(e, g, 4))) return rc;
+  }
+  return GMB_OK;
+}
+
+template <int KIND>
+int launch_grad_nc(gmb_engine* e, const GradArgs& a, int nblocks) {
+  const dim3 grid(nblocks), block(256);
+  switch (e->nc_pad) {
+    case 1: hipLaunchKernelGGL((grad_tile_kernel<KIND, 1>), grid, block, 0, e->stream, a); break;
+    case 2: hipLaunchKernelGGL((grad_tile_kernel<KIND, 2>), grid, block, 0, e->stream, a); break;
+    case 4: hipLaunchKernelGGL((grad_tile_kernel<KIND, 4>), grid, block, 0, e->stream, a); break;
+    case 8: hipLaunchKernelGGL((grad_tile_kernel<KIND, 8>), grid, block, 0, e->stream, a); break;
+    default: hipLaunchKernelGGL((grad_tile_kernel<KIND, 16>), grid, block, 0, e->stream, a); break;
+  }
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+constexpr int GACC_DOUBLES = 64 + MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS + 64;
+
+int grad_impl(gmb_engine* e, double* grad) {
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (e->factor_consumed)
+    return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
+  const gmb_kernel_spec& s = e->spec;
+  int rc;
+  gmb_timings& tm = e->tm;
+  tm.grad_ms = tm.grad_gemm_ms = tm.grad_gemm_flops = 0.0;
+  if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
+  if (e->cap_pts_alpha < e->Np) {
+    if ((rc = alloc(e, &e->dalpha, e->Np))) return rc;
+    e->cap_pts_alpha = e->Np;
+  }
+  if (!e->dgpart && (rc = alloc(e, &e->dgpart, (int64_t)GACC_DOUBLES))) return rc;
+  PhaseTimer tg(e);
+  const int nt = (int)(e->Np / TILE);
+  // 1. W = L^-1
+  if ((rc = winv_cols(e, 0, nt))) return rc;
+  // 2. alpha = W^T v = Sigma^-1 y
+  hipLaunchKernelGGL(wt_v_kernel, dim3((unsigned)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->dW, e->Np,
+                     e->dv, e->N, e->dalpha);
+  HIP_TRY(e, hipGetLastError());
+  // 3. Sigma^-1 = W^T W (lower triangle) into the factor buffer -- the factor is consumed
+  {
+    GemmArgs g{};
+    g.C = e->dA;
+    g.ldc = e->ld;
+    g.A = e->dW;
+    g.lda = e->Np;
+    g.B = e->dW;
+    g.ldb = e->Np;
+    g.ta = g.tb = 1;
+    g.mt = g.nt = nt;
+    g.k = (int)e->Np;
+    g.klo_n = 1;
+    g.tri = 1;
+    g.alpha = 1.0;
+    g.beta = 0.0;
+    e->factor_consumed = true;
+    if ((rc = launch_gemm(e, g, 4))) return rc;
+  }
+  // 4. fused trace reductions
+  HIP_TRY(e, hipMemsetAsync(e->dgpart, 0, GACC_DOUBLES * sizeof(double), e->stream));
+  GradArgs a{};
+  a.p = e->cp;
+  a.pts = train_set(e);
+  a.Z = e->dA;
+  a.ldz = e->ld;
+  a.alpha = e->dalpha;
+  a.tiles = nt;
+  a.ard = s.ard;
+  a.nc_real = s.n_cont;
+  for (int k = 0; k < 16; ++k) a.inv_ls[k] = k < s.n_cont ? e->prep_proto.inv_ls[k] : 0.0;
+  const int n_ls = s.ard ? s.n_cont : 1;
+  a.eta = e->theta[n_ls];
+  a.acc = e->dgpart;
+  const int ntab = spec_ntab(s);
+  int off = 64;
+  for (int t = 0; t < ntab; ++t) {
+    a.tab_acc_off[t] = off;
+    off += e->cp.tab_levels[t] * e->cp.tab_levels[t];
+  }
+  const int diag_off = off;  // [sigma, noise table...]
+  const int nblocks = nt * (nt + 1) / 2;
+  switch (e->cp.kind) {
+    case GMB_EXPQUAD: rc = launch_grad_nc<0>(e, a, nblocks); break;
+    case GMB_MATERN52: rc = launch_grad_nc<1>(e, a, nblocks); break;
+    case GMB_MATERN32: rc = launch_grad_nc<2>(e, a, nblocks); break;
+    case GMB_MATERN12: rc = launch_grad_nc<3>(e, a, nblocks); break;
+    default: rc = launch_grad_nc<4>(e, a, nblocks); break;
+  }
+  if (rc) return rc;
+  const double sigma = e->theta[n_ls + 1];
+  hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->dalpha,
+                     train_set(e), e->cp, sigma, e->dgpart + diag_off);
+  HIP_TRY(e, hipGetLastError());
+  tg.stop();
+  std::vector<double> h(GACC_DOUBLES);
+  HIP_TRY(e, hipMemcpyAsync(h.data(), e->dgpart, GACC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
+                            e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  tm.grad_ms = tg.ms();
+  ev_collect(e);
+  // 5. chain rule back to the packed natural-scale parameters
+  const double* th = e->theta.data();
+  int k = 0;
+  for (int i = 0; i < n_ls; ++i) grad[k++] = h[i];
+  grad[k++] = h[n_ls];              // eta
+  grad[k++] = h[diag_off];          // sigma
+  if (s.n_lin > 0) {
+    for (int i = 0; i < s.n_lin; ++i) grad[k++] = h[n_ls + 2 + i];
+    grad[k++] = h[n_ls + 1];        // tau
+  }
+  for (int t = 0; t < ntab; ++t) {
+    const int L = e->cp.tab_levels[t];
+    const double* G = h.data() + a.tab_acc_off[t];
+    const double* W = th + k;
+    for (int x = 0; x < L; ++x)
+      for (int q = 0; q < 2; ++q) {
+        double acc = 0.0;
+        for (int b = 0; b < L; ++b) acc += (G[x * L + b] + G[b * L + x]) * W[2 * b + q];
+        grad[k + 2 * x + q] = acc;
+      }
+    for (int x = 0; x < L; ++x) grad[k + 2 * L + x] = G[x * L + x];
+    k += 3 * L;
+  }
+  if (s.out_col >= 0 && s.hetero_noise) {
+    const int P = s.n_out;
+    const double* W = th + k;
+    for (int x = 0; x < P; ++x) {
+      const double gd = h[diag_off + 1 + x];
+      grad[k + 2 * x] = 2.0 * gd * W[2 * x];
+      grad[k + 2 * x + 1] = 2.0 * gd * W[2 * x + 1];
+      grad[k + 2 * P + x] = gd;
+    }
+    k += 3 * P;
+  }
+  if (k != (int)e->theta.size()) return fail(e, GMB_EINVAL, "internal: gradient packing mismatch");
+  return GMB_OK;
+}
+
+int require_ready(gmb_engine* e, bool need_factor) {
+  if (!e) return GMB_EINVAL;
+  if (e->N <= 0) return fail(e, GMB_EINVAL, "gmb_set_data has not been called");
+  if (!e->have_spec) return fail(e, GMB_EINVAL, "gmb_set_kernel has not been called");
+  if (!e->have_theta) return fail(e, GMB_EINVAL, "gmb_set_theta has not been called");
+  if (need_factor && !e->factored)
+    return fail(e, GMB_EINVAL, "no valid factorisation: call gmb_factorize first");
+  return GMB_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int gmb_abi_version(void) { return GMB_ABI_VERSION; }
+
+int gmb_device_count(void) {
+  int n = 0;
+  hipError_t s = hipGetDeviceCount(&n);
+  if (s != hipSuccess || n <= 0) return GMB_ENODEVICE;
+  return n;
+}
+
+int gmb_create(gmb_engine** out, int32_t device, void* stream) {
+  if (!out) return GMB_EINVAL;
+  *out = nullptr;
+  int n = gmb_device_count();
+  if (n < 0) return GMB_ENODEVICE;
+  if (device < 0 || device >= n) return GMB_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) return GMB_EHIP;
+  gmb_engine* e = new gmb_engine();
+  e->device = device;
+  if (stream) {
+    e->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete e;
+      return GMB_EHIP;
+    }
+    e->own_stream = true;
+  }
+  const char* nl = getenv("GMB_LEAF_NAIVE");
+  e->naive_leaf = nl && nl[0] == '1';
+  if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
+    gmb_destroy(e);
+    return GMB_ENOMEM;
+  }
+  *out = e;
+  return GMB_OK;
+}
+
+void gmb_destroy(gmb_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  void* ptrs[] = {e->dX,   e->dy,   e->dA,   e->dInv,  e->xs,    e->xl,   e->cat,    e->dtabs,
+                  e->dnoise, e->dscal, e->dinfo, e->dv,  e->dV,    e->dXs,  e->txs,    e->txl,
+                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+const char* gmb_last_error(const gmb_engine* e) { return e ? e->err.c_str() : "null engine"; }
+void* gmb_stream(const gmb_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int gmb_theta_size(const gmb_kernel_spec* s) {
+  if (!s) return GMB_EINVAL;
+  int n = (s->ard ? s->n_cont : 1) + 2;
+  if (s->n_lin > 0) n += s->n_lin + 1;
+  for (int t = 0; t < s->n_coreg; ++t) n += 3 * s->coreg_levels[t];
+  if (s->out_col >= 0) {
+    n += 3 * s->n_out;
+    if (s->hetero_noise) n += 3 * s->n_out;
+  }
+  return n;
+}
+
+int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t ldx, const double* y,
+                 int32_t memspace) {
+  if (!e) return GMB_EINVAL;
+  if (!X || !y || N < 1 || D < 1 || ldx < D) return fail(e, GMB_EINVAL, "bad X/y/N/D/ldx");
+  if (e->have_spec) {
+    int rc = validate_spec(e, e->spec, D);
+    if (rc) return rc;
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  e->factored = false;
+  e->N = N;
+  e->D = D;
+  e->Np = round_up(N, TILE);
+  e->Nr = round_up(N + 1, TILE);
+  e->ld = e->Nr;
+  int rc;
+  if ((rc = alloc(e, &e->dX, N * (int64_t)D))) return rc;
+  if ((rc = alloc(e, &e->dy, e->Np))) return rc;
+  if ((rc = ensure(e, &e->dA, &e->cap_A, e->Nr * e->Np))) return rc;
+  if ((rc = ensure(e, &e->dInv, &e->cap_inv, (e->Np / TILE) * (int64_t)TILE * TILE))) return rc;
+  if ((rc = alloc(e, &e->dv, e->Np))) return rc;
+  const hipMemcpyKind kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIP_TRY(e, hipMemcpy2DAsync(e->dX, D * sizeof(double), X, ldx * sizeof(double), D * sizeof(double), N,
+                              kind, e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->dy, 0, e->Np * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->dy, y, N * sizeof(double), kind, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->cap_pts = 0;  // prepared coordinates must be rebuilt
+  e->have_theta = false;
+  return GMB_OK;
+}
+
+int gmb_set_kernel(gmb_engine* e, const gmb_kernel_spec* spec) {
+  if (!e || !spec) return GMB_EINVAL;
+  int rc = validate_spec(e, *spec, e->D);
+  if (rc) return rc;
+  e->spec = *spec;
+  e->have_spec = true;
+  e->have_theta = false;
+  e->factored = false;
+  e->nc_pad = pick_nc(spec->n_cont);
+  e->cap_pts = 0;
+  return GMB_OK;
+}
+
+int gmb_set_theta(gmb_engine* e, const double* theta, int32_t n) {
+  if (!e || !theta) return GMB_EINVAL;
+  if (!e->have_spec) return fail(e, GMB_EINVAL, "gmb_set_kernel must precede gmb_set_theta");
+  if (e->N <= 0) return fail(e, GMB_EINVAL, "gmb_set_data must precede gmb_set_theta");
+  if (n != gmb_theta_size(&e->spec))
+    return fail(e, GMB_EINVAL, "theta has %d entries, kernel needs %d", n, gmb_theta_size(&e->spec));
+  for (int i = 0; i < n; ++i)
+    if (!std::isfinite(theta[i])) return fail(e, GMB_EINVAL, "theta[%d] is not finite", i);
+  HIP_TRY(e, hipSetDevice(e->device));
+  e->theta.assign(theta, theta + n);
+  e->factored = false;
+  int rc = apply_theta(e);
+  if (rc) return rc;
+  if (e->cap_pts < e->Nr) {
+    if ((rc = alloc(e, &e->xs, (int64_t)16 * e->Nr))) return rc;
+    if ((rc = alloc(e, &e->xl, (int64_t)MAX_LIN * e->Nr))) return rc;
+    if ((rc = alloc(e, &e->cat, (int64_t)MAX_TABS * e->Nr))) return rc;
+    e->cap_pts = e->Nr;
+  }
+  rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat);
+  if (rc) return rc;
+  e->have_theta = true;
+  return GMB_OK;
+}
+
+int gmb_set_profiling(gmb_engine* e, int32_t on) {
+  if (!e) return GMB_EINVAL;
+  e->profiling = on != 0;
+  return GMB_OK;
+}
+
+int gmb_timings_get(const gmb_engine* e, gmb_timings* out) {
+  if (!e || !out) return GMB_EINVAL;
+  *out = e->tm;
+  return GMB_OK;
+}
+
+int64_t gmb_notpd_index(const gmb_engine* e) { return e ? e->notpd : -1; }
+
+int gmb_factorize(gmb_engine* e) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  e->factored = false;
+  e->factor_consumed = false;
+  e->notpd = -1;
+  gmb_timings& tm = e->tm;
+  tm.kbuild_ms = tm.chol_ms = tm.chol_gemm_ms = tm.chol_gemm_flops = 0.0;
+  tm.chol_leaf_ms = tm.chol_trsm_ms = 0.0;
+  tm.chol_gemm_launches = 0;
+  HIP_TRY(e, hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream));
+
+  // 1. covariance build: lower-triangular tiles of Sigma, y row, identity padding
+  PhaseTimer tk(e);
+  {
+    CovTileArgs a{};
+    a.p = e->cp;
+    a.rows = train_set(e);
+    a.cols = PointSet{e->xs, e->xl, e->cat, e->N, e->Nr};
+    a.out = e->dA;
+    a.ldo = e->ld;
+    a.i0 = a.j0 = 0;
+    a.ti = (int)(e->Nr / TILE);
+    a.tj = (int)(e->Np / TILE);
+    a.mode = COV_TRAIN;
+    a.lower_only = 1;
+    a.y = e->dy;
+    if ((rc = launch_cov(e, a))) return rc;
+  }
+  tk.stop();
+  // 2. Cholesky
+  PhaseTimer tc(e);
+  if ((rc = chol_cols(e, 0, (int)(e->Np / TILE)))) return rc;
+  // 3. v = L^-1 y is row N of the factor
+  hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
+                     e->dscal + 1);
+  tc.stop();
+  HIP_TRY(e, hipGetLastError());
+  double hs[2];
+  int32_t info = 0;
+  HIP_TRY(e, hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  tm.kbuild_ms = tk.ms();
+  tm.chol_ms = tc.ms();
+  tm.kbuild_bytes = 8.0 * (double)e->N * (double)(e->N + 1) / 2.0 +
+                    8.0 * (double)e->N * (double)(e->spec.n_cont + 1);
+  ev_collect(e);
+  if (info != 0) {
+    e->notpd = (int64_t)info - 1;
+    return fail(e, GMB_ENOTPD, "covariance matrix is not positive definite at row %lld",
+                (long long)e->notpd);
+  }
+  e->logdet = hs[0];
+  e->vnorm2 = hs[1];
+  if (!std::isfinite(e->logdet) || !std::isfinite(e->vnorm2)) {
+    e->notpd = 0;
+    return fail(e, GMB_ENOTPD, "factorisation produced non-finite values");
+  }
+  e->factored = true;
+  return GMB_OK;
+}
+
+int gmb_nlml(gmb_engine* e, double* nlml, double* grad) {
+  int rc = require_ready(e, true);
+  if (rc) return rc;
+  if (!nlml) return fail(e, GMB_EINVAL, "nlml output pointer is null");
+  *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
+  if (grad) return grad_impl(e, grad);
+  return GMB_OK;
+}
+
+int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_t with_noise,
+                double* mean, double* var, int32_t memspace) {
+  int rc = require_ready(e, true);
+  if (rc) return rc;
+  if (M < 0 || (M > 0 && (!Xs || !mean || !var)) || ldxs < e->D)
+    return fail(e, GMB_EINVAL, "bad Xs/M/ldxs/mean/var");
+  if (M == 0) return GMB_OK;
+  if (e->factor_consumed)
+    return fail(e, GMB_EINVAL, "the factor was consumed by a gradient call: call gmb_factorize again");
+  HIP_TRY(e, hipSetDevice(e->device));
+  gmb_timings& tm = e->tm;
+  tm.predict_ms = tm.predict_gemm_ms = tm.predict_gemm_flops = 0.0;
+  tm.predict_gemm_launches = 0;
+
+  // tile M so that the solved cross-covariance (Mt x Np doubles) stays within ~8 GiB
+  int64_t mt_max = (int64_t)(8.0 * 1024 * 1024 * 1024 / 8.0 / (double)e->Np);
+  mt_max = std::max<int64_t>(TILE, std::min<int64_t>(mt_max / TILE * TILE, 32768));
+  const int64_t Mt = std::min<int64_t>(round_up(M, TILE), mt_max);
+  if (e->Mt_cap < Mt) {
+    if ((rc = alloc(e, &e->dV, Mt * e->Np))) return rc;
+    if ((rc = alloc(e, &e->dXs, Mt * (int64_t)e->D))) return rc;
+    if ((rc = alloc(e, &e->txs, (int64_t)16 * Mt))) return rc;
+    if ((rc = alloc(e, &e->txl, (int64_t)MAX_LIN * Mt))) return rc;
+    if ((rc = alloc(e, &e->tcat, (int64_t)MAX_TABS * Mt))) return rc;
+    if ((rc = alloc(e, &e->dkss, Mt))) return rc;
+    if ((rc = alloc(e, &e->dmean, Mt))) return rc;
+    if ((rc = alloc(e, &e->dvar, Mt))) return rc;
+    e->Mt_cap = Mt;
+  }
+  const int nchunk = (int)((e->N + RED_CHUNK - 1) / RED_CHUNK);
+  if ((rc = ensure(e, &e->dpart, &e->cap_part, (int64_t)2 * nchunk * e->Mt_cap))) return rc;
+
+  const hipMemcpyKind in_kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const hipMemcpyKind out_kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  PhaseTimer tp(e);
+  for (int64_t m0 = 0; m0 < M; m0 += Mt) {
+    const int64_t mc = std::min<int64_t>(Mt, M - m0);
+    const int64_t mpad = round_up(mc, TILE);
+    HIP_TRY(e, hipMemcpy2DAsync(e->dXs, e->D * sizeof(double), Xs + m0 * ldxs, ldxs * sizeof(double),
+                                e->D * sizeof(double), mc, in_kind, e->stream));
+    if ((rc = prep_points(e, e->dXs, mc, e->D, mpad, e->txs, e->txl, e->tcat))) return rc;
+    const PointSet test{e->txs, e->txl, e->tcat, mc, mpad};
+    {  // cross-covariance W[m + i*mpad] = k(x*_m, x_i)
+      CovTileArgs a{};
+      a.p = e->cp;
+      a.rows = test;
+      a.cols = train_set(e);
+      a.out = e->dV;
+      a.ldo = mpad;
+      a.ti = (int)(mpad / TILE);
+      a.tj = (int)(e->Np / TILE);
+      a.mode = COV_CROSS;
+      if ((rc = launch_cov(e, a))) return rc;
+    }
+    if ((rc = trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, (int)(e->Np / TILE)))) return rc;
+    {
+      KssArgs k{};
+      k.p = e->cp;
+      k.pts = test;
+      k.with_noise = with_noise;
+      k.kss = e->dkss;
+      hipLaunchKernelGGL(kss_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, e->stream, k);
+      double* pmu = e->dpart;
+      double* ps = e->dpart + (int64_t)nchunk * mpad;
+      hipLaunchKernelGGL(predict_partial_kernel, dim3((unsigned)(mpad / 256 + (mpad % 256 ? 1 : 0)), nchunk),
+                         dim3(256), 0, e->stream, e->dV, mpad, e->dv, e->N, pmu, ps, mpad);
+      hipLaunchKernelGGL(predict_final_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, e->stream,
+                         pmu, ps, nchunk, mpad, e->dkss, mc, e->dmean, e->dvar);
+      HIP_TRY(e, hipGetLastError());
+    }
+    HIP_TRY(e, hipMemcpyAsync(mean + m0, e->dmean, mc * sizeof(double), out_kind, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(var + m0, e->dvar, mc * sizeof(double), out_kind, e->stream));
+  }
+  tp.stop();
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  tm.predict_ms = tp.ms();
+  ev_collect(e);
+  return GMB_OK;
+}
+
+int gmb_copy_factor(const gmb_engine* ce, int64_t r0, int64_t nr, int64_t c0, int64_t nc, double* out) {
+  gmb_engine* e = const_cast<gmb_engine*>(ce);
+  if (!e || !out) return GMB_EINVAL;
+  if (!e->dA || r0 < 0 || c0 < 0 || nr < 0 || nc < 0 || r0 + nr > e->Nr || c0 + nc > e->Np)
+    return fail(e, GMB_EINVAL, "factor window out of range");
+  if (nr == 0 || nc == 0) return GMB_OK;
+  std::vector<double> tmp((size_t)nr * nc);  // column-major window
+  HIP_TRY(e, hipMemcpy2D(tmp.data(), nr * sizeof(double), e->dA + r0 + c0 * e->ld, e->ld * sizeof(double),
+                         nr * sizeof(double), nc, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < nr; ++i)
+    for (int64_t j = 0; j < nc; ++j) out[i * nc + j] = tmp[(size_t)j * nr + i];
+  return GMB_OK;
+}
+
+int gmb_copy_v(const gmb_engine* ce, double* out) {
+  gmb_engine* e = const_cast<gmb_engine*>(ce);
+  int rc = require_ready(e, true);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpy(out, e->dv, e->N * sizeof(double), hipMemcpyDeviceToHost));
+  return GMB_OK;
+}
+
+int gmb_ls_limits(int32_t device, const double* X, int64_t N, int32_t n_cols, int64_t ldx, int32_t ard,
+                  double* lower, double* upper) {
+  if (!X || !lower || !upper || N < 1 || n_cols < 1 || n_cols > GMB_MAX_DIMS || ldx < n_cols)
+    return GMB_EINVAL;
+  int nd = gmb_device_count();
+  if (nd < 0) return GMB_ENODEVICE;
+  if (device < 0 || device >= nd) return GMB_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) return GMB_EHIP;
+  const int64_t npad = round_up(N, TILE);
+  const int ngroups = ard ? n_cols : 1, gw = ard ? 1 : n_cols;
+  std::vector<double> soa((size_t)n_cols * npad, 0.0);
+  for (int64_t i = 0; i < N; ++i)
+    for (int k = 0; k < n_cols; ++k) soa[(size_t)k * npad + i] = X[i * ldx + k];
+  double* dpts = nullptr;
+  unsigned long long *dmn = nullptr, *dmx = nullptr;
+  int rc = GMB_OK;
+  std::vector<unsigned long long> hmn(ngroups, ~0ull), hmx(ngroups, 0ull);
+  if (hipMalloc((void**)&dpts, soa.size() * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&dmn, ngroups * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void**)&dmx, ngroups * sizeof(unsigned long long)) != hipSuccess) {
+    rc = GMB_ENOMEM;
+  } else if (hipMemcpy(dpts, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(dmn, hmn.data(), ngroups * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(dmx, hmx.data(), ngroups * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess) {
+    rc = GMB_EHIP;
+  } else {
+    const int tiles = (int)(npad / TILE);
+    const int64_t npairs = (int64_t)tiles * (tiles + 1) / 2;
+    hipLaunchKernelGGL(ls_limits_kernel, dim3((unsigned)npairs, ngroups), dim3(256), 0, 0, dpts, N, npad, gw,
+                       dmn, dmx, tiles);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(hmn.data(), dmn, ngroups * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(hmx.data(), dmx, ngroups * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = GMB_EHIP;
+  }
+  if (dpts) (void)hipFree(dpts);
+  if (dmn) (void)hipFree(dmn);
+  if (dmx) (void)hipFree(dmx);
+  if (rc) return rc;
+  for (int g = 0; g < ngroups; ++g) {
+    if (hmn[g] == ~0ull) {
+      lower[g] = -1.0;
+      upper[g] = -1.0;
+    } else {
+      double lo, hi;
+      memcpy(&lo, &hmn[g], 8);
+      memcpy(&hi, &hmx[g], 8);
+      lower[g] = std::sqrt(lo);
+      upper[g] = std::sqrt(hi);
+    }
+  }
+  return GMB_OK;
+}
+
+int gmb_mfma_f64_peak(int32_t device, double* tflops) {
+  if (!tflops) return GMB_EINVAL;
+  int nd = gmb_device_count();
+  if (nd < 0) return GMB_ENODEVICE;
+  if (device < 0 || device >= nd) return GMB_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) return GMB_EHIP;
+  double* sink = nullptr;
+  if (hipMalloc((void**)&sink, 8) != hipSuccess) return GMB_ENOMEM;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  const int blocks = 256 * 8, iters = 4000;
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100);  // warm-up
+  (void)hipEventRecord(a, 0);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters);
+  (void)hipEventRecord(b, 0);
+  int rc = GMB_OK;
+  if (hipEventSynchronize(b) != hipSuccess || hipGetLastError() != hipSuccess) rc = GMB_EHIP;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(sink);
+  if (rc) return rc;
+  const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  *tflops = flops / ((double)ms * 1e-3) / 1e12;
+  return GMB_OK;
+}
+
+// ---- block-level operations (multi-GPU driver) ---------------------------------------------
+int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, double* invLkk,
+                  double* logdet_accum, int32_t* info) {
+  if (!e || !Akk || nvalid < 1 || nvalid > TILE || lda < TILE) return fail(e, GMB_EINVAL, "bad potrf block");
+  HIP_TRY(e, hipSetDevice(e->device));
+  LeafArgs a;
+  a.A = Akk;
+  a.lda = lda;
+  a.nvalid = nvalid;
+  a.invL = invLkk;
+  a.logdet = logdet_accum;
+  a.info = info ? info : e->dinfo;
+  a.row0 = 0;
+  return launch_leaf(e, a);
+}
+
+int gmb_blk_gemm_nt(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                    int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, int32_t tri,
+                    int64_t tri_shift) {
+  if (!e || !C || !A || !B) return fail(e, GMB_EINVAL, "null gemm operand");
+  if (m % TILE || n % TILE || k % KT || m < 0 || n < 0 || k < 0)
+    return fail(e, GMB_EINVAL, "gemm sizes must be multiples of 128 (m, n) and 16 (k)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  GemmArgs g{};
+  g.C = C;
+  g.ldc = ldc;
+  g.A = A;
+  g.lda = lda;
+  g.B = B;
+  g.ldb = ldb;
+  g.mt = (int)(m / TILE);
+  g.nt = (int)(n / TILE);
+  g.k = (int)k;
+  g.alpha = alpha;
+  g.beta = beta;
+  g.tri = tri;
+  g.tri_shift = (int)tri_shift;
+  return launch_gemm(e, g, 0);
+}
+
+int gmb_blk_kbuild(gmb_engine* e, double* out, int64_t ldo, int64_t i0, int64_t ni, int64_t j0, int64_t nj) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  if (!out || i0 % TILE || j0 % TILE || ni % TILE || nj % TILE || i0 < 0 || j0 < 0 || i0 + ni > e->Nr ||
+      j0 + nj > e->Np || ldo < ni)
+    return fail(e, GMB_EINVAL, "kbuild window must be 128-aligned and inside the padded matrix");
+  HIP_TRY(e, hipSetDevice(e->device));
+  CovTileArgs a{};
+  a.p = e->cp;
+  a.rows = train_set(e);
+  a.cols = train_set(e);
+  a.out = out;
+  a.ldo = ldo;
+  a.i0 = i0;
+  a.j0 = j0;
+  a.ti = (int)(ni / TILE);
+  a.tj = (int)(nj / TILE);
+  a.mode = COV_TRAIN;
+  a.lower_only = 1;
+  a.y = e->dy;
+  return launch_cov(e, a);
+}
+
+}  // extern "C"

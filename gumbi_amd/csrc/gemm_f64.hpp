@@ -1,0 +1,221 @@
+// gemm_f64.hpp -- the one dense contraction of the GP hot path, on gfx950 f64 MFMA.
+//
+//   C[n + m*ldc] = beta * C[n + m*ldc] + alpha * sum_{k in [k_lo, k_hi)} Aop(m,k) * Bop(n,k)
+//
+// with every matrix column-major.  Aop(m,k) = A[m + k*lda] (TA = false, "k-major": consecutive
+// m contiguous for a fixed k) or A[k + m*lda] (TA = true); Bop likewise.  Users:
+//   * Cholesky trailing update (SYRK/GEMM):  A = B = factored panel, C = trailing block,
+//     alpha = -1, beta = 1, tri = 1 (tiles strictly above the diagonal are skipped);
+//   * panel / predict triangular solves:     A = inv(L_kk) (128 x 128), C aliases B,
+//     alpha = 1, beta = 0;
+//   * predict forward-substitution update:   A = L block row, B = solved V columns;
+//   * NLML gradient: L^-1 by recursive block inversion and Sigma^-1 = L^-T L^-1 (TA/TB forms,
+//     per-tile k ranges that skip the structurally zero part of the triangular operands).
+//
+// Replaces the LAPACK dpotrf/dtrsm/dpotri calls PyTensor's Cholesky / SolveTriangular ops (and
+// their gradients) make under pm.gp.Marginal (call sites gumbi/regression/pymc/GP.py:580, 811,
+// 845-847).
+//
+// Tiling (MI355X, wave64): 256 threads = 4 waves, block tile 128(m) x 128(n), each wave a
+// 64 x 64 quadrant = 4 x 4 v_mfma_f64_16x16x4_f64 tiles (16 accumulators x 4 f64 per lane).
+// Operands are staged through LDS in [k][row] order with a row pitch of 128+16 doubles so that
+// the two k-slices a 32-lane group reads (ds_read_b64, 64 banks x 4 B) fall on disjoint banks.
+// Global loads are 16 B per lane along the contiguous index, one k-tile ahead of the MFMAs
+// (register-staged double buffer, one barrier per k-tile).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmb {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int TILE = 128;         // block tile edge (both m and n)
+constexpr int KT = 16;            // k extent of one LDS stage
+constexpr int PITCH = TILE + 16;  // LDS row pitch in doubles: PITCH % 32 == 16 -> conflict-free
+
+struct GemmArgs {
+  double* C;
+  int64_t ldc;
+  const double* A;
+  int64_t lda;
+  const double* B;
+  int64_t ldb;
+  int32_t mt, nt;  // tile counts along m and n
+  int32_t k;       // multiple of KT
+  double alpha, beta;
+  int32_t tri;        // skip tile (tm, tn) when tn + tri_shift < tm
+  int32_t tri_shift;  // in tiles
+  // per-tile contraction range (in units of TILE): k_lo = (klo_m*tm + klo_n*tn)*TILE,
+  // k_hi = khi_n ? min(k, (tn+1)*TILE) : k
+  int32_t klo_m, klo_n, khi_n;
+  int32_t ta, tb;  // operand layouts (see header comment)
+};
+
+// XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous
+// run of tiles so neighbouring tiles (which share an A panel) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
+  __shared__ double lds[2][2][KT][PITCH];  // [stage][A|B][k][row]  = 73,728 B
+
+  const int nwg = g.mt * g.nt;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int tm = wg / g.nt;
+  const int tn = wg - tm * g.nt;
+  if (g.tri && tn + g.tri_shift < tm) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  int k_lo = (g.klo_m * tm + g.klo_n * tn) * TILE;
+  int k_hi = g.k;
+  if (g.khi_n) k_hi = min(k_hi, (tn + 1) * TILE);
+  if (k_lo > k_hi) k_lo = k_hi;
+
+  // per-thread staging coordinates
+  //   k-major operand: wave w brings k-rows w, w+4, w+8, w+12; lane covers 2 consecutive rows
+  //   transposed operand: thread covers row (tid>>3)+32p and 2 consecutive k at (tid&7)*2
+  const double* __restrict__ Ag =
+      TA ? g.A + (int64_t)(tm * TILE + (tid >> 3)) * g.lda + 2 * (tid & 7)
+         : g.A + (int64_t)tm * TILE + 2 * lane;
+  const double* __restrict__ Bg =
+      TB ? g.B + (int64_t)(tn * TILE + (tid >> 3)) * g.ldb + 2 * (tid & 7)
+         : g.B + (int64_t)tn * TILE + 2 * lane;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  d2 ra[4], rb[4];
+  const int kt0 = k_lo / KT, kt1 = k_hi / KT;
+
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if constexpr (TA) {
+        ra[p] = *reinterpret_cast<const d2*>(Ag + (int64_t)kt * KT + (int64_t)(32 * p) * g.lda);
+      } else {
+        ra[p] = *reinterpret_cast<const d2*>(Ag + ((int64_t)kt * KT + wave + 4 * p) * g.lda);
+      }
+      if constexpr (TB) {
+        rb[p] = *reinterpret_cast<const d2*>(Bg + (int64_t)kt * KT + (int64_t)(32 * p) * g.ldb);
+      } else {
+        rb[p] = *reinterpret_cast<const d2*>(Bg + ((int64_t)kt * KT + wave + 4 * p) * g.ldb);
+      }
+    }
+  };
+  auto lstore = [&](int st) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if constexpr (TA) {
+        lds[st][0][2 * (tid & 7)][(tid >> 3) + 32 * p] = ra[p][0];
+        lds[st][0][2 * (tid & 7) + 1][(tid >> 3) + 32 * p] = ra[p][1];
+      } else {
+        *reinterpret_cast<d2*>(&lds[st][0][wave + 4 * p][2 * lane]) = ra[p];
+      }
+      if constexpr (TB) {
+        lds[st][1][2 * (tid & 7)][(tid >> 3) + 32 * p] = rb[p][0];
+        lds[st][1][2 * (tid & 7) + 1][(tid >> 3) + 32 * p] = rb[p][1];
+      } else {
+        *reinterpret_cast<d2*>(&lds[st][1][wave + 4 * p][2 * lane]) = rb[p];
+      }
+    }
+  };
+
+  if (kt0 < kt1) {
+    gload(kt0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int st = (kt - kt0) & 1;
+      if (kt + 1 < kt1) gload(kt + 1);
+#pragma unroll
+      for (int k4 = 0; k4 < KT; k4 += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = lds[st][0][k4 + kq][wm * 64 + i * 16 + r16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = lds[st][1][k4 + kq][wn * 64 + j * 16 + r16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < kt1) lstore(st ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // epilogue.  v_mfma_f64_16x16x4_f64 D layout: n = lane & 15, m = (lane >> 4) + 4 * reg.
+  double* __restrict__ Cg = g.C + (int64_t)tn * TILE + wn * 64 + r16;
+  const int64_t m0 = (int64_t)tm * TILE + wm * 64 + kq;
+  if (g.beta == 0.0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* row = Cg + (m0 + i * 16 + 4 * r) * g.ldc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row[j * 16] = g.alpha * acc[i][j][r];
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* row = Cg + (m0 + i * 16 + 4 * r) * g.ldc;
+        double c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = row[j * 16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row[j * 16] = g.beta * c[j] + g.alpha * acc[i][j][r];
+      }
+  }
+}
+
+// MFMA-only microbenchmark: `iters` rounds of 8 independent v_mfma_f64_16x16x4_f64 per wave, no
+// memory traffic -- measures the f64 matrix peak the roofline is priced against.
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* sink, int iters) {
+  d4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) sink[0] = s;  // keep the chain alive without a store on the timed path
+}
+
+// flops the kernel actually performs (computed tiles x their k ranges), for roofline accounting
+inline double gemm_flops(const GemmArgs& g) {
+  double f = 0.0;
+  for (int tm = 0; tm < g.mt; ++tm)
+    for (int tn = 0; tn < g.nt; ++tn) {
+      if (g.tri && tn + g.tri_shift < tm) continue;
+      int k_lo = (g.klo_m * tm + g.klo_n * tn) * TILE;
+      int k_hi = g.k;
+      if (g.khi_n && (tn + 1) * TILE < k_hi) k_hi = (tn + 1) * TILE;
+      if (k_hi > k_lo) f += 2.0 * TILE * TILE * (double)(k_hi - k_lo);
+    }
+  return f;
+}
+
+}  // namespace gmb

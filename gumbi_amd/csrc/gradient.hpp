@@ -1,0 +1,233 @@
+// gradient.hpp -- fused trace reductions for the NLML gradient
+//
+//   d NLML / d theta = sum_ij M_ij * dSigma_ij/dtheta,   M = 1/2 (Sigma^-1 - alpha alpha^T)
+//
+// PyMC gets this by reverse-mode autodiff through its Cholesky op inside pm.find_MAP (call site
+// gumbi/regression/pymc/GP.py:811); here Sigma^-1 (lower triangle, column-major, from the MFMA
+// GEMMs in engine.hip) is streamed ONCE from HBM and every per-parameter partial is reduced in
+// the same pass -- distances and kernel values are recomputed from the LDS-staged coordinates
+// instead of being re-read.  Off-diagonal entries are visited once (i > j) with weight 2.
+//
+// Accumulator layout (doubles) in `acc`:
+//   [0, NC)            d/d ls_k   (ARD)  or [0] d/d ls (shared)      -- natural-scale lengthscales
+//   [NC]               d/d eta
+//   [NC+1]             d/d tau
+//   [NC+2, +n_lin)     d/d c_k
+//   then per coregion table t: L_t*L_t entries G_t[a][b] = sum M_ij * K_ij / B_t[a,b]
+// The diagonal-only terms (sigma, noise table) come from grad_diag_kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "covariance.hpp"
+
+namespace gmb {
+
+struct GradArgs {
+  CovParams p;
+  PointSet pts;
+  const double* Z;  // Sigma^-1, lower triangle valid, column-major
+  int64_t ldz;
+  const double* alpha;
+  int32_t tiles;    // tiles per side (N rounded up / 128)
+  int32_t ard;
+  int32_t nc_real;
+  double inv_ls[16];
+  double eta;
+  double* acc;      // global accumulators (atomicAdd)
+  int32_t tab_acc_off[MAX_TABS];
+};
+
+constexpr int GRAD_MAX_LDS_ACC = 16 + 2 + MAX_LIN + MAX_TABS * 64;  // tables up to 8 levels in LDS
+
+template <int KIND, int NC>
+__global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
+  __shared__ double xj[NC][TILE];
+  __shared__ double lj[MAX_LIN][TILE];
+  __shared__ double li[MAX_LIN][TILE];
+  __shared__ int32_t cj[MAX_TABS][TILE];
+  __shared__ int32_t ci[MAX_TABS][TILE];
+  __shared__ double aj[TILE];
+  __shared__ double sacc[GRAD_MAX_LDS_ACC];
+
+  // lower-triangle tile pair (ti >= tj)
+  int tjx = 0, rem = blockIdx.x;
+  while (rem >= a.tiles - tjx) {
+    rem -= a.tiles - tjx;
+    ++tjx;
+  }
+  const int tix = tjx + rem;
+  const int64_t gi0 = (int64_t)tix * TILE, gj0 = (int64_t)tjx * TILE;
+  const int tid = threadIdx.x;
+  const int il = tid & (TILE - 1), jh = tid >> 7;
+  const int64_t gi = gi0 + il;
+  const CovParams& p = a.p;
+  const int n_acc_small = NC + 2 + p.n_lin;
+
+  for (int idx = tid; idx < GRAD_MAX_LDS_ACC; idx += 256) sacc[idx] = 0.0;
+  for (int idx = tid; idx < NC * TILE; idx += 256) {
+    const int k = idx / TILE, j = idx - k * TILE;
+    xj[k][j] = a.pts.xs[(int64_t)k * a.pts.npad + gj0 + j];
+  }
+  for (int idx = tid; idx < p.n_lin * TILE; idx += 256) {
+    const int k = idx / TILE, j = idx - k * TILE;
+    lj[k][j] = a.pts.xl[(int64_t)k * a.pts.npad + gj0 + j];
+    li[k][j] = a.pts.xl[(int64_t)k * a.pts.npad + gi0 + j];
+  }
+  for (int idx = tid; idx < p.n_tab * TILE; idx += 256) {
+    const int t = idx / TILE, j = idx - t * TILE;
+    cj[t][j] = a.pts.cat[(int64_t)t * a.pts.npad + gj0 + j];
+    ci[t][j] = a.pts.cat[(int64_t)t * a.pts.npad + gi0 + j];
+  }
+  if (tid < TILE) aj[tid] = (gj0 + tid < a.pts.n) ? a.alpha[gj0 + tid] : 0.0;
+  double xi[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) xi[k] = a.pts.xs[(int64_t)k * a.pts.npad + gi];
+  const bool row_real = gi < a.pts.n;
+  const double ai = row_real ? a.alpha[gi] : 0.0;
+  __syncthreads();
+
+  double g_ls[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) g_ls[k] = 0.0;
+  double g_eta = 0.0, g_tau = 0.0;
+
+  const double* zp = a.Z + gi + (gj0 + jh * (TILE / 2)) * a.ldz;
+  for (int jj = 0; jj < TILE / 2; ++jj) {
+    const int j = jh * (TILE / 2) + jj;
+    const int64_t gj = gj0 + j;
+    if (!row_real || gj >= a.pts.n || gj > gi) continue;
+    const double mfull = 0.5 * (zp[(int64_t)jj * a.ldz] - ai * aj[j]);  // M_ij
+    const double m = (gi == gj) ? mfull : 2.0 * mfull;                   // (i,j) and (j,i)
+    double d2[NC];
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const double d = xi[k] - xj[k][j];
+      d2[k] = d * d;
+      r2 += d2[k];
+    }
+    const double ks = stationary<KIND>(r2);
+    const double dk = p.eta2 * stationary_dr2<KIND>(r2);
+    double lin = 0.0;
+    for (int k = 0; k < p.n_lin; ++k) lin = fma(li[k][il], lj[k][j], lin);
+    double F = 1.0;
+    for (int t = 0; t < p.n_tab; ++t)
+      F *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
+    const double mF = m * F;
+    // d r2 / d ls_k = -2 d2_k / ls_k   (d2 already in scaled units)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) g_ls[k] = fma(mF * dk, -2.0 * d2[k] * a.inv_ls[k], g_ls[k]);
+    g_eta = fma(mF, 2.0 * a.eta * ks, g_eta);
+    if (p.n_lin > 0) {
+      g_tau = fma(mF, lin, g_tau);
+      for (int k = 0; k < p.n_lin; ++k)
+        atomicAdd(&sacc[NC + 2 + k], -mF * p.tau * (li[k][il] + lj[k][j]));
+    }
+    if (p.n_tab > 0) {
+      const double base = p.eta2 * ks + p.tau * lin;
+      for (int t = 0; t < p.n_tab; ++t) {
+        double others = 1.0;
+        for (int t2 = 0; t2 < p.n_tab; ++t2)
+          if (t2 != t) others *= p.tabs[p.tab_off[t2] + ci[t2][il] * p.tab_levels[t2] + cj[t2][j]];
+        const int L = p.tab_levels[t];
+        const double val = mfull * base * others;
+        // ordered pair (i,j) feeds G[a][b]; its mirror (j,i) feeds G[b][a] (off-diagonal only)
+        const int ca = ci[t][il], cb = cj[t][j];
+        const bool off = gi != gj;
+        if (L <= 8) {
+          atomicAdd(&sacc[n_acc_small + t * 64 + ca * L + cb], val);
+          if (off) atomicAdd(&sacc[n_acc_small + t * 64 + cb * L + ca], val);
+        } else {
+          atomicAdd(&a.acc[a.tab_acc_off[t] + ca * L + cb], val);
+          if (off) atomicAdd(&a.acc[a.tab_acc_off[t] + cb * L + ca], val);
+        }
+      }
+    }
+  }
+  // block reduction of the register accumulators
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    double v = g_ls[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((tid & 63) == 0) atomicAdd(&sacc[k], v);
+  }
+  {
+    double v = g_eta, u = g_tau;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      v += __shfl_down(v, off);
+      u += __shfl_down(u, off);
+    }
+    if ((tid & 63) == 0) {
+      atomicAdd(&sacc[NC], v);
+      atomicAdd(&sacc[NC + 1], u);
+    }
+  }
+  __syncthreads();
+  // flush: ARD keeps one slot per dim; shared lengthscale sums all dims into slot 0
+  if (tid < NC) {
+    if (a.ard) {
+      if (tid < a.nc_real) atomicAdd(&a.acc[tid], sacc[tid]);
+    } else if (tid == 0) {
+      double s = 0.0;
+      for (int k = 0; k < NC; ++k) s += sacc[k];
+      atomicAdd(&a.acc[0], s);
+    }
+  }
+  const int n_ls_out = a.ard ? a.nc_real : 1;
+  if (tid == 0) {
+    atomicAdd(&a.acc[n_ls_out], sacc[NC]);
+    atomicAdd(&a.acc[n_ls_out + 1], sacc[NC + 1]);
+  }
+  if (tid < p.n_lin) atomicAdd(&a.acc[n_ls_out + 2 + tid], sacc[NC + 2 + tid]);
+  for (int t = 0; t < p.n_tab; ++t) {
+    const int L = p.tab_levels[t];
+    if (L <= 8 && tid < L * L) {
+      const double v = sacc[n_acc_small + t * 64 + tid];
+      if (v != 0.0) atomicAdd(&a.acc[a.tab_acc_off[t] + tid], v);
+    }
+  }
+}
+
+// Diagonal-only terms: d/d sigma and the noise-table partials.
+//   out[0] += sum_i M_ii * 2 sigma * nmult_i ;  out[1 + a] += sum_{i: out(i) = a} M_ii * sigma^2
+__global__ __launch_bounds__(256) void grad_diag_kernel(const double* Z, int64_t ldz,
+                                                        const double* alpha, PointSet pts,
+                                                        CovParams p, double sigma, double* out) {
+  __shared__ double red[4];
+  double gs = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pts.n; i += (int64_t)gridDim.x * 256) {
+    const double a = alpha[i];
+    const double m = 0.5 * (Z[i + i * ldz] - a * a);
+    double mult = 1.0;
+    if (p.noise_tab >= 0) {
+      const int c = pts.cat[(int64_t)p.noise_tab * pts.npad + i];
+      mult = p.noise_mult[c];
+      atomicAdd(&out[1 + c], m * sigma * sigma);
+    }
+    gs = fma(m, 2.0 * sigma * mult, gs);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gs += __shfl_down(gs, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gs;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[0], red[0] + red[1] + red[2] + red[3]);
+}
+
+// alpha = W^T v with W = L^-1 lower triangular, column-major: alpha_j = sum_{k>=j} W[k + j*ld] v_k
+__global__ __launch_bounds__(256) void wt_v_kernel(const double* W, int64_t ld, const double* v,
+                                                   int64_t n, double* alpha) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+  if (j >= n) return;
+  const double* col = W + j * ld;
+  double s = 0.0;
+  for (int64_t k = j + lane; k < n; k += 64) s = fma(col[k], v[k], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) alpha[j] = s;
+}
+
+}  // namespace gmb

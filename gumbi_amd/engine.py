@@ -1,0 +1,410 @@
+"""ctypes binding of ``libgumbi_hip.so`` (C ABI in ``include/gumbi_hip.h``).
+
+This is the only door between the Python front end and the numerics: there is no Python / numpy
+implementation of the covariance build, the Cholesky factorisation or the posterior solves in
+this package.  If the shared library is missing or no HIP device is present every call raises --
+the product path never falls back to the CPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+__all__ = ["Engine", "KernelSpec", "GumbiHipError", "library_path", "load_library", "KERNEL_KINDS",
+           "ls_limits"]
+
+GMB_MAX_DIMS, GMB_MAX_LIN, GMB_MAX_COREG, GMB_MAX_LEVELS = 16, 8, 4, 32
+GMB_OK, GMB_EINVAL, GMB_ENOMEM, GMB_EHIP, GMB_ENOTPD, GMB_ENODEVICE = 0, -1, -2, -3, -4, -5
+GMB_HOST, GMB_DEVICE = 0, 1
+
+# pm.gp.cov names accepted by PymcGP._construct_kernels (gumbi/regression/pymc/GP.py:664-674)
+KERNEL_KINDS = {"ExpQuad": 0, "Matern52": 1, "Matern32": 2, "Matern12": 3, "Exponential": 4}
+
+
+class GumbiHipError(RuntimeError):
+    """A libgumbi_hip call failed (bad HIP state, missing device, out of memory ...)."""
+
+
+class _Spec(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("ard", C.c_int32),
+        ("n_cont", C.c_int32),
+        ("idx_cont", C.c_int32 * GMB_MAX_DIMS),
+        ("n_lin", C.c_int32),
+        ("idx_lin", C.c_int32 * GMB_MAX_LIN),
+        ("n_coreg", C.c_int32),
+        ("coreg_col", C.c_int32 * GMB_MAX_COREG),
+        ("coreg_levels", C.c_int32 * GMB_MAX_COREG),
+        ("out_col", C.c_int32),
+        ("n_out", C.c_int32),
+        ("hetero_noise", C.c_int32),
+        ("jitter", C.c_double),
+    ]
+
+
+class Timings(C.Structure):
+    _fields_ = [
+        ("kbuild_ms", C.c_double),
+        ("chol_ms", C.c_double),
+        ("chol_gemm_ms", C.c_double),
+        ("chol_gemm_flops", C.c_double),
+        ("chol_gemm_launches", C.c_int64),
+        ("chol_leaf_ms", C.c_double),
+        ("chol_trsm_ms", C.c_double),
+        ("predict_ms", C.c_double),
+        ("predict_gemm_ms", C.c_double),
+        ("predict_gemm_flops", C.c_double),
+        ("predict_gemm_launches", C.c_int64),
+        ("grad_ms", C.c_double),
+        ("grad_gemm_ms", C.c_double),
+        ("grad_gemm_flops", C.c_double),
+        ("kbuild_bytes", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+@dataclass
+class KernelSpec:
+    """Which columns of X feed which covariance term (mirror of ``gmb_kernel_spec``)."""
+
+    D: int
+    idx_cont: list
+    kind: str | int = "ExpQuad"
+    ard: bool = True
+    idx_lin: list = field(default_factory=list)
+    coreg: list = field(default_factory=list)  # [(column, n_levels), ...]
+    out_col: int = -1
+    n_out: int = 0
+    hetero_noise: bool = True
+    jitter: float = 1e-6
+
+    @property
+    def kind_id(self) -> int:
+        if isinstance(self.kind, str):
+            if self.kind not in KERNEL_KINDS:
+                raise ValueError(f"Continuous kernel must be one of {list(KERNEL_KINDS)}, got {self.kind!r}")
+            return KERNEL_KINDS[self.kind]
+        return int(self.kind)
+
+    def as_dict(self) -> dict:
+        return dict(D=int(self.D), kind=self.kind_id, ard=bool(self.ard),
+                    idx_cont=[int(i) for i in self.idx_cont], idx_lin=[int(i) for i in self.idx_lin],
+                    coreg=[(int(c), int(n)) for c, n in self.coreg], out_col=int(self.out_col),
+                    n_out=int(self.n_out), hetero_noise=bool(self.hetero_noise), jitter=float(self.jitter))
+
+    def theta_size(self) -> int:
+        n = (len(self.idx_cont) if self.ard else 1) + 2
+        if self.idx_lin:
+            n += len(self.idx_lin) + 1
+        n += sum(3 * L for _, L in self.coreg)
+        if self.out_col >= 0:
+            n += 3 * self.n_out * (2 if self.hetero_noise else 1)
+        return n
+
+    def to_c(self) -> _Spec:
+        if not 1 <= len(self.idx_cont) <= GMB_MAX_DIMS:
+            raise ValueError(f"between 1 and {GMB_MAX_DIMS} continuous dimensions are supported")
+        if len(self.idx_lin) > GMB_MAX_LIN:
+            raise ValueError(f"at most {GMB_MAX_LIN} linear dimensions are supported")
+        if len(self.coreg) > GMB_MAX_COREG:
+            raise ValueError(f"at most {GMB_MAX_COREG} categorical dimensions are supported")
+        s = _Spec()
+        s.kind, s.ard = self.kind_id, int(bool(self.ard))
+        s.n_cont = len(self.idx_cont)
+        for i, v in enumerate(self.idx_cont):
+            s.idx_cont[i] = int(v)
+        s.n_lin = len(self.idx_lin)
+        for i, v in enumerate(self.idx_lin):
+            s.idx_lin[i] = int(v)
+        s.n_coreg = len(self.coreg)
+        for i, (col, lev) in enumerate(self.coreg):
+            s.coreg_col[i], s.coreg_levels[i] = int(col), int(lev)
+        s.out_col, s.n_out = int(self.out_col), int(self.n_out)
+        s.hetero_noise = int(bool(self.hetero_noise))
+        s.jitter = float(self.jitter)
+        return s
+
+
+# ------------------------------------------------------------------------------------------------
+_LIB = None
+_DBL_P = C.POINTER(C.c_double)
+
+
+def library_path() -> Path:
+    override = os.environ.get("GUMBI_HIP_LIB")
+    if override:
+        return Path(override)
+    return Path(__file__).resolve().parent / "lib" / "libgumbi_hip.so"
+
+
+_SIGNATURES = {
+    "gmb_abi_version": (C.c_int, []),
+    "gmb_device_count": (C.c_int, []),
+    "gmb_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "gmb_destroy": (None, [C.c_void_p]),
+    "gmb_last_error": (C.c_char_p, [C.c_void_p]),
+    "gmb_stream": (C.c_void_p, [C.c_void_p]),
+    "gmb_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int32]),
+    "gmb_set_kernel": (C.c_int, [C.c_void_p, C.POINTER(_Spec)]),
+    "gmb_theta_size": (C.c_int, [C.POINTER(_Spec)]),
+    "gmb_set_theta": (C.c_int, [C.c_void_p, _DBL_P, C.c_int32]),
+    "gmb_factorize": (C.c_int, [C.c_void_p]),
+    "gmb_notpd_index": (C.c_int64, [C.c_void_p]),
+    "gmb_nlml": (C.c_int, [C.c_void_p, _DBL_P, _DBL_P]),
+    "gmb_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                              C.c_void_p, C.c_int32]),
+    "gmb_ls_limits": (C.c_int, [C.c_int32, _DBL_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _DBL_P, _DBL_P]),
+    "gmb_mfma_f64_peak": (C.c_int, [C.c_int32, _DBL_P]),
+    "gmb_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gmb_timings_get": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    "gmb_copy_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _DBL_P]),
+    "gmb_copy_v": (C.c_int, [C.c_void_p, _DBL_P]),
+    "gmb_blk_potrf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmb_blk_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                  C.c_int32, C.c_int64]),
+    "gmb_blk_kbuild": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+}
+
+
+def exported_symbols() -> list:
+    """Every entry point ``include/gumbi_hip.h`` declares."""
+    return list(_SIGNATURES)
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so with the
+    same SONAME (libamdhip64.so.7) as /opt/rocm's; whichever is mapped first serves every later
+    request for that SONAME, but torch asks for its copy by *file name* and would map a second
+    runtime if ours came from /opt/rocm first.  Mapping torch's copy up front (when torch is
+    installed) makes libgumbi_hip.so, torch and RCCL share one runtime -- and therefore streams,
+    events and device pointers -- in either import order."""
+    if os.environ.get("GUMBI_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+        if cand.exists():
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass  # fall back to whatever libamdhip64.so.7 the loader finds
+
+
+def load_library():
+    """Load libgumbi_hip.so (once) and attach the prototypes.  Raises if it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise GumbiHipError(
+            f"{path} not found: the HIP engine is not built (run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C gumbi_amd/csrc`). gumbi_amd has no CPU fallback."
+        )
+    _preload_hip_runtime()
+    lib = C.CDLL(str(path))
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.restype, fn.argtypes = restype, argtypes
+    _LIB = lib
+    return lib
+
+
+def _ptr(arr):
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def _dptr(arr):
+    return arr.ctypes.data_as(_DBL_P)
+
+
+def device_count() -> int:
+    n = load_library().gmb_device_count()
+    return max(n, 0)
+
+
+class Engine:
+    """One GP resident on one MI355X: data, covariance / factor, predict workspaces."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.gmb_create(C.byref(self._h), int(device), C.c_void_p(stream) if stream else None)
+        if rc == GMB_ENODEVICE:
+            raise GumbiHipError("no HIP device visible: gumbi_amd needs an MI355X (gfx950); there is no CPU fallback")
+        if rc != GMB_OK:
+            raise GumbiHipError(f"gmb_create failed with status {rc}")
+        self.spec = None
+        self.N = 0
+        self.D = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.gmb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- error mapping (Regressor error surface: ValueError / LinAlgError) ---------
+    def _check(self, rc, what):
+        if rc == GMB_OK:
+            return
+        msg = self._lib.gmb_last_error(self._h)
+        msg = msg.decode() if msg else ""
+        if rc == GMB_EINVAL:
+            raise ValueError(f"{what}: {msg}")
+        if rc == GMB_ENOTPD:
+            raise np.linalg.LinAlgError(f"{what}: {msg}")
+        if rc == GMB_ENOMEM:
+            raise MemoryError(f"{what}: {msg}")
+        if rc == GMB_ENODEVICE:
+            raise GumbiHipError(f"{what}: no HIP device (no CPU fallback exists)")
+        raise GumbiHipError(f"{what}: status {rc}: {msg}")
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.gmb_stream(self._h) or 0)
+
+    # -- model definition -----------------------------------------------------------------------
+    def set_data(self, X, y):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if X.ndim != 2 or y.ndim != 1 or X.shape[0] != y.shape[0]:
+            raise ValueError(f"X must be (N, D) and y (N,), got {X.shape} and {y.shape}")
+        self._check(self._lib.gmb_set_data(self._h, _ptr(X), X.shape[0], X.shape[1], X.shape[1], _ptr(y), GMB_HOST),
+                    "gmb_set_data")
+        self.N, self.D = X.shape
+
+    def set_data_device(self, x_ptr: int, N: int, D: int, ldx: int, y_ptr: int):
+        """Inputs already in HBM (e.g. ``torch.Tensor.data_ptr()``)."""
+        self._check(self._lib.gmb_set_data(self._h, C.c_void_p(x_ptr), N, D, ldx, C.c_void_p(y_ptr), GMB_DEVICE),
+                    "gmb_set_data")
+        self.N, self.D = N, D
+
+    def set_kernel(self, spec: KernelSpec):
+        cs = spec.to_c()
+        self._check(self._lib.gmb_set_kernel(self._h, C.byref(cs)), "gmb_set_kernel")
+        self.spec = spec
+
+    def set_theta(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        self._check(self._lib.gmb_set_theta(self._h, _dptr(theta), theta.size), "gmb_set_theta")
+
+    # -- hot path ----------------------------------------------------------------------------------
+    def factorize(self):
+        self._check(self._lib.gmb_factorize(self._h), "gmb_factorize")
+
+    def notpd_index(self) -> int:
+        return int(self._lib.gmb_notpd_index(self._h))
+
+    def nlml(self, grad: bool = False):
+        val = C.c_double()
+        if not grad:
+            self._check(self._lib.gmb_nlml(self._h, C.byref(val), None), "gmb_nlml")
+            return val.value
+        g = np.empty(self.spec.theta_size(), dtype=np.float64)
+        self._check(self._lib.gmb_nlml(self._h, C.byref(val), _dptr(g)), "gmb_nlml")
+        return val.value, g
+
+    def predict(self, Xs, with_noise=True):
+        Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+        if Xs.ndim != 2 or Xs.shape[1] != self.D:
+            raise ValueError(f"points_array must be (M, {self.D}), got {Xs.shape}")
+        M = Xs.shape[0]
+        mean = np.empty(M, dtype=np.float64)
+        var = np.empty(M, dtype=np.float64)
+        self._check(
+            self._lib.gmb_predict(self._h, _ptr(Xs), M, Xs.shape[1], int(bool(with_noise)), _ptr(mean), _ptr(var),
+                                  GMB_HOST),
+            "gmb_predict",
+        )
+        return mean, var
+
+    def predict_device(self, xs_ptr: int, M: int, ldxs: int, mean_ptr: int, var_ptr: int, with_noise=True):
+        self._check(
+            self._lib.gmb_predict(self._h, C.c_void_p(xs_ptr), M, ldxs, int(bool(with_noise)), C.c_void_p(mean_ptr),
+                                  C.c_void_p(var_ptr), GMB_DEVICE),
+            "gmb_predict",
+        )
+
+    # -- introspection -----------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._check(self._lib.gmb_set_profiling(self._h, int(bool(on))), "gmb_set_profiling")
+
+    def timings(self) -> dict:
+        t = Timings()
+        self._check(self._lib.gmb_timings_get(self._h, C.byref(t)), "gmb_timings_get")
+        return t.as_dict()
+
+    def copy_factor(self, r0=0, nr=None, c0=0, nc=None):
+        nr = self.N if nr is None else nr
+        nc = self.N if nc is None else nc
+        out = np.empty((nr, nc), dtype=np.float64)
+        self._check(self._lib.gmb_copy_factor(self._h, r0, nr, c0, nc, _dptr(out)), "gmb_copy_factor")
+        return out
+
+    def copy_v(self):
+        out = np.empty(self.N, dtype=np.float64)
+        self._check(self._lib.gmb_copy_v(self._h, _dptr(out)), "gmb_copy_v")
+        return out
+
+    # -- block-level operations (device pointers) --------------------------------------------------------
+    def blk_potrf(self, a_ptr, lda, nvalid, inv_ptr, logdet_ptr=0, info_ptr=0):
+        self._check(self._lib.gmb_blk_potrf(self._h, C.c_void_p(a_ptr), lda, nvalid, C.c_void_p(inv_ptr),
+                                            C.c_void_p(logdet_ptr) if logdet_ptr else None,
+                                            C.c_void_p(info_ptr) if info_ptr else None), "gmb_blk_potrf")
+
+    def blk_gemm_nt(self, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, m, n, k, alpha, beta, tri=0, tri_shift=0):
+        self._check(self._lib.gmb_blk_gemm_nt(self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda,
+                                              C.c_void_p(b_ptr), ldb, m, n, k, alpha, beta, tri, tri_shift),
+                    "gmb_blk_gemm_nt")
+
+    def blk_kbuild(self, out_ptr, ldo, i0, ni, j0, nj):
+        self._check(self._lib.gmb_blk_kbuild(self._h, C.c_void_p(out_ptr), ldo, i0, ni, j0, nj), "gmb_blk_kbuild")
+
+
+def ls_limits(X, ard: bool, device: int = 0):
+    """Minimum non-zero and maximum pairwise distance per group (``gmb_ls_limits``)."""
+    lib = load_library()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n_groups = X.shape[1] if ard else 1
+    lo = np.empty(n_groups)
+    hi = np.empty(n_groups)
+    rc = lib.gmb_ls_limits(int(device), _dptr(X), X.shape[0], X.shape[1], X.shape[1], int(bool(ard)), _dptr(lo),
+                           _dptr(hi))
+    if rc == GMB_ENODEVICE:
+        raise GumbiHipError("gmb_ls_limits: no HIP device (no CPU fallback exists)")
+    if rc != GMB_OK:
+        raise GumbiHipError(f"gmb_ls_limits failed with status {rc}")
+    return lo, hi
+
+
+def mfma_f64_peak(device: int = 0) -> float:
+    """Measured f64 MFMA rate in TFLOP/s (``gmb_mfma_f64_peak``)."""
+    out = C.c_double()
+    rc = load_library().gmb_mfma_f64_peak(int(device), C.byref(out))
+    if rc != GMB_OK:
+        raise GumbiHipError(f"gmb_mfma_f64_peak failed with status {rc}")
+    return out.value

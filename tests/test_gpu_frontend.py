@@ -1,0 +1,133 @@
+"""End-to-end ``GP(ds).fit() -> prepare_grid() -> predict_grid()`` on the MI355X, checked against
+the oracle evaluated at the hyper-parameters the fit found (the reference's own tests for this
+path are smoke tests -- tests/test_regression.py:146-191 -- so value parity is against the
+oracle)."""
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+example_stdzr = {
+    "a": {"μ": -0.762, "σ2": 1.258**2}, "b": {"μ": -0.0368, "σ2": 0.351**2}, "c": {"μ": -5.30, "σ2": 0.582**2},
+    "d": {"μ": -0.307, "σ2": 0.158**2}, "e": {"μ": -1.056, "σ2": 0.398**2}, "f": {"μ": 3.34, "σ2": 0.1501**2},
+    "X": {"μ": -0.282, "σ2": 1**2}, "Y": {"μ": 4.48, "σ2": 0.75**2}, "lg10_Z": {"μ": 5, "σ2": 2**2},
+}
+
+FIT_INPUTS = [
+    {"outputs": ["d", "c"], "continuous_dims": ["X", "Y"]},
+    {"continuous_dims": ["X", "Y"], "categorical_dims": "Code"},
+    {"continuous_dims": ["X", "Y", "Name"]},
+    {"continuous_dims": ["X", "Y", "lg10_Z"]},
+    {"continuous_dims": ["X", "Y", "Name"], "continuous_levels": {"Name": ["intense-opportunity"]}},
+]
+
+
+def example_gp():
+    import gumbi_amd as gmb
+
+    es = pd.read_pickle(GOLD / "test_dataset.pkl")
+    stdzr = gmb.Standardizer(**{k: dict(v) for k, v in example_stdzr.items()}, log_vars=["d", "f", "b", "c", "Y"],
+                             logit_vars=["e", "X"])
+    ds = gmb.DataSet.from_tidy(es, names_column="Parameter", stdzr=stdzr)
+    return gmb.GP(ds, outputs="d")
+
+
+def oracle_spec(gp):
+    return gp.model.spec.as_dict()
+
+
+@pytest.mark.parametrize("fit_inputs", FIT_INPUTS)
+def test_gp_fit_and_predict(gpu, fit_inputs):
+    gp = example_gp().fit(**fit_inputs, MAP_kwargs={"maxeval": 60})
+    assert isinstance(gp.MAP, dict) and "ls_total" in gp.MAP and "σ_log__" in gp.MAP
+    assert gp.nlml_trace[-1] <= gp.nlml_trace[0] + 1e-6 or len(gp.nlml_trace) < 3
+    cat = {d: gp.categorical_levels[d][0] for d in gp.categorical_dims if d != gp.out_col} or None
+    gp.prepare_grid(resolution=6)
+    pred = gp.predict_grid(categorical_levels=cat)
+    assert pred.shape == gp.grid_parray.shape
+    # same inputs through the oracle at the fitted hyper-parameters
+    X, y = gp.get_shaped_data("mean")
+    points = gp.grid_points if cat is None else gp.append_categorical_points(gp.grid_points, cat)
+    out = gp._parse_prediction_output(None)
+    pa, _, _ = gp._prepare_points_for_prediction(points, output=out)
+    mu, var = O.predict(oracle_spec(gp), gp._theta_fitted, X, y, pa, with_noise=True)
+    mu_g, var_g = gp.predict(pa)
+    assert np.max(np.abs(mu_g - mu)) <= 1e-8 * max(np.max(np.abs(mu)), 1e-3)
+    assert np.max(np.abs(var_g - var)) <= 1e-8
+    if len(out) > 1:
+        assert pred.names == out and pred.cor.shape == (2, 2)
+        name = out[0]
+        got = pred.get(name).z
+    else:
+        got = pred.z
+        sel = slice(None)
+        assert np.allclose(got.μ.ravel(), mu[sel], rtol=1e-7, atol=1e-9)
+        assert np.allclose(got.σ2.ravel(), var[sel], rtol=1e-7, atol=1e-9)
+
+
+def test_map_objective_matches_oracle_formula(gpu):
+    """Objective and gradient handed to L-BFGS == -(loglik + log-priors + log-Jacobians) restated
+    in the oracle (PyMC's find_MAP objective)."""
+    gp = example_gp()
+    gp.specify_model(outputs=["d", "c"], continuous_dims=["X", "Y"], linear_dims=["Y"], categorical_dims="Code")
+    gp.build_model()
+    X, y = gp.get_shaped_data("mean")
+    theta = gp._initial_theta() * 0.9 + 0.05
+    theta = np.where(gp._positive_mask(), np.abs(theta) + 0.05, theta)
+    pos = gp._positive_mask()
+    u = np.where(pos, np.log(theta), theta)
+    f, g = gp._objective(u, pos)
+    spec = oracle_spec(gp)
+    nl, gn = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+    lp = O.log_prior_and_jacobian(spec, theta, gp.model.ls_params["alpha"], gp.model.ls_params["beta"])
+    assert np.isclose(f, nl - lp, rtol=1e-9)
+    h = 1e-6
+    for i in range(0, u.size, max(1, u.size // 8)):
+        up, um = u.copy(), u.copy()
+        up[i] += h
+        um[i] -= h
+        fd = (gp._objective(up, pos)[0] - gp._objective(um, pos)[0]) / (2 * h)
+        assert abs(fd - g[i]) <= 1e-4 * max(1.0, abs(g[i])), (i, fd, g[i])
+
+
+def test_unsupported_options_raise_like_reference(gpu):
+    gp = example_gp().specify_model(continuous_dims=["X", "Y"])
+    with pytest.raises(NotImplementedError):
+        gp.build_model(heteroskedastic_inputs=True)
+    with pytest.raises(NotImplementedError):
+        gp.build_model(sparse=True)
+    with pytest.raises(ValueError):
+        gp.build_model(continuous_kernel="RatQuad")
+    with pytest.raises(NotImplementedError):
+        gp.build_model()
+        gp.find_MAP(maxeval=3)
+        gp.predict(np.zeros((2, 2)), additive_level="Code")
+    with pytest.raises(NotImplementedError):
+        gp.sample()
+
+
+def test_synthetic_mpg_like_end_to_end(gpu):
+    """C1 stand-in (the mpg table is a network fetch): N = 392, horsepower ~ LogNormal, both
+    variables log-normal, 1-D RBF; prediction wrapping goes back through the Standardizer."""
+    import gumbi_amd as gmb
+
+    rng = np.random.default_rng(2021)
+    hp = np.exp(rng.normal(4.6, 0.35, 392))
+    mpg = np.exp(7.1 - 0.85 * np.log(hp) + rng.normal(0, 0.12, 392))
+    df = pd.DataFrame({"horsepower": hp, "mpg": mpg, "acceleration": rng.normal(15, 2, 392)})
+    ds = gmb.DataSet(df, outputs=["mpg", "acceleration"], log_vars=["mpg", "acceleration", "horsepower"])
+    gp = gmb.GP(ds)
+    gp.fit(outputs=["mpg"], continuous_dims=["horsepower"])
+    Xg = gp.prepare_grid()
+    yg = gp.predict_grid()
+    assert Xg.shape == (100,) and yg.shape == (100,)
+    assert np.all(np.asarray(yg.μ) > 0) and np.all(np.diff(np.asarray(yg.μ)[20:80]) < 0)  # decreasing trend
+    assert 0.03 < float(gp.MAP["σ"]) < 1.0
+    mid = np.argmin(np.abs(np.asarray(Xg["horsepower"].values()) - 100.0))
+    assert abs(np.log(float(yg.μ[mid])) - (7.1 - 0.85 * np.log(100.0))) < 0.1
