@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void predict_partial_kernel(const double* __re
   const int64_t i1 = (i0 + RED_CHUNK < n) ? i0 + RED_CHUNK : n;
   if (i0 + threadIdx.x < n) vs[threadIdx.x] = v[i0 + threadIdx.x];
   __syncthreads();
+  if (m >= mpad) return;  // mpad is a multiple of 128, the block covers 256
   double am = 0.0, as = 0.0;
   const double* col = V + m + i0 * ldz;
   for (int64_t i = i0; i < i1; ++i) {

@@ -587,6 +587,9 @@ int grad_impl(gmb_engine* e, double* grad) {
   const int nt = (int)(e->Np / TILE);
   // 1. W = L^-1
   if ((rc = winv_cols(e, 0, nt))) return rc;
+  if (e->Np > e->N)
+    hipLaunchKernelGGL(reset_pad_rows_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, e->stream,
+                       e->dW, e->Np, e->N, e->Np);
   // 2. alpha = W^T v = Sigma^-1 y
   hipLaunchKernelGGL(wt_v_kernel, dim3((unsigned)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->dW, e->Np,
                      e->dv, e->N, e->dalpha);

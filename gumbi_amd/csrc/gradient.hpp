@@ -216,6 +216,14 @@ __global__ __launch_bounds__(256) void grad_diag_kernel(const double* Z, int64_t
   if (threadIdx.x == 0) atomicAdd(&out[0], red[0] + red[1] + red[2] + red[3]);
 }
 
+// The factor buffer carries y (later v) in row N, so the block inversion leaves -v^T L^-1 in the
+// padding rows [n, npad) of W; reset them to identity before forming W^T W.
+__global__ void reset_pad_rows_kernel(double* W, int64_t ld, int64_t n, int64_t npad) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= npad) return;
+  for (int64_t r = n; r < npad; ++r) W[r + c * ld] = (r == c) ? 1.0 : 0.0;
+}
+
 // alpha = W^T v with W = L^-1 lower triangular, column-major: alpha_j = sum_{k>=j} W[k + j*ld] v_k
 __global__ __launch_bounds__(256) void wt_v_kernel(const double* W, int64_t ld, const double* v,
                                                    int64_t n, double* alpha) {

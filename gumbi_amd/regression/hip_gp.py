@@ -313,7 +313,8 @@ class HipGP(Regressor):
             th = self._theta_from_dict(theta, theta0) if isinstance(theta, dict) else np.asarray(theta, float)
             self.n_eval = 0
         else:
-            u0 = np.where(pos, np.log(theta0), theta0)
+            u0 = theta0.copy()
+            u0[pos] = np.log(theta0[pos])
             res = minimize(self._objective, u0, args=(pos,), jac=True, method=method,
                            options={"maxfun": int(maxeval), **kwargs.pop("options", {})}, **kwargs)
             th = np.where(pos, np.exp(res.x), res.x)

@@ -273,9 +273,12 @@ def test_ls_limits_joint_matches_oracle(gpu):
     lo, hi = ls_limits(X, ard=False)
     lo_r, hi_r = O.parse_ls_limits(X, ARD=False)
     assert np.isclose(lo[0], lo_r[0], rtol=1e-14) and np.isclose(hi[0], hi_r[0], rtol=1e-14)
-    lo, hi = ls_limits(X, ard=True)
-    lo_r, hi_r = O.parse_ls_limits(X, ARD=True)
-    assert np.allclose(lo, lo_r, rtol=1e-14) and np.allclose(hi, hi_r, rtol=1e-14)
+    from scipy.spatial.distance import pdist
+
+    lo, hi = ls_limits(X, ard=True)  # raw extrema (the 0.01 floor is applied by parse_ls_limits)
+    for j in range(X.shape[1]):
+        dj = pdist(X[:, [j]])
+        assert np.isclose(lo[j], dj[dj != 0].min(), rtol=1e-14) and np.isclose(hi[j], dj.max(), rtol=1e-14)
     lo2, hi2 = parse_ls_limits(X, ARD=False)
     assert np.isclose(lo2[0], lo_r[0]) and np.isclose(hi2[0], hi_r[0])
     lo, hi = ls_limits(np.ones((5, 2)), ard=False)
