@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""Headline benchmark: GP fit + predict on synthetic N x d fp64 tables (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1] [--map-evals E]
+
+A *step* is one pass of the hot path the reference reaches through ``gp.fit()`` +
+``gp.predict_grid()``, with the inputs already resident in HBM:
+
+    find_MAP  -- L-BFGS-B on -(log-lik + log-priors + log-Jacobians); every objective / gradient
+                 evaluation = covariance build -> Cholesky -> v = L^-1 y, log-det ->
+                 L^-1, Sigma^-1, fused trace reductions                  (all in libgumbi_hip.so)
+    refactor at the MAP, predict mean / variance on the M-point grid     (libgumbi_hip.so)
+
+The default workload is BASELINE.json configs[1]: N = 10k, d = 4, RBF-ARD, fp64, M = 10^4 grid
+(100 x 100 over dims 0,1; other dims pinned at 0).  ``value`` = algorithmic GFLOP/s of the whole
+step; ``ms_per_step`` is the fit + predict wall time.  One JSON line is printed by rank 0.
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank currently
+fits its own replica of the workload ("replicas only", weak scaling, no data-path collective);
+the barrier / max-over-ranks timing contract is kept.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet (vector = matrix FP64); MI355X_MICROARCH.md lists none
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+CONFIGS = {
+    # name: (N, d, kernel, M-grid resolution)
+    "c1": dict(N=392, d=1, kernel="ExpQuad", res=100, label="C1-like synthetic N=392 d=1 RBF"),
+    "c2": dict(N=10_000, d=4, kernel="ExpQuad", res=100, label="synthetic N=10k d=4 RBF-ARD fp64, M=10^4 grid"),
+    "c3": dict(N=50_000, d=8, kernel="Matern52", res=100, label="synthetic N=50k d=8 Matern-5/2 ARD fp64, M=10^4 grid"),
+}
+
+
+def synthetic_table(N, d, seed=2021, sigma=0.2):
+    """SURVEY.md section 8d generator (same draws as oracle/gp_oracle.py:synthetic_table)."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, d))
+    ls = np.geomspace(0.7, 2.0, d) if d > 1 else np.array([1.0])
+    f = np.sum(np.sin(X / ls), axis=1) / np.sqrt(d)
+    y = f + sigma * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std(ddof=1)
+    return X, y, ls
+
+
+def synthetic_grid(d, res=100, lim=2.4):
+    g = np.linspace(-lim, lim, res)
+    if d == 1:
+        return g[:, None].copy()
+    G0, G1 = np.meshgrid(g, g, indexing="ij")
+    Xs = np.zeros((res * res, d))
+    Xs[:, 0], Xs[:, 1] = G0.ravel(), G1.ravel()
+    return Xs
+
+
+def build_gp(cfg, device):
+    """Front-end objects exactly as a Gumbi user builds them (DataSet -> GP -> build_model)."""
+    import pandas as pd
+
+    import gumbi_amd as gmb
+
+    X, y, _ = synthetic_table(cfg["N"], cfg["d"])
+    cols = [f"x{k}" for k in range(cfg["d"])]
+    df = pd.DataFrame(X, columns=cols)
+    df["y"] = y
+    ds = gmb.DataSet(df, outputs=["y"])
+    gp = gmb.GP(ds, outputs=["y"], device=device)
+    gp.specify_model(continuous_dims=cols)
+    gp.build_model(continuous_kernel=cfg["kernel"])
+    return gp
+
+
+def step_flops(N, M, n_eval):
+    """Algorithmic flops of one step: per evaluation N^3/3 (Cholesky) +
+    2N^3/3 (inverse + Sigma^-1); final Cholesky N^3/3; predict N^2 M + 4 N M."""
+    n3 = float(N) ** 3
+    return n_eval * n3 + n3 / 3.0 + float(N) ** 2 * M + 4.0 * N * M
+
+
+def cpu_baseline(cfg, target_seconds=15.0):
+    """Oracle (numpy + LAPACK through scipy) timed on a bounded sample of the same workload:
+    one MAP objective+gradient evaluation and one grid prediction at a reduced N chosen (from a
+    short probe, cost ~ N^3) to take about ``target_seconds`` on this host."""
+    from oracle import gp_oracle as O
+
+    d = cfg["d"]
+    Xs = O.synthetic_grid(d, cfg["res"])
+    spec = O.make_spec(d, range(d), kind=cfg["kernel"])
+
+    def run(n):
+        X, y, ls = O.synthetic_table(n, d)
+        theta = O.pack_theta(spec, ls, 1.0, 0.2)
+        t0 = time.perf_counter()
+        O.nlml_and_grad(spec, theta, X, y, dist_mode="gemm")
+        O.predict(spec, theta, X, y, Xs, with_noise=True)
+        return time.perf_counter() - t0
+
+    probe_n = min(cfg["N"], 1500)
+    t_probe = run(probe_n)
+    Ns = int(min(cfg["N"], max(probe_n, probe_n * (target_seconds / max(t_probe, 1e-3)) ** (1.0 / 3.0))))
+    Ns = max(128, Ns // 128 * 128) if Ns < cfg["N"] else cfg["N"]
+    dt = run(Ns) if Ns != probe_n else t_probe
+    flops = step_flops(Ns, len(Xs), 1)
+    cores = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        pass
+    return {
+        "value": round(flops / dt / 1e9, 2),
+        "unit": "GFLOP/s",
+        "cores": int(cores),
+        "kind": "port",
+        "sample": f"1 MAP objective+gradient evaluation + predict(M={len(Xs)}) at N={Ns}, d={d}, {cfg['kernel']} "
+                  f"(numpy/LAPACK oracle, {dt:.1f} s)",
+        "seconds": round(dt, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--map-evals", type=int, default=0,
+                    help="cap on L-BFGS objective evaluations per fit (0 = run to convergence, cap 200)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cfg = CONFIGS[args.config]
+
+    dist = None
+    import torch
+
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gumbi_amd import engine
+
+    if engine.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libgumbi_hip has no CPU fallback")
+    gp = build_gp(cfg, device=local_rank)
+    eng = gp.engine
+    Xs = synthetic_grid(cfg["d"], cfg["res"])
+    M = len(Xs)
+    dev = torch.device("cuda", local_rank)
+    xs_dev = torch.tensor(Xs, dtype=torch.float64, device=dev)  # X* resident in HBM
+    mean_dev = torch.empty(M, dtype=torch.float64, device=dev)
+    var_dev = torch.empty(M, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    maxeval = args.map_evals if args.map_evals > 0 else 200
+
+    def one_step():
+        gp.find_MAP(maxeval=maxeval)
+        eng.predict_device(xs_dev.data_ptr(), M, cfg["d"], mean_dev.data_ptr(), var_dev.data_ptr(), True)
+        return gp.n_eval
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    eng.set_profiling(True)  # per-launch HIP events on the engine's stream (resets the totals)
+    barrier()
+    t0 = time.perf_counter()
+    n_evals = [one_step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timings()
+    eng.set_profiling(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    flops_total = sum(step_flops(cfg["N"], M, n) for n in n_evals) * world
+    mean_host = mean_dev.cpu().numpy()
+    var_host = var_dev.cpu().numpy()
+    finite = bool(np.all(np.isfinite(mean_host)) and np.all(var_host > 0))
+
+    if rank == 0:
+        gemm_tf = tm["total_gemm_flops"] / max(tm["total_gemm_ms"], 1e-9) / 1e9
+        kb_gbs = tm["total_kbuild_bytes"] / max(tm["total_kbuild_ms"], 1e-9) / 1e6
+        out = {
+            "metric": "fit+predict achieved GFLOP/s (fp64 exact GP: MAP fit + grid prediction)",
+            "value": round(flops_total / elapsed / 1e9, 2),
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": cfg["label"],
+                "N": cfg["N"], "d": cfg["d"], "kernel": cfg["kernel"], "M": M,
+                "map_evals_per_step": n_evals,
+                "parallelism": "1 GPU" if world == 1 else f"{world} replicas (one GP per GPU)",
+            },
+            "fit_predict_seconds": round(elapsed / args.steps, 4),
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "gemm_f64_kernel (v_mfma_f64_16x16x4_f64 SYRK/GEMM: Cholesky trailing update, "
+                          "triangular solves, inverse)",
+                "achieved": round(gemm_tf, 3),
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(gemm_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launches": int(tm["total_gemm_launches"]),
+                "avg_launch_ms": round(tm["total_gemm_ms"] / max(tm["total_gemm_launches"], 1), 5),
+                "flops_per_launch": round(tm["total_gemm_flops"] / max(tm["total_gemm_launches"], 1), 1),
+            },
+            "kbuild": {
+                "bound": "hbm", "achieved": round(kb_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(kb_gbs / HBM_PEAK_GBS, 4), "launches": int(tm["total_kbuild_launches"]),
+            },
+            "results_finite": finite,
+        }
+        try:
+            tf, cyc = engine.mfma_f64_peak(local_rank)
+            out["roofline"]["mfma_only_microbench_tflops"] = round(tf, 2)  # sustained ceiling under DVFS
+        except Exception:
+            pass
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out, ensure_ascii=False))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,7 @@ struct EventPair {
   hipEvent_t a, b;
   int kind;  // 0 chol gemm, 1 leaf, 2 trsm, 3 predict gemm, 4 grad gemm
   double flops;
+  int mt, nt, k, flags;
 };
 
 }  // namespace
@@ -180,9 +181,13 @@ struct PhaseTimer {
   }
 };
 
-void ev_begin(gmb_engine* e, int kind, double flops) {
+void ev_begin(gmb_engine* e, int kind, double flops, int mt = 0, int nt = 0, int k = 0, int flags = 0) {
   if (!e->profiling) return;
   EventPair p;
+  p.mt = mt;
+  p.nt = nt;
+  p.k = k;
+  p.flags = flags;
   (void)hipEventCreate(&p.a);
   (void)hipEventCreate(&p.b);
   p.kind = kind;
@@ -195,9 +200,20 @@ void ev_end(gmb_engine* e) {
   (void)hipEventRecord(e->evs.back().b, e->stream);
 }
 void ev_collect(gmb_engine* e) {  // stream already synchronised
+  static FILE* trace = nullptr;
+  if (!trace && !e->evs.empty()) {
+    const char* path = getenv("GMB_TRACE_FILE");  // per-launch log for tuning: kind mt nt k flags ms GF
+    if (path && path[0]) trace = fopen(path, "a");
+  }
   for (auto& p : e->evs) {
     float t = 0.f;
     (void)hipEventElapsedTime(&t, p.a, p.b);
+    if (trace) fprintf(trace, "%d %d %d %d %d %.5f %.1f\n", p.kind, p.mt, p.nt, p.k, p.flags, t, p.flops / 1e9);
+    if (p.kind == 0 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
+      e->tm.total_gemm_ms += t;
+      e->tm.total_gemm_flops += p.flops;
+      e->tm.total_gemm_launches += 1;
+    }
     switch (p.kind) {
       case 0:
         e->tm.chol_gemm_ms += t;
@@ -220,12 +236,14 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
     (void)hipEventDestroy(p.b);
   }
   e->evs.clear();
+  if (trace) fflush(trace);
 }
 
 // ---- kernel launch helpers ----------------------------------------------------------------
 int launch_gemm(gmb_engine* e, const GemmArgs& g, int ev_kind) {
   if (g.mt <= 0 || g.nt <= 0 || g.k <= 0) return GMB_OK;
-  ev_begin(e, ev_kind, e->profiling ? gemm_flops(g) : 0.0);
+  ev_begin(e, ev_kind, e->profiling ? gemm_flops(g) : 0.0, g.mt, g.nt, g.k,
+           g.tri | (g.ta << 1) | (g.tb << 2) | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5));
   const dim3 grid(g.mt * g.nt), block(256);
   if (g.ta && g.tb)
     hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, e->stream, g);
@@ -849,6 +867,12 @@ int gmb_set_theta(gmb_engine* e, const double* theta, int32_t n) {
 int gmb_set_profiling(gmb_engine* e, int32_t on) {
   if (!e) return GMB_EINVAL;
   e->profiling = on != 0;
+  if (on) {
+    e->tm.total_gemm_ms = e->tm.total_gemm_flops = 0.0;
+    e->tm.total_gemm_launches = 0;
+    e->tm.total_kbuild_ms = e->tm.total_kbuild_bytes = 0.0;
+    e->tm.total_kbuild_launches = 0;
+  }
   return GMB_OK;
 }
 
@@ -910,6 +934,11 @@ int gmb_factorize(gmb_engine* e) {
   tm.kbuild_bytes = 8.0 * (double)e->N * (double)(e->N + 1) / 2.0 +
                     8.0 * (double)e->N * (double)(e->spec.n_cont + 1);
   ev_collect(e);
+  if (e->profiling) {
+    tm.total_kbuild_ms += tm.kbuild_ms;
+    tm.total_kbuild_bytes += tm.kbuild_bytes;
+    tm.total_kbuild_launches += 1;
+  }
   if (info != 0) {
     e->notpd = (int64_t)info - 1;
     return fail(e, GMB_ENOTPD, "covariance matrix is not positive definite at row %lld",
@@ -1090,14 +1119,14 @@ int gmb_ls_limits(int32_t device, const double* X, int64_t N, int32_t n_cols, in
   return GMB_OK;
 }
 
-int gmb_mfma_f64_peak(int32_t device, double* tflops) {
+int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
   if (!tflops) return GMB_EINVAL;
   int nd = gmb_device_count();
   if (nd < 0) return GMB_ENODEVICE;
   if (device < 0 || device >= nd) return GMB_EINVAL;
   if (hipSetDevice(device) != hipSuccess) return GMB_EHIP;
   double* sink = nullptr;
-  if (hipMalloc((void**)&sink, 8) != hipSuccess) return GMB_ENOMEM;
+  if (hipMalloc((void**)&sink, 16) != hipSuccess) return GMB_ENOMEM;
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
@@ -1112,8 +1141,12 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops) {
   (void)hipEventElapsedTime(&ms, a, b);
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
+  double hsink[2] = {0.0, 0.0};
+  if (rc == GMB_OK && hipMemcpy(hsink, sink, 16, hipMemcpyDeviceToHost) != hipSuccess) rc = GMB_EHIP;
   (void)hipFree(sink);
   if (rc) return rc;
+  // block 0 times its own MFMA stream with s_memtime; 2 waves share each SIMD at this occupancy
+  if (cycles_per_mfma) *cycles_per_mfma = hsink[1] / ((double)iters * 8.0);
   const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
   *tflops = flops / ((double)ms * 1e-3) / 1e12;
   return GMB_OK;

@@ -65,6 +65,12 @@ class Timings(C.Structure):
         ("grad_gemm_ms", C.c_double),
         ("grad_gemm_flops", C.c_double),
         ("kbuild_bytes", C.c_double),
+        ("total_gemm_ms", C.c_double),
+        ("total_gemm_flops", C.c_double),
+        ("total_gemm_launches", C.c_int64),
+        ("total_kbuild_ms", C.c_double),
+        ("total_kbuild_bytes", C.c_double),
+        ("total_kbuild_launches", C.c_int64),
     ]
 
     def as_dict(self):
@@ -162,7 +168,7 @@ _SIGNATURES = {
     "gmb_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                               C.c_void_p, C.c_int32]),
     "gmb_ls_limits": (C.c_int, [C.c_int32, _DBL_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _DBL_P, _DBL_P]),
-    "gmb_mfma_f64_peak": (C.c_int, [C.c_int32, _DBL_P]),
+    "gmb_mfma_f64_peak": (C.c_int, [C.c_int32, _DBL_P, _DBL_P]),
     "gmb_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_timings_get": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     "gmb_copy_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _DBL_P]),
@@ -401,10 +407,10 @@ def ls_limits(X, ard: bool, device: int = 0):
     return lo, hi
 
 
-def mfma_f64_peak(device: int = 0) -> float:
-    """Measured f64 MFMA rate in TFLOP/s (``gmb_mfma_f64_peak``)."""
-    out = C.c_double()
-    rc = load_library().gmb_mfma_f64_peak(int(device), C.byref(out))
+def mfma_f64_peak(device: int = 0):
+    """(TFLOP/s, shader cycles per MFMA as seen by one wave) from ``gmb_mfma_f64_peak``."""
+    out, cyc = C.c_double(), C.c_double()
+    rc = load_library().gmb_mfma_f64_peak(int(device), C.byref(out), C.byref(cyc))
     if rc != GMB_OK:
         raise GumbiHipError(f"gmb_mfma_f64_peak failed with status {rc}")
-    return out.value
+    return out.value, cyc.value

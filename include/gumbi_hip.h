@@ -96,6 +96,13 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
   double grad_gemm_ms;
   double grad_gemm_flops;
   double kbuild_bytes;       /* algorithmic bytes the K-build wrote+read (8N(N+1)/2 + 8N(d+1)) */
+  /* cumulative since the last gmb_set_profiling(e, 1): every MFMA GEMM launch of every phase */
+  double total_gemm_ms;
+  double total_gemm_flops;
+  int64_t total_gemm_launches;
+  double total_kbuild_ms;
+  double total_kbuild_bytes;
+  int64_t total_kbuild_launches;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;
@@ -161,8 +168,9 @@ int gmb_set_profiling(gmb_engine* e, int32_t on); /* per-launch hipEvent timing 
 int gmb_timings_get(const gmb_engine* e, gmb_timings* out);
 
 /* Microbenchmark: sustained v_mfma_f64_16x16x4_f64 rate of `device` in TFLOP/s (register-only
- * kernel, no memory traffic) -- the measured denominator for the MFMA roofline. */
-int gmb_mfma_f64_peak(int32_t device, double* tflops);
+ * kernel, no memory traffic) -- the measured denominator for the MFMA roofline -- and the shader
+ * cycles one wave spends per MFMA (64 = the datasheet issue rate; wall rate / this = clock). */
+int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma);
 
 /* Copy out pieces of the resident state (tests / multi-GPU driver):
  *   rows [r0, r0+nr) x cols [c0, c0+nc) of the factor buffer (lower triangle meaningful),

@@ -20,7 +20,7 @@ def libs():
 def main():
     sizes = [int(s) for s in (sys.argv[1:] or ["2000", "10000"])]
     print("devices:", engine.device_count(), "runtime:", libs())
-    print("mfma f64 peak TFLOP/s:", [round(engine.mfma_f64_peak(0), 2) for _ in range(3)])
+    print("mfma f64 peak (TFLOP/s, cycles/MFMA/wave):", [tuple(round(v, 2) for v in engine.mfma_f64_peak(0)) for _ in range(3)])
     for N in sizes:
         d = 4
         X, y, ls = O.synthetic_table(N, d)
