@@ -240,11 +240,15 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
 }
 
 // ---- kernel launch helpers ----------------------------------------------------------------
-int launch_gemm(gmb_engine* e, const GemmArgs& g, int ev_kind) {
-  if (g.mt <= 0 || g.nt <= 0 || g.k <= 0) return GMB_OK;
-  ev_begin(e, ev_kind, e->profiling ? gemm_flops(g) : 0.0, g.mt, g.nt, g.k,
+int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
+  if (g_in.mt <= 0 || g_in.nt <= 0 || g_in.k <= 0) return GMB_OK;
+  GemmArgs g = g_in;
+  double flops = 0.0;
+  const int nblocks = gemm_schedule(g, &flops);
+  if (nblocks <= 0) return GMB_OK;
+  ev_begin(e, ev_kind, flops, g.mt, g.nt, g.k,
            g.tri | (g.ta << 1) | (g.tb << 2) | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5));
-  const dim3 grid(g.mt * g.nt), block(256);
+  const dim3 grid(nblocks), block(256);
   if (g.ta && g.tb)
     hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, e->stream, g);
   else if (g.ta)
@@ -519,31 +523,46 @@ int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1) {
 }
 
 // ---- NLML gradient ---------------------------------------------------------------------------
-// W = L^-1 by recursive block inversion into e->dW (lower triangle; the mirrored upper region is
-// scratch for the intermediate products):  [[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]].
+// Triangular inverse by recursive block inversion, kept in BOTH orientations so that every
+// product is a k-major ("NT") MFMA GEMM with fully coalesced operand loads:
+//   W = L^-1   (lower) in e->dW,
+//   U = L^-T   (upper) in the upper triangle + diagonal tiles of the factor buffer e->dA
+//              (the diagonal blocks of L are no longer needed once inv(L_kk) exists; the
+//              off-diagonal blocks of L stay intact in the lower triangle).
+//   [[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]]:
+//     T^T = U_A B^T (scratch, mirrored region of dW),  W21 = -W_C T,  U12 = W21^T (transpose).
+int launch_transpose(gmb_engine* e, const double* src, int64_t lds_, double* dst, int64_t ldd, int rows,
+                     int cols) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, e->stream, src,
+                     lds_, dst, ldd, rows, cols);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
 int winv_cols(gmb_engine* e, int c0, int c1) {
-  const int64_t ldw = e->Np;
+  const int64_t ldw = e->Np, lda = e->ld;
   double* W = e->dW;
+  double* A = e->dA;
   if (c1 - c0 == 1) {
-    HIP_TRY(e, hipMemcpy2DAsync(W + (int64_t)c0 * TILE + (int64_t)c0 * TILE * ldw, ldw * sizeof(double),
-                                e->dInv + (int64_t)c0 * TILE * TILE, TILE * sizeof(double),
-                                TILE * sizeof(double), TILE, hipMemcpyDeviceToDevice, e->stream));
-    return GMB_OK;
+    const double* inv = e->dInv + (int64_t)c0 * TILE * TILE;
+    HIP_TRY(e, hipMemcpy2DAsync(W + (int64_t)c0 * TILE + (int64_t)c0 * TILE * ldw, ldw * sizeof(double), inv,
+                                TILE * sizeof(double), TILE * sizeof(double), TILE, hipMemcpyDeviceToDevice,
+                                e->stream));
+    return launch_transpose(e, inv, TILE, A + (int64_t)c0 * TILE + (int64_t)c0 * TILE * lda, lda, TILE, TILE);
   }
   const int mid = c0 + (c1 - c0 + 1) / 2;
   int rc;
   if ((rc = winv_cols(e, c0, mid))) return rc;
   if ((rc = winv_cols(e, mid, c1))) return rc;
   const int n1 = mid - c0, n2 = c1 - mid;
-  {  // T^T[j][r] = sum_{k>=j} Wa[k][j] * B[r][k]   -> scratch at W[c0.., mid..]
+  {  // T^T[j][r] = sum_{k>=j} U_A[j][k] * B[r][k]   -> scratch at W[c0.., mid..]
     GemmArgs g{};
     g.C = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;
     g.ldc = ldw;
-    g.A = e->dA + (int64_t)mid * TILE + (int64_t)c0 * TILE * e->ld;  // B = L21, k-major
-    g.lda = e->ld;
-    g.B = W + (int64_t)c0 * TILE + (int64_t)c0 * TILE * ldw;          // Wa, contraction on rows
-    g.ldb = ldw;
-    g.tb = 1;
+    g.A = A + (int64_t)mid * TILE + (int64_t)c0 * TILE * lda;  // B = L21
+    g.lda = lda;
+    g.B = A + (int64_t)c0 * TILE + (int64_t)c0 * TILE * lda;   // U_A (upper triangle of the factor buffer)
+    g.ldb = lda;
     g.mt = n2;
     g.nt = n1;
     g.k = n1 * TILE;
@@ -552,13 +571,13 @@ int winv_cols(gmb_engine* e, int c0, int c1) {
     g.beta = 0.0;
     if ((rc = launch_gemm(e, g, 4))) return rc;
   }
-  {  // W21[r][j] = -sum_{s<=r} Wc[r][s] * T^T[j][s]
+  {  // W21[r][j] = -sum_{s<=r} W_C[r][s] * T^T[j][s]
     GemmArgs g{};
     g.C = W + (int64_t)mid * TILE + (int64_t)c0 * TILE * ldw;
     g.ldc = ldw;
-    g.A = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;   // T^T, k-major
+    g.A = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;   // T^T
     g.lda = ldw;
-    g.B = W + (int64_t)mid * TILE + (int64_t)mid * TILE * ldw;  // Wc, k-major
+    g.B = W + (int64_t)mid * TILE + (int64_t)mid * TILE * ldw;  // W_C
     g.ldb = ldw;
     g.mt = n1;
     g.nt = n2;
@@ -568,7 +587,9 @@ int winv_cols(gmb_engine* e, int c0, int c1) {
     g.beta = 0.0;
     if ((rc = launch_gemm(e, g, 4))) return rc;
   }
-  return GMB_OK;
+  // U12 = W21^T into the upper triangle of the factor buffer
+  return launch_transpose(e, W + (int64_t)mid * TILE + (int64_t)c0 * TILE * ldw, ldw,
+                          A + (int64_t)c0 * TILE + (int64_t)mid * TILE * lda, lda, n2 * TILE, n1 * TILE);
 }
 
 template <int KIND>
@@ -603,32 +624,31 @@ int grad_impl(gmb_engine* e, double* grad) {
   if (!e->dgpart && (rc = alloc(e, &e->dgpart, (int64_t)GACC_DOUBLES))) return rc;
   PhaseTimer tg(e);
   const int nt = (int)(e->Np / TILE);
-  // 1. W = L^-1
+  // 1. W = L^-1 (dW, lower) and U = L^-T (factor buffer, upper); the factor is consumed from here on
+  e->factor_consumed = true;
   if ((rc = winv_cols(e, 0, nt))) return rc;
-  if (e->Np > e->N)
-    hipLaunchKernelGGL(reset_pad_rows_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, e->stream,
-                       e->dW, e->Np, e->N, e->Np);
-  // 2. alpha = W^T v = Sigma^-1 y
+  // 2. alpha = W^T v = Sigma^-1 y   (before Sigma^-1 overwrites W)
   hipLaunchKernelGGL(wt_v_kernel, dim3((unsigned)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->dW, e->Np,
                      e->dv, e->N, e->dalpha);
+  if (e->Np > e->N)
+    hipLaunchKernelGGL(reset_pad_cols_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, e->stream,
+                       e->dA, e->ld, e->N, e->Np);
   HIP_TRY(e, hipGetLastError());
-  // 3. Sigma^-1 = W^T W (lower triangle) into the factor buffer -- the factor is consumed
+  // 3. Sigma^-1 = U U^T (lower triangle) into dW
   {
     GemmArgs g{};
-    g.C = e->dA;
-    g.ldc = e->ld;
-    g.A = e->dW;
-    g.lda = e->Np;
-    g.B = e->dW;
-    g.ldb = e->Np;
-    g.ta = g.tb = 1;
+    g.C = e->dW;
+    g.ldc = e->Np;
+    g.A = e->dA;
+    g.lda = e->ld;
+    g.B = e->dA;
+    g.ldb = e->ld;
     g.mt = g.nt = nt;
     g.k = (int)e->Np;
     g.klo_n = 1;
     g.tri = 1;
     g.alpha = 1.0;
     g.beta = 0.0;
-    e->factor_consumed = true;
     if ((rc = launch_gemm(e, g, 4))) return rc;
   }
   // 4. fused trace reductions
@@ -636,8 +656,8 @@ int grad_impl(gmb_engine* e, double* grad) {
   GradArgs a{};
   a.p = e->cp;
   a.pts = train_set(e);
-  a.Z = e->dA;
-  a.ldz = e->ld;
+  a.Z = e->dW;
+  a.ldz = e->Np;
   a.alpha = e->dalpha;
   a.tiles = nt;
   a.ard = s.ard;
@@ -663,7 +683,7 @@ int grad_impl(gmb_engine* e, double* grad) {
   }
   if (rc) return rc;
   const double sigma = e->theta[n_ls + 1];
-  hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->dalpha,
+  hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, e->dW, e->Np, e->dalpha,
                      train_set(e), e->cp, sigma, e->dgpart + diag_off);
   HIP_TRY(e, hipGetLastError());
   tg.stop();

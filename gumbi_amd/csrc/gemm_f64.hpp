@@ -51,11 +51,17 @@ struct GemmArgs {
   // k_hi = khi_n ? min(k, (tn+1)*TILE) : k
   int32_t klo_m, klo_n, khi_n;
   int32_t ta, tb;  // operand layouts (see header comment)
+  // XCD-balanced schedule (filled by gemm_schedule): the computed tiles, enumerated row-major
+  // (tm outer, tn inner), are cut into 8 contiguous runs of equal WORK; block b serves run b % 8.
+  int32_t xstart[9];
 };
 
-// XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous
-// run of tiles so neighbouring tiles (which share an A panel) hit the same L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+// XCD-aware tile order.  The dispatcher places block b on XCD b % 8 (observed, speed only), and
+// each XCD has its own L2.  Handing XCD x one CONTIGUOUS run of the row-major tile list keeps
+// tiles that share an A panel on one L2; cutting the runs by accumulated work (triangular
+// updates skip tiles, triangular operands shorten k ranges) keeps the 8 XCDs equally busy --
+// equal tile COUNTS left the last XCD idle for half of a SYRK (23 vs 44 TFLOP/s measured).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {  // equal-count variant (K-build)
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -66,11 +72,30 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   __shared__ double lds[2][2][KT][PITCH];  // [stage][A|B][k][row]  = 73,728 B
 
-  const int nwg = g.mt * g.nt;
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  const int tm = wg / g.nt;
-  const int tn = wg - tm * g.nt;
-  if (g.tri && tn + g.tri_shift < tm) return;
+  // compact index of this block's tile within its XCD's run, then (tm, tn) by walking the rows
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7;
+    int ci = g.xstart[xcd] + (blockIdx.x >> 3);
+    if (ci >= g.xstart[xcd + 1]) return;
+    if (!g.tri) {
+      tm = ci / g.nt;
+      tn = ci - tm * g.nt;
+    } else {
+      tm = 0;
+      for (;;) {
+        int first = tm - g.tri_shift;
+        first = first < 0 ? 0 : first;
+        const int cnt = g.nt - first;
+        if (ci < cnt) {
+          tn = first + ci;
+          break;
+        }
+        ci -= cnt > 0 ? cnt : 0;
+        ++tm;
+      }
+    }
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -207,18 +232,83 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* sink, int it
   if (blockIdx.x == 0 && threadIdx.x == 0) sink[1] = (double)(t1 - t0);
 }
 
-// flops the kernel actually performs (computed tiles x their k ranges), for roofline accounting
-inline double gemm_flops(const GemmArgs& g) {
-  double f = 0.0;
-  for (int tm = 0; tm < g.mt; ++tm)
-    for (int tn = 0; tn < g.nt; ++tn) {
-      if (g.tri && tn + g.tri_shift < tm) continue;
-      int k_lo = (g.klo_m * tm + g.klo_n * tn) * TILE;
-      int k_hi = g.k;
-      if (g.khi_n && (tn + 1) * TILE < k_hi) k_hi = (tn + 1) * TILE;
-      if (k_hi > k_lo) f += 2.0 * TILE * TILE * (double)(k_hi - k_lo);
+// Host side: fill g.xstart with work-balanced cuts of the row-major list of computed tiles and
+// return the grid size (8 x the longest run).  *flops receives the flops the launch performs.
+// A tile's work is its k range in units of TILE plus one unit for prologue / epilogue; for the
+// patterns the engine uses it depends on tn only, so prefix sums make this O(mt + nt).
+inline int gemm_schedule(GemmArgs& g, double* flops) {
+  const int KTt = (g.k + TILE - 1) / TILE;
+  auto first_of = [&](int tm) {
+    if (!g.tri) return 0;
+    const int f = tm - g.tri_shift;
+    return f < 0 ? 0 : (f > g.nt ? g.nt : f);
+  };
+  auto kunits = [&](int tm, int tn) {
+    const int lo = g.klo_m * tm + g.klo_n * tn;
+    const int hi = g.khi_n ? ((tn + 1) < KTt ? (tn + 1) : KTt) : KTt;
+    return hi > lo ? hi - lo : 0;
+  };
+  // prefix sums over tn (exact when klo_m == 0; otherwise evaluated at tm = 0 -- balance only)
+  static thread_local long long* P = nullptr;
+  static thread_local long long* F = nullptr;
+  static thread_local int cap = 0;
+  if (cap < g.nt + 1) {
+    delete[] P;
+    delete[] F;
+    cap = g.nt + 1;
+    P = new long long[cap];
+    F = new long long[cap];
+  }
+  P[0] = F[0] = 0;
+  for (int tn = 0; tn < g.nt; ++tn) {
+    const int w = kunits(0, tn);
+    P[tn + 1] = P[tn] + w + 1;
+    F[tn + 1] = F[tn] + w;
+  }
+  long long total = 0, funits = 0;
+  long long nact = 0;
+  for (int tm = 0; tm < g.mt; ++tm) {
+    const int f = first_of(tm);
+    total += P[g.nt] - P[f];
+    funits += F[g.nt] - F[f];
+    nact += g.nt - f;
+  }
+  if (g.klo_m) {  // rare: recount the flops exactly
+    funits = 0;
+    for (int tm = 0; tm < g.mt; ++tm)
+      for (int tn = first_of(tm); tn < g.nt; ++tn) funits += kunits(tm, tn);
+  }
+  if (flops)
+    *flops = (g.k % TILE == 0) ? 2.0 * TILE * TILE * TILE * (double)funits
+                               : 2.0 * TILE * TILE * (double)g.k * (double)nact;
+  // cut points: smallest compact index whose preceding work reaches x/8 of the total
+  g.xstart[0] = 0;
+  long long acc = 0, ci = 0;
+  int x = 1, tm = 0;
+  for (; tm < g.mt && x < 8; ++tm) {
+    const int f = first_of(tm);
+    const long long roww = P[g.nt] - P[f];
+    while (x < 8 && (acc + roww) * 8 >= (long long)x * total) {
+      // boundary falls inside (or at the end of) this row: first tn with acc + (P[tn]-P[f]) >= x*total/8
+      int lo = f, hi = g.nt;
+      while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if ((acc + P[mid] - P[f]) * 8 >= (long long)x * total) hi = mid; else lo = mid + 1;
+      }
+      g.xstart[x++] = (int)(ci + (lo - f));
     }
-  return f;
+    acc += roww;
+    ci += g.nt - f;
+  }
+  while (x <= 8) g.xstart[x++] = (int)nact;
+  g.xstart[8] = (int)nact;
+  int longest = 0;
+  for (int i = 0; i < 8; ++i) {
+    if (g.xstart[i + 1] < g.xstart[i]) g.xstart[i + 1] = g.xstart[i];
+    const int len = g.xstart[i + 1] - g.xstart[i];
+    longest = longest > len ? longest : len;
+  }
+  return longest * 8;
 }
 
 }  // namespace gmb

@@ -224,6 +224,29 @@ __global__ void reset_pad_rows_kernel(double* W, int64_t ld, int64_t n, int64_t 
   for (int64_t r = n; r < npad; ++r) W[r + c * ld] = (r == c) ? 1.0 : 0.0;
 }
 
+// dst[c + r*ldd] = src[r + c*lds] for an (rows x cols) block (both column-major); 32 x 32 tiles
+// through LDS so that reads and writes are both contiguous along the fast index.
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, int64_t lds_,
+                                                        double* __restrict__ dst, int64_t ldd, int rows,
+                                                        int cols) {
+  __shared__ double tile[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + tx < rows && c0 + j < cols) tile[j][tx] = src[(r0 + tx) + (int64_t)(c0 + j) * lds_];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + tx < cols && r0 + j < rows) dst[(c0 + tx) + (int64_t)(r0 + j) * ldd] = tile[tx][j];
+}
+
+// U = L^-T lives in the upper triangle of the factor buffer; its padding COLUMNS [n, npad) pick up
+// the y row's pollution through the transposes -- reset them to identity.
+__global__ void reset_pad_cols_kernel(double* U, int64_t ld, int64_t n, int64_t npad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  for (int64_t k = n; k < npad; ++k) U[i + k * ld] = (i == k) ? 1.0 : 0.0;
+}
+
 // alpha = W^T v with W = L^-1 lower triangular, column-major: alpha_j = sum_{k>=j} W[k + j*ld] v_k
 __global__ __launch_bounds__(256) void wt_v_kernel(const double* W, int64_t ld, const double* v,
                                                    int64_t n, double* alpha) {
