@@ -112,6 +112,7 @@ struct gmb_engine {
   gmb_timings tm{};
   std::vector<EventPair> evs;
   bool naive_leaf = false;
+  bool small_tiles = true;
 };
 
 namespace {
@@ -240,23 +241,44 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
 }
 
 // ---- kernel launch helpers ----------------------------------------------------------------
+// `g_in` describes the product in 128-tile units (mt, nt) and elements (k); pick the block tile so
+// that the launch fills the chip, convert, schedule and launch.
 int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   if (g_in.mt <= 0 || g_in.nt <= 0 || g_in.k <= 0) return GMB_OK;
   GemmArgs g = g_in;
+  // tiles the 128 x 128 tiling would compute
+  long long nact = 0;
+  for (int tm = 0; tm < g.mt; ++tm) {
+    int f = g.tri ? tm - g.tri_shift : 0;
+    f = f < 0 ? 0 : (f > g.nt ? g.nt : f);
+    nact += g.nt - f;
+  }
+  const bool in_place = (const double*)g.C == g.B;  // the block must own every column of its rows
+  int wtm = 4, wtn = 4;
+  if (in_place) {
+    if (g.mt != 1) return fail(e, GMB_EINVAL, "internal: in-place GEMM needs m == 128");
+    if (nact < 64) wtn = 1; else if (nact < 128) wtn = 2;
+  } else if (nact < 192 && e->small_tiles) {
+    wtm = wtn = 2;
+  }
+  const int bm = 32 * wtm, bn = 32 * wtn;
+  g.mt = g_in.mt * (TILE / bm);
+  g.nt = g_in.nt * (TILE / bn);
+  g.tri_shift = g_in.tri_shift * (TILE / bm);
   double flops = 0.0;
-  const int nblocks = gemm_schedule(g, &flops);
+  const int nblocks = gemm_schedule(g, bm, bn, &flops);
   if (nblocks <= 0) return GMB_OK;
-  ev_begin(e, ev_kind, flops, g.mt, g.nt, g.k,
-           g.tri | (g.ta << 1) | (g.tb << 2) | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5));
+  ev_begin(e, ev_kind, flops, g_in.mt, g_in.nt, g.k,
+           g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (wtm << 8) | (wtn << 12));
   const dim3 grid(nblocks), block(256);
-  if (g.ta && g.tb)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, e->stream, g);
-  else if (g.ta)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, e->stream, g);
-  else if (g.tb)
-    hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, e->stream, g);
+  if (wtm == 4 && wtn == 4)
+    hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, block, 0, e->stream, g);
+  else if (wtm == 2)
+    hipLaunchKernelGGL((gemm_f64_kernel<2, 2>), grid, block, 0, e->stream, g);
+  else if (wtn == 2)
+    hipLaunchKernelGGL((gemm_f64_kernel<4, 2>), grid, block, 0, e->stream, g);
   else
-    hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, e->stream, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<4, 1>), grid, block, 0, e->stream, g);
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -443,6 +465,7 @@ int chol_leaf(gmb_engine* e, int c) {
   a.logdet = e->dscal;
   a.info = e->dinfo;
   a.row0 = (int64_t)c * TILE;
+  a.dbg = nullptr;
   int rc = launch_leaf(e, a);
   if (rc) return rc;
   // panel rows below the diagonal block:  P <- P inv(L_cc)^T   (in place, one row tile per block)
@@ -777,6 +800,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   }
   const char* nl = getenv("GMB_LEAF_NAIVE");
   e->naive_leaf = nl && nl[0] == '1';
+  const char* st = getenv("GMB_SMALL_TILES");  // tuning switch: 0 forces the 128 x 128 tiling
+  e->small_tiles = !(st && st[0] == '0');
   if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
     gmb_destroy(e);
@@ -1185,6 +1210,7 @@ int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, doubl
   a.logdet = logdet_accum;
   a.info = info ? info : e->dinfo;
   a.row0 = 0;
+  a.dbg = getenv("GMB_LEAF_DBG") ? logdet_accum + 1 : nullptr;  // tuning: stamps after the log-det slot
   return launch_leaf(e, a);
 }
 

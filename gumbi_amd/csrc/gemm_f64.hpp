@@ -1,27 +1,29 @@
 // gemm_f64.hpp -- the one dense contraction of the GP hot path, on gfx950 f64 MFMA.
 //
-//   C[n + m*ldc] = beta * C[n + m*ldc] + alpha * sum_{k in [k_lo, k_hi)} Aop(m,k) * Bop(n,k)
+//   C[n + m*ldc] = beta * C[n + m*ldc] + alpha * sum_{k in [k_lo, k_hi)} A[m + k*lda] * B[n + k*ldb]
 //
-// with every matrix column-major.  Aop(m,k) = A[m + k*lda] (TA = false, "k-major": consecutive
-// m contiguous for a fixed k) or A[k + m*lda] (TA = true); Bop likewise.  Users:
+// with every matrix column-major and both operands "k-major" (consecutive m / n contiguous in
+// memory for a fixed k), so every global load is a full-line coalesced read.  Users:
 //   * Cholesky trailing update (SYRK/GEMM):  A = B = factored panel, C = trailing block,
 //     alpha = -1, beta = 1, tri = 1 (tiles strictly above the diagonal are skipped);
 //   * panel / predict triangular solves:     A = inv(L_kk) (128 x 128), C aliases B,
 //     alpha = 1, beta = 0;
 //   * predict forward-substitution update:   A = L block row, B = solved V columns;
-//   * NLML gradient: L^-1 by recursive block inversion and Sigma^-1 = L^-T L^-1 (TA/TB forms,
-//     per-tile k ranges that skip the structurally zero part of the triangular operands).
+//   * NLML gradient: L^-1 / L^-T by recursive block inversion and Sigma^-1 = L^-T L^-1, with
+//     per-tile k ranges that skip the structurally zero part of the triangular operands.
 //
 // Replaces the LAPACK dpotrf/dtrsm/dpotri calls PyTensor's Cholesky / SolveTriangular ops (and
 // their gradients) make under pm.gp.Marginal (call sites gumbi/regression/pymc/GP.py:580, 811,
 // 845-847).
 //
-// Tiling (MI355X, wave64): 256 threads = 4 waves, block tile 128(m) x 128(n), each wave a
-// 64 x 64 quadrant = 4 x 4 v_mfma_f64_16x16x4_f64 tiles (16 accumulators x 4 f64 per lane).
-// Operands are staged through LDS in [k][row] order with a row pitch of 128+16 doubles so that
-// the two k-slices a 32-lane group reads (ds_read_b64, 64 banks x 4 B) fall on disjoint banks.
-// Global loads are 16 B per lane along the contiguous index, one k-tile ahead of the MFMAs
-// (register-staged double buffer, one barrier per k-tile).
+// Tiling (MI355X, wave64): 256 threads = 4 waves as 2 x 2; a wave owns WTM x WTN
+// v_mfma_f64_16x16x4_f64 tiles, so the block tile is (32 WTM) x (32 WTN): 128 x 128 for the
+// large updates (16 accumulators x 4 f64 per lane), 64 x 64 / 128 x 64 / 128 x 32 when a launch
+// would otherwise leave most of the 256 CUs idle (the bottom of the recursion, the 128-column
+// in-place solves).  Operands are staged through LDS in [k][row] order with a row pitch of
+// (tile + 16) doubles so that the two k-slices a 32-lane group reads (ds_read_b64, 64 banks x
+// 4 B) fall on disjoint banks.  Global loads are 16 B per lane along the contiguous index, one
+// k-tile ahead of the MFMAs (register-staged double buffer, one barrier per k-tile).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,15 +44,13 @@ struct GemmArgs {
   int64_t lda;
   const double* B;
   int64_t ldb;
-  int32_t mt, nt;  // tile counts along m and n
+  int32_t mt, nt;  // tile counts along m and n (in the launch's own block-tile units)
   int32_t k;       // multiple of KT
   double alpha, beta;
-  int32_t tri;        // skip tile (tm, tn) when tn + tri_shift < tm
+  int32_t tri;        // skip tile (tm, tn) when tn + tri_shift < tm (square block tiles only)
   int32_t tri_shift;  // in tiles
-  // per-tile contraction range (in units of TILE): k_lo = (klo_m*tm + klo_n*tn)*TILE,
-  // k_hi = khi_n ? min(k, (tn+1)*TILE) : k
+  // per-tile contraction range: k_lo = klo_m*tm*BM + klo_n*tn*BN, k_hi = khi_n ? min(k, (tn+1)*BN) : k
   int32_t klo_m, klo_n, khi_n;
-  int32_t ta, tb;  // operand layouts (see header comment)
   // XCD-balanced schedule (filled by gemm_schedule): the computed tiles, enumerated row-major
   // (tm outer, tn inner), are cut into 8 contiguous runs of equal WORK; block b serves run b % 8.
   int32_t xstart[9];
@@ -68,9 +68,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {  // equal-count var
   return base + idx;
 }
 
-template <bool TA, bool TB>
+template <int WTM, int WTN>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
-  __shared__ double lds[2][2][KT][PITCH];  // [stage][A|B][k][row]  = 73,728 B
+  constexpr int BM = 32 * WTM, BN = 32 * WTN;   // block tile: 4 waves as 2 x 2, wave tile 16*WTM x 16*WTN
+  constexpr int PA = BM + 16, PB = BN + 16;     // LDS pitches, % 32 == 16 -> conflict-free ds_read_b64
+  constexpr int LA = BM / 2, RA = 256 / LA, NA = KT / RA;  // staging: lanes per k-row, rows per pass, passes
+  constexpr int LB_ = BN / 2, RB = 256 / LB_, NB = KT / RB;
+  __shared__ double lds[2][KT * (PA + PB)];
 
   // compact index of this block's tile within its XCD's run, then (tm, tn) by walking the rows
   int tm, tn;
@@ -103,61 +107,40 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, kq = lane >> 4;
 
-  int k_lo = (g.klo_m * tm + g.klo_n * tn) * TILE;
+  int k_lo = g.klo_m * tm * BM + g.klo_n * tn * BN;
   int k_hi = g.k;
-  if (g.khi_n) k_hi = min(k_hi, (tn + 1) * TILE);
+  if (g.khi_n) k_hi = min(k_hi, (tn + 1) * BN);
   if (k_lo > k_hi) k_lo = k_hi;
 
-  // per-thread staging coordinates
-  //   k-major operand: wave w brings k-rows w, w+4, w+8, w+12; lane covers 2 consecutive rows
-  //   transposed operand: thread covers row (tid>>3)+32p and 2 consecutive k at (tid&7)*2
-  const double* __restrict__ Ag =
-      TA ? g.A + (int64_t)(tm * TILE + (tid >> 3)) * g.lda + 2 * (tid & 7)
-         : g.A + (int64_t)tm * TILE + 2 * lane;
-  const double* __restrict__ Bg =
-      TB ? g.B + (int64_t)(tn * TILE + (tid >> 3)) * g.ldb + 2 * (tid & 7)
-         : g.B + (int64_t)tn * TILE + 2 * lane;
+  const int a_row = tid / LA, a_col = 2 * (tid % LA);
+  const int b_row = tid / LB_, b_col = 2 * (tid % LB_);
+  const double* __restrict__ Ag = g.A + (int64_t)tm * BM + a_col;
+  const double* __restrict__ Bg = g.B + (int64_t)tn * BN + b_col;
 
-  d4 acc[4][4];
+  d4 acc[WTM][WTN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < WTN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
-  d2 ra[4], rb[4];
+  d2 ra[NA], rb[NB];
   const int kt0 = k_lo / KT, kt1 = k_hi / KT;
 
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      if constexpr (TA) {
-        ra[p] = *reinterpret_cast<const d2*>(Ag + (int64_t)kt * KT + (int64_t)(32 * p) * g.lda);
-      } else {
-        ra[p] = *reinterpret_cast<const d2*>(Ag + ((int64_t)kt * KT + wave + 4 * p) * g.lda);
-      }
-      if constexpr (TB) {
-        rb[p] = *reinterpret_cast<const d2*>(Bg + (int64_t)kt * KT + (int64_t)(32 * p) * g.ldb);
-      } else {
-        rb[p] = *reinterpret_cast<const d2*>(Bg + ((int64_t)kt * KT + wave + 4 * p) * g.ldb);
-      }
-    }
+    for (int p = 0; p < NA; ++p)
+      ra[p] = *reinterpret_cast<const d2*>(Ag + ((int64_t)kt * KT + a_row + RA * p) * g.lda);
+#pragma unroll
+    for (int p = 0; p < NB; ++p)
+      rb[p] = *reinterpret_cast<const d2*>(Bg + ((int64_t)kt * KT + b_row + RB * p) * g.ldb);
   };
   auto lstore = [&](int st) {
+    double* As = &lds[st][0];
+    double* Bs = &lds[st][KT * PA];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      if constexpr (TA) {
-        lds[st][0][2 * (tid & 7)][(tid >> 3) + 32 * p] = ra[p][0];
-        lds[st][0][2 * (tid & 7) + 1][(tid >> 3) + 32 * p] = ra[p][1];
-      } else {
-        *reinterpret_cast<d2*>(&lds[st][0][wave + 4 * p][2 * lane]) = ra[p];
-      }
-      if constexpr (TB) {
-        lds[st][1][2 * (tid & 7)][(tid >> 3) + 32 * p] = rb[p][0];
-        lds[st][1][2 * (tid & 7) + 1][(tid >> 3) + 32 * p] = rb[p][1];
-      } else {
-        *reinterpret_cast<d2*>(&lds[st][1][wave + 4 * p][2 * lane]) = rb[p];
-      }
-    }
+    for (int p = 0; p < NA; ++p) *reinterpret_cast<d2*>(&As[(a_row + RA * p) * PA + a_col]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) *reinterpret_cast<d2*>(&Bs[(b_row + RB * p) * PB + b_col]) = rb[p];
   };
 
   if (kt0 < kt1) {
@@ -167,17 +150,19 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     for (int kt = kt0; kt < kt1; ++kt) {
       const int st = (kt - kt0) & 1;
       if (kt + 1 < kt1) gload(kt + 1);
+      const double* As = &lds[st][0];
+      const double* Bs = &lds[st][KT * PA];
 #pragma unroll
       for (int k4 = 0; k4 < KT; k4 += 4) {
-        double a[4], b[4];
+        double a[WTM], b[WTN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = lds[st][0][k4 + kq][wm * 64 + i * 16 + r16];
+        for (int i = 0; i < WTM; ++i) a[i] = As[(k4 + kq) * PA + wm * (16 * WTM) + i * 16 + r16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = lds[st][1][k4 + kq][wn * 64 + j * 16 + r16];
+        for (int j = 0; j < WTN; ++j) b[j] = Bs[(k4 + kq) * PB + wn * (16 * WTN) + j * 16 + r16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WTM; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < WTN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
       }
       if (kt + 1 < kt1) lstore(st ^ 1);
@@ -186,28 +171,28 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   }
 
   // epilogue.  v_mfma_f64_16x16x4_f64 D layout: n = lane & 15, m = (lane >> 4) + 4 * reg.
-  double* __restrict__ Cg = g.C + (int64_t)tn * TILE + wn * 64 + r16;
-  const int64_t m0 = (int64_t)tm * TILE + wm * 64 + kq;
+  double* __restrict__ Cg = g.C + (int64_t)tn * BN + wn * (16 * WTN) + r16;
+  const int64_t m0 = (int64_t)tm * BM + wm * (16 * WTM) + kq;
   if (g.beta == 0.0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double* row = Cg + (m0 + i * 16 + 4 * r) * g.ldc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) row[j * 16] = g.alpha * acc[i][j][r];
+        for (int j = 0; j < WTN; ++j) row[j * 16] = g.alpha * acc[i][j][r];
       }
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double* row = Cg + (m0 + i * 16 + 4 * r) * g.ldc;
-        double c[4];
+        double c[WTN];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = row[j * 16];
+        for (int j = 0; j < WTN; ++j) c[j] = row[j * 16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) row[j * 16] = g.beta * c[j] + g.alpha * acc[i][j][r];
+        for (int j = 0; j < WTN; ++j) row[j * 16] = g.beta * c[j] + g.alpha * acc[i][j][r];
       }
   }
 }
@@ -234,21 +219,21 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* sink, int it
 
 // Host side: fill g.xstart with work-balanced cuts of the row-major list of computed tiles and
 // return the grid size (8 x the longest run).  *flops receives the flops the launch performs.
-// A tile's work is its k range in units of TILE plus one unit for prologue / epilogue; for the
+// A tile's work is its k range in units of KT plus a constant for prologue / epilogue; for the
 // patterns the engine uses it depends on tn only, so prefix sums make this O(mt + nt).
-inline int gemm_schedule(GemmArgs& g, double* flops) {
-  const int KTt = (g.k + TILE - 1) / TILE;
+inline int gemm_schedule(GemmArgs& g, int bm, int bn, double* flops) {
+  const int KU = g.k / KT;
   auto first_of = [&](int tm) {
     if (!g.tri) return 0;
     const int f = tm - g.tri_shift;
     return f < 0 ? 0 : (f > g.nt ? g.nt : f);
   };
   auto kunits = [&](int tm, int tn) {
-    const int lo = g.klo_m * tm + g.klo_n * tn;
-    const int hi = g.khi_n ? ((tn + 1) < KTt ? (tn + 1) : KTt) : KTt;
+    const int lo = (g.klo_m * tm * bm + g.klo_n * tn * bn) / KT;
+    int hi = KU;
+    if (g.khi_n && (tn + 1) * bn / KT < hi) hi = (tn + 1) * bn / KT;
     return hi > lo ? hi - lo : 0;
   };
-  // prefix sums over tn (exact when klo_m == 0; otherwise evaluated at tm = 0 -- balance only)
   static thread_local long long* P = nullptr;
   static thread_local long long* F = nullptr;
   static thread_local int cap = 0;
@@ -259,14 +244,14 @@ inline int gemm_schedule(GemmArgs& g, double* flops) {
     P = new long long[cap];
     F = new long long[cap];
   }
+  const int fixed = 4;  // prologue + epilogue expressed in k-tile units
   P[0] = F[0] = 0;
   for (int tn = 0; tn < g.nt; ++tn) {
     const int w = kunits(0, tn);
-    P[tn + 1] = P[tn] + w + 1;
+    P[tn + 1] = P[tn] + w + fixed;
     F[tn + 1] = F[tn] + w;
   }
-  long long total = 0, funits = 0;
-  long long nact = 0;
+  long long total = 0, funits = 0, nact = 0;
   for (int tm = 0; tm < g.mt; ++tm) {
     const int f = first_of(tm);
     total += P[g.nt] - P[f];
@@ -278,19 +263,15 @@ inline int gemm_schedule(GemmArgs& g, double* flops) {
     for (int tm = 0; tm < g.mt; ++tm)
       for (int tn = first_of(tm); tn < g.nt; ++tn) funits += kunits(tm, tn);
   }
-  if (flops)
-    *flops = (g.k % TILE == 0) ? 2.0 * TILE * TILE * TILE * (double)funits
-                               : 2.0 * TILE * TILE * (double)g.k * (double)nact;
-  // cut points: smallest compact index whose preceding work reaches x/8 of the total
+  if (flops) *flops = 2.0 * bm * bn * KT * (double)funits;
   g.xstart[0] = 0;
   long long acc = 0, ci = 0;
-  int x = 1, tm = 0;
-  for (; tm < g.mt && x < 8; ++tm) {
+  int x = 1;
+  for (int tm = 0; tm < g.mt && x < 8; ++tm) {
     const int f = first_of(tm);
     const long long roww = P[g.nt] - P[f];
     while (x < 8 && (acc + roww) * 8 >= (long long)x * total) {
-      // boundary falls inside (or at the end of) this row: first tn with acc + (P[tn]-P[f]) >= x*total/8
-      int lo = f, hi = g.nt;
+      int lo = f, hi = g.nt;  // first tn with acc + (P[tn] - P[f]) >= x * total / 8
       while (lo < hi) {
         const int mid = (lo + hi) / 2;
         if ((acc + P[mid] - P[f]) * 8 >= (long long)x * total) hi = mid; else lo = mid + 1;

@@ -66,7 +66,75 @@ struct LeafArgs {
   double* logdet;   // += sum_{c<nvalid} log L_cc
   int32_t* info;    // set to row0 + c + 1 of the first non-positive pivot (0 = ok)
   int64_t row0;     // global index of the block's first row (for info)
+  double* dbg;      // optional: 8 wall-clock stamps (100 MHz) at the phase boundaries
 };
+
+#define LEAF_STAMP(i) do { if (g.dbg && threadIdx.x == 0) g.dbg[i] = (double)wall_clock64(); } while (0)
+
+// sqrt(p) and 1/sqrt(p) from the hardware rsq estimate + two Newton steps and one residual
+// correction (the dependent chain is ~10 FMAs instead of a full sqrt followed by a division)
+__device__ __forceinline__ void sqrt_rsqrt(double p, double& l, double& rl) {
+  double y = __builtin_amdgcn_rsq(p);
+  const double h = 0.5 * p;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  double s = p * y;
+  s = fma(0.5 * y, fma(-s, s, p), s);
+  y = y * fma(-h * y, y, 1.5);
+  l = s;
+  rl = y;
+}
+
+// Wave 0: factor the 16 x 16 diagonal sub-block at (c0, c0) held in S (lower triangle), leave
+// L_ss in S, 1/diag in rdiag, X_ss = L_ss^-1 dense in dinv_s (column-major) and its strict lower
+// part transposed into the upper triangle of S_ss.  Everything stays in registers; pivots,
+// multipliers and the entries of L are moved between lanes with v_readlane.
+__device__ __forceinline__ void factor_diag16(double* S, double* dinv_s, double* rdiag, int c0, int nv,
+                                              int32_t* info, int64_t row0) {
+  const int lane = threadIdx.x & 63;
+  const int rr = lane < SB ? lane : SB - 1;
+  double d[SB];
+#pragma unroll
+  for (int c = 0; c < SB; ++c) d[c] = S[(c0 + c) * LP + c0 + rr];
+  double rl[SB];
+  double x[SB];  // X = L^-1, column `rr` per lane:  x[a] = ((a == j) - sum_{k<a} L[a][k] x[k]) / L[a][a]
+#pragma unroll
+  for (int c = 0; c < SB; ++c) {
+    double piv = readlane_f64(d[c], c);
+    if (!(piv > 0.0)) {  // also catches NaN; wave-uniform
+      if (lane == 0 && c0 + c < nv) atomicCAS(info, 0, (int)(row0 + c0 + c + 1));
+      piv = 1.0;
+    }
+    // row c of L is final here (its entries sit in lane c, registers 0..c-1): start row c of the
+    // inverse -- independent of the pivot's sqrt chain, so it fills that latency
+    double t = (c == rr) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < c; ++k) t = fma(-readlane_f64(d[k], c), x[k], t);
+    double l;
+    sqrt_rsqrt(piv, l, rl[c]);
+    x[c] = t * rl[c];
+    d[c] = (rr == c) ? l : d[c] * rl[c];
+#pragma unroll
+    for (int c2 = c + 1; c2 < SB; ++c2) {
+      const double m = readlane_f64(d[c], c2);  // L[c2][c]
+      d[c2] = fma(-d[c], m, d[c2]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < SB; ++c) {
+    if (lane == c) rdiag[c0 + c] = rl[c];
+    if (lane < SB) {
+      if (c <= lane) S[(c0 + c) * LP + c0 + lane] = d[c];   // L_ss, row `lane`
+    }
+  }
+  if (lane < SB) {
+#pragma unroll
+    for (int a = 0; a < SB; ++a) {
+      dinv_s[lane * SB + a] = x[a];                          // X[a][lane], column-major
+      if (a > lane) S[(c0 + a) * LP + c0 + lane] = x[a];     // strict lower part, transposed
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
   __shared__ double S[LB * LP];        // 133,120 B
@@ -79,90 +147,89 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
   const int wave = tid >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int nv = g.nvalid;
+  LEAF_STAMP(0);
 
   // ---- load: lower triangle of real columns, identity elsewhere, zeros above the diagonal ----
-  for (int idx = tid; idx < LB * LB; idx += 256) {
-    const int c = idx >> 7, r = idx & 127;
-    double v = (r == c) ? 1.0 : 0.0;
-    if (c < nv && r >= c) v = g.A[r + (int64_t)c * g.lda];
-    S[c * LP + r] = v;
+  // (8 independent loads in flight per thread: the block is read once, latency-bound otherwise)
+  {
+    // all 32 16-byte loads of a thread are issued before the first use (one latency, not 64)
+    d2 buf[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int p = tid + 256 * i;            // pair index: column p / 64, rows 2 (p % 64), +1
+      const int c = p >> 6, r = (p & 63) * 2;
+      buf[i] = *reinterpret_cast<const d2*>(g.A + r + (int64_t)c * g.lda);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int p = tid + 256 * i;
+      const int c = p >> 6, r = (p & 63) * 2;
+      d2 v = buf[i];
+      if (c >= nv) v = d2{0.0, 0.0};
+      if (r < c) v[0] = 0.0;
+      if (r + 1 < c) v[1] = 0.0;
+      if (c >= nv && r == c) v[0] = 1.0;
+      if (c >= nv && r + 1 == c) v[1] = 1.0;
+      S[c * LP + r] = v[0];
+      S[c * LP + r + 1] = v[1];
+    }
   }
   __syncthreads();
+  LEAF_STAMP(1);
 
-  // ---- factorisation ---------------------------------------------------------------------
-  for (int s = 0; s < LB / SB; ++s) {
+  // ---- factorisation: right-looking over 16-column sub-panels with one-step look-ahead -------
+  if (wave == 0) factor_diag16(S, dinv[0], rdiag, 0, nv, g.info, g.row0);
+  __syncthreads();
+  for (int s = 0; s < LB / SB - 1; ++s) {
     const int c0 = s * SB;
-    if (wave == 0) {
-      // 16 x 16 diagonal sub-block, row `lane` per lane (lanes >= 16 mirror lane 15)
-      const int rr = lane < SB ? lane : SB - 1;
-      double d[SB];
+    // (B) sub-panel rows below the diagonal sub-block:  P <- P X_ss^T  (MFMA, in place per tile)
+    for (int tr = s + 1 + wave; tr < LB / SB; tr += 4) {
+      const int rw = tr * SB;
+      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+      acc = mfma_tile_k16(dinv[s], SB, &S[c0 * LP + rw], LP, acc);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int c = 0; c < SB; ++c) d[c] = S[(c0 + c) * LP + c0 + rr];
-#pragma unroll
-      for (int c = 0; c < SB; ++c) {
-        double piv = readlane_f64(d[c], c);
-        if (!(piv > 0.0)) {  // also catches NaN; wave-uniform
-          if (lane == 0 && c0 + c < nv) atomicCAS(g.info, 0, (int)(g.row0 + c0 + c + 1));
-          piv = 1.0;
-        }
-        const double l = sqrt(piv);
-        const double rl = 1.0 / l;
-        d[c] = (rr == c) ? l : d[c] * rl;
-        if (lane == c) rdiag[c0 + c] = rl;
-#pragma unroll
-        for (int c2 = c + 1; c2 < SB; ++c2) {
-          const double m = readlane_f64(d[c], c2);  // L[c2][c]
-          d[c2] -= d[c] * m;
-        }
-      }
-      if (lane < SB) {
-#pragma unroll
-        for (int c = 0; c < SB; ++c)
-          if (c <= lane) S[(c0 + c) * LP + c0 + lane] = d[c];
-      }
+      for (int r = 0; r < 4; ++r) S[(c0 + kq + 4 * r) * LP + rw + r16] = acc[r];
     }
     __syncthreads();
-    // sub-panel rows below the diagonal sub-block: X * L_ss^T = P, row per thread
-    if (wave > 0) {
-      const int x = c0 + SB + (tid - 64);
-      if (x < LB) {
-        double p[SB];
-#pragma unroll
-        for (int c = 0; c < SB; ++c) p[c] = S[(c0 + c) * LP + x];
-#pragma unroll
-        for (int c = 0; c < SB; ++c) {
-          double a = p[c];
-#pragma unroll
-          for (int k = 0; k < c; ++k) a -= p[k] * S[(c0 + k) * LP + c0 + c];
-          p[c] = a * rdiag[c0 + c];
-        }
-#pragma unroll
-        for (int c = 0; c < SB; ++c) S[(c0 + c) * LP + x] = p[c];
-      }
-    }
-    __syncthreads();
-    // rank-16 update of the remaining lower triangle: tiles (tc, tr), s < tc <= tr < 8
+    // (C) rank-16 update of the remaining lower triangle.  Wave 0 takes the next diagonal tile
+    //     first and factors it straight away, hiding that dependent chain behind the other
+    //     waves' MFMA tiles.
     {
-      const int n = LB / SB - 1 - s;
-      const int ntile = n * (n + 1) / 2;
-      for (int t = wave; t < ntile; t += 4) {
-        int tc = 0, rem = t;
-        while (rem >= n - tc) {
-          rem -= n - tc;
-          ++tc;
-        }
-        const int tr = tc + rem;
-        const int cc = (s + 1 + tc) * SB, rw = (s + 1 + tr) * SB;
+      const int n = LB / SB - 1 - s;  // remaining block rows
+      if (wave == 0) {
+        const int cc = (s + 1) * SB;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-        acc = mfma_tile_k16(&S[c0 * LP + cc], LP, &S[c0 * LP + rw], LP, acc);
+        acc = mfma_tile_k16(&S[c0 * LP + cc], LP, &S[c0 * LP + cc], LP, acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S[(cc + kq + 4 * r) * LP + rw + r16] -= acc[r];
+        for (int r = 0; r < 4; ++r) S[(cc + kq + 4 * r) * LP + cc + r16] -= acc[r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        factor_diag16(S, dinv[s + 1], rdiag, cc, nv, g.info, g.row0);
+      } else {
+        const int ntile = n * (n + 1) / 2;
+        for (int t = wave; t < ntile; t += 3) {  // t = 0 is the diagonal tile wave 0 owns
+          int tc = 0, rem = t;
+          while (rem >= n - tc) {
+            rem -= n - tc;
+            ++tc;
+          }
+          const int tr = tc + rem;
+          const int cc = (s + 1 + tc) * SB, rw = (s + 1 + tr) * SB;
+          d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+          acc = mfma_tile_k16(&S[c0 * LP + cc], LP, &S[c0 * LP + rw], LP, acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[(cc + kq + 4 * r) * LP + rw + r16] -= acc[r];
+        }
       }
     }
     __syncthreads();
   }
 
+  LEAF_STAMP(2);
   // ---- write the factor back (real columns only), accumulate log-det ------------------------
+#pragma unroll 8
   for (int idx = tid; idx < LB * LB; idx += 256) {
     const int c = idx >> 7, r = idx & 127;
     if (c < nv && r >= c) g.A[r + (int64_t)c * g.lda] = S[c * LP + r];
@@ -177,36 +244,42 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     if (tid == 0 && g.logdet) atomicAdd(g.logdet, red[0] + red[1] + red[2] + red[3]);
   }
   if (g.invL == nullptr) return;
+  LEAF_STAMP(3);
 
   // ---- inversion ----------------------------------------------------------------------------
-  if (nv < LB) {  // panel rows do not belong to the triangular factor; padding is identity
+  if (nv < LB) {
+    // Only the last diagonal block of a matrix is ragged.  Its panel rows (the y row, padding)
+    // are not part of the triangular factor and the padding is identity: rebuild the affected
+    // state the slow way.
+    __syncthreads();
     for (int idx = tid; idx < LB * LB; idx += 256) {
       const int c = idx >> 7, r = idx & 127;
       if (c < nv && r >= nv) S[c * LP + r] = 0.0;
       if (c >= nv && r >= c) S[c * LP + r] = (r == c) ? 1.0 : 0.0;
+      if (r < c) S[c * LP + r] = 0.0;  // drop the X_ss transposes stored during factorisation
     }
     if (tid >= nv && tid < LB) rdiag[tid] = 1.0;
-  }
-  __syncthreads();
-  if (tid < LB) {  // X_ss for all 8 diagonal sub-blocks, one column per thread
-    const int s = tid >> 4, j = tid & 15, c0 = s * SB;
-    double xc[SB];
+    __syncthreads();
+    if (tid < LB) {
+      const int s = tid >> 4, j = tid & 15, c0 = s * SB;
+      double xc[SB];
 #pragma unroll
-    for (int a = 0; a < SB; ++a) {
-      double t = (a == j) ? 1.0 : 0.0;
+      for (int a = 0; a < SB; ++a) {
+        double t = (a == j) ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < a; ++k) t -= S[(c0 + k) * LP + c0 + a] * xc[k];
-      xc[a] = t * rdiag[c0 + a];
+        for (int k = 0; k < a; ++k) t -= S[(c0 + k) * LP + c0 + a] * xc[k];
+        xc[a] = t * rdiag[c0 + a];
+      }
+#pragma unroll
+      for (int a = 0; a < SB; ++a) dinv[s][j * SB + a] = xc[a];
     }
+    __syncthreads();
+    if (tid < LB) {
+      const int s = tid >> 4, j = tid & 15, c0 = s * SB;
 #pragma unroll
-    for (int a = 0; a < SB; ++a) dinv[s][j * SB + a] = xc[a];
-  }
-  __syncthreads();
-  if (tid < LB) {  // strict lower part of X_ss, transposed into the upper triangle of S_ss
-    const int s = tid >> 4, j = tid & 15, c0 = s * SB;
-#pragma unroll
-    for (int a = 0; a < SB; ++a)
-      if (a > j) S[(c0 + a) * LP + c0 + j] = dinv[s][j * SB + a];
+      for (int a = 0; a < SB; ++a)
+        if (a > j) S[(c0 + a) * LP + c0 + j] = dinv[s][j * SB + a];
+    }
   }
   __syncthreads();
   for (int dist = 1; dist < LB / SB; ++dist) {
@@ -241,7 +314,9 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     }
     __syncthreads();
   }
+  LEAF_STAMP(4);
   // X[p][q] (p > q) sits at S[p*LP + q]; diagonal in rdiag
+#pragma unroll 8
   for (int idx = tid; idx < LB * LB; idx += 256) {
     const int q = idx >> 7, p = idx & 127;
     double v = 0.0;
@@ -249,6 +324,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     else if (p > q) v = S[p * LP + q];
     g.invL[p + q * LB] = v;
   }
+  LEAF_STAMP(5);
 }
 
 // Plain reference leaf (one column at a time, no MFMA) -- selected with GMB_LEAF_NAIVE=1 to

@@ -80,13 +80,17 @@ def test_mfma_gemm_block_op_layouts(gpu):
     torch.cuda.synchronize()
     got2 = tC2.cpu().numpy().T
     want2 = 2.0 * B @ A.T
+    # tri: every entry on or below the diagonal of the (n, m) index space is computed; block
+    # tiles strictly above it are skipped (how many depends on the tile size the launch picked)
+    ni, mi = np.meshgrid(np.arange(n), np.arange(m), indexing="ij")
+    low = ni >= mi
+    assert rel(got2[low], want2[low]) < 1e-13
     for tm in range(m // 128):
         for tn in range(n // 128):
-            blk = got2[tn * 128:(tn + 1) * 128, tm * 128:(tm + 1) * 128]
             if tn < tm:
-                assert np.all(blk == 7.0)
-            else:
-                assert rel(blk, want2[tn * 128:(tn + 1) * 128, tm * 128:(tm + 1) * 128]) < 1e-13
+                assert np.all(got2[tn * 128:(tn + 1) * 128, tm * 128:(tm + 1) * 128] == 7.0)
+    upper = got2[~low]
+    assert np.all((upper == 7.0) | (np.abs(upper - want2[~low]) < 1e-10 * np.abs(want2).max()))
 
 
 @pytest.mark.parametrize("naive", [False, True])
