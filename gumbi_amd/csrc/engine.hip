@@ -247,10 +247,11 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   if (g_in.mt <= 0 || g_in.nt <= 0 || g_in.k <= 0) return GMB_OK;
   GemmArgs g = g_in;
   // tiles the 128 x 128 tiling would compute
+  if (g.nblk_stride < 1) g.nblk_stride = 1;
   long long nact = 0;
   for (int tm = 0; tm < g.mt; ++tm) {
-    int f = g.tri ? tm - g.tri_shift : 0;
-    f = f < 0 ? 0 : (f > g.nt ? g.nt : f);
+    int f = g.tri ? gemm_first_tn((int64_t)tm * TILE - g.tri_off - (TILE - 1), TILE, g.nblk_stride) : 0;
+    f = f > g.nt ? g.nt : f;
     nact += g.nt - f;
   }
   const bool in_place = (const double*)g.C == g.B;  // the block must own every column of its rows
@@ -264,7 +265,6 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   const int bm = 32 * wtm, bn = 32 * wtn;
   g.mt = g_in.mt * (TILE / bm);
   g.nt = g_in.nt * (TILE / bn);
-  g.tri_shift = g_in.tri_shift * (TILE / bm);
   double flops = 0.0;
   const int nblocks = gemm_schedule(g, bm, bn, &flops);
   if (nblocks <= 0) return GMB_OK;
@@ -502,7 +502,6 @@ int chol_cols(gmb_engine* e, int c0, int c1) {
   g.alpha = -1.0;
   g.beta = 1.0;
   g.tri = 1;
-  g.tri_shift = 0;
   rc = launch_gemm(e, g, 0);
   if (rc) return rc;
   return chol_cols(e, mid, c1);
@@ -1234,8 +1233,110 @@ int gmb_blk_gemm_nt(gmb_engine* e, double* C, int64_t ldc, const double* A, int6
   g.alpha = alpha;
   g.beta = beta;
   g.tri = tri;
-  g.tri_shift = (int)tri_shift;
+  g.tri_off = (int)(tri_shift * TILE);
   return launch_gemm(e, g, 0);
+}
+
+int gmb_blk_gemm_strided(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                         int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, int32_t tri,
+                         int64_t tri_off, int32_t nblk_stride) {
+  if (!e || !C || !A || !B) return fail(e, GMB_EINVAL, "null gemm operand");
+  if (m % TILE || n % TILE || k % KT || m < 0 || n < 0 || k < 0 || nblk_stride < 1)
+    return fail(e, GMB_EINVAL, "gemm sizes must be multiples of 128 (m, n) and 16 (k)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  GemmArgs g{};
+  g.C = C;
+  g.ldc = ldc;
+  g.A = A;
+  g.lda = lda;
+  g.B = B;
+  g.ldb = ldb;
+  g.mt = (int)(m / TILE);
+  g.nt = (int)(n / TILE);
+  g.k = (int)k;
+  g.alpha = alpha;
+  g.beta = beta;
+  g.tri = tri;
+  g.tri_off = (int)tri_off;
+  g.nblk_stride = nblk_stride;
+  return launch_gemm(e, g, 0);
+}
+
+int gmb_blk_pack(gmb_engine* e, double* mat, int64_t ld, int64_t stride_blocks, int32_t count, double* packed,
+                 int64_t ldp, int32_t to_packed) {
+  if (!e || !mat || !packed || count < 0 || stride_blocks < 1 || ldp < (int64_t)count * TILE)
+    return fail(e, GMB_EINVAL, "bad pack arguments");
+  if (count == 0) return GMB_OK;
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(pack_blocks_kernel, dim3(count, TILE / 2), dim3(256), 0, e->stream, mat, ld, stride_blocks,
+                     count, packed, ldp, to_packed);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_t* Np, void** invL, void** scal,
+                       void** info) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  if (A) *A = e->dA;
+  if (ld) *ld = e->ld;
+  if (Nr) *Nr = e->Nr;
+  if (Np) *Np = e->Np;
+  if (invL) *invL = e->dInv;
+  if (scal) *scal = e->dscal;
+  if (info) *info = e->dinfo;
+  return GMB_OK;
+}
+
+int gmb_local_logdet_info(gmb_engine* e, double* logdet, int64_t* info) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  if (!logdet || !info) return fail(e, GMB_EINVAL, "null output");
+  HIP_TRY(e, hipSetDevice(e->device));
+  int32_t i32 = 0;
+  HIP_TRY(e, hipMemcpyAsync(logdet, e->dscal, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(&i32, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  *info = i32;
+  return GMB_OK;
+}
+
+int gmb_begin_external_factorization(gmb_engine* e) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  e->factored = false;
+  e->factor_consumed = false;
+  e->notpd = -1;
+  HIP_TRY(e, hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream));
+  return GMB_OK;
+}
+
+int gmb_finish_external_factorization(gmb_engine* e, double logdet, int64_t info) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (info != 0) {
+    e->notpd = info - 1;
+    return fail(e, GMB_ENOTPD, "covariance matrix is not positive definite at row %lld", (long long)e->notpd);
+  }
+  HIP_TRY(e, hipMemsetAsync(e->dscal + 1, 0, sizeof(double), e->stream));
+  hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
+                     e->dscal + 1);
+  HIP_TRY(e, hipGetLastError());
+  double vn = 0.0;
+  HIP_TRY(e, hipMemcpyAsync(&vn, e->dscal + 1, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  ev_collect(e);
+  e->logdet = logdet;
+  e->vnorm2 = vn;
+  if (!std::isfinite(logdet) || !std::isfinite(vn)) {
+    e->notpd = 0;
+    return fail(e, GMB_ENOTPD, "factorisation produced non-finite values");
+  }
+  e->factored = true;
+  return GMB_OK;
 }
 
 int gmb_blk_kbuild(gmb_engine* e, double* out, int64_t ldo, int64_t i0, int64_t ni, int64_t j0, int64_t nj) {

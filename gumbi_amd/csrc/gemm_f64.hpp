@@ -47,8 +47,15 @@ struct GemmArgs {
   int32_t mt, nt;  // tile counts along m and n (in the launch's own block-tile units)
   int32_t k;       // multiple of KT
   double alpha, beta;
-  int32_t tri;        // skip tile (tm, tn) when tn + tri_shift < tm (square block tiles only)
-  int32_t tri_shift;  // in tiles
+  // tri: skip tile (tm, tn) when it lies strictly above the diagonal, i.e. when its last row
+  // noff(tn) + BN - 1 + tri_off is smaller than its first column tm*BM (rows / columns measured
+  // from the origins of C's row and column ranges; tri_off shifts the row origin).
+  int32_t tri;
+  int32_t tri_off;     // elements
+  // n-side block stride: the n index walks 128-row blocks that are `nblk_stride` blocks apart in
+  // memory (1 = contiguous).  This is how one rank of the block-cyclic row partition updates
+  // only the block rows it owns: noff(tn) = ((tn*BN)/128)*nblk_stride*128 + (tn*BN)%128.
+  int32_t nblk_stride;
   // per-tile contraction range: k_lo = klo_m*tm*BM + klo_n*tn*BN, k_hi = khi_n ? min(k, (tn+1)*BN) : k
   int32_t klo_m, klo_n, khi_n;
   // XCD-balanced schedule (filled by gemm_schedule): the computed tiles, enumerated row-major
@@ -66,6 +73,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {  // equal-count var
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// row offset of n-tile tn, and the first n-tile whose rows reach element T (see GemmArgs)
+__host__ __device__ __forceinline__ int64_t gemm_noff(int tn, int bn, int stride) {
+  const int64_t e = (int64_t)tn * bn;
+  return (e >> 7) * stride * 128 + (e & 127);
+}
+__host__ __device__ __forceinline__ int gemm_first_tn(int64_t T, int bn, int stride) {
+  if (T <= 0) return 0;
+  const int64_t S = (int64_t)stride * 128;
+  const int64_t q = T / S, r = T % S;
+  const int per = 128 / bn;
+  if (r == 0) return (int)(q * per);
+  if (r > 128 - bn) return (int)((q + 1) * per);
+  return (int)(q * per + (r + bn - 1) / bn);
 }
 
 template <int WTM, int WTN>
@@ -88,14 +110,14 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     } else {
       tm = 0;
       for (;;) {
-        int first = tm - g.tri_shift;
-        first = first < 0 ? 0 : first;
+        int first = gemm_first_tn((int64_t)tm * BM - g.tri_off - (BN - 1), BN, g.nblk_stride);
+        first = first > g.nt ? g.nt : first;
         const int cnt = g.nt - first;
         if (ci < cnt) {
           tn = first + ci;
           break;
         }
-        ci -= cnt > 0 ? cnt : 0;
+        ci -= cnt;
         ++tm;
       }
     }
@@ -115,7 +137,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int a_row = tid / LA, a_col = 2 * (tid % LA);
   const int b_row = tid / LB_, b_col = 2 * (tid % LB_);
   const double* __restrict__ Ag = g.A + (int64_t)tm * BM + a_col;
-  const double* __restrict__ Bg = g.B + (int64_t)tn * BN + b_col;
+  const int64_t noff = gemm_noff(tn, BN, g.nblk_stride);
+  const double* __restrict__ Bg = g.B + noff + b_col;
 
   d4 acc[WTM][WTN];
 #pragma unroll
@@ -171,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   }
 
   // epilogue.  v_mfma_f64_16x16x4_f64 D layout: n = lane & 15, m = (lane >> 4) + 4 * reg.
-  double* __restrict__ Cg = g.C + (int64_t)tn * BN + wn * (16 * WTN) + r16;
+  double* __restrict__ Cg = g.C + noff + wn * (16 * WTN) + r16;
   const int64_t m0 = (int64_t)tm * BM + wm * (16 * WTM) + kq;
   if (g.beta == 0.0) {
 #pragma unroll
@@ -225,8 +248,8 @@ inline int gemm_schedule(GemmArgs& g, int bm, int bn, double* flops) {
   const int KU = g.k / KT;
   auto first_of = [&](int tm) {
     if (!g.tri) return 0;
-    const int f = tm - g.tri_shift;
-    return f < 0 ? 0 : (f > g.nt ? g.nt : f);
+    const int f = gemm_first_tn((int64_t)tm * bm - g.tri_off - (bn - 1), bn, g.nblk_stride);
+    return f > g.nt ? g.nt : f;
   };
   auto kunits = [&](int tm, int tn) {
     const int lo = (g.klo_m * tm * bm + g.klo_n * tn * bn) / KT;

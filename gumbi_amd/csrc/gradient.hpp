@@ -247,6 +247,25 @@ __global__ void reset_pad_cols_kernel(double* U, int64_t ld, int64_t n, int64_t 
   for (int64_t k = n; k < npad; ++k) U[i + k * ld] = (i == k) ? 1.0 : 0.0;
 }
 
+// Gather / scatter `count` 128 x 128 blocks between a strided set of block rows of a column-major
+// matrix (rows first_row + t*stride_blocks*128, 128 columns starting at `mat`) and a packed
+// (count*128) x 128 column-major buffer.  Used around the panel all-gather of the multi-GPU
+// Cholesky (each rank owns every G-th block row).
+__global__ __launch_bounds__(256) void pack_blocks_kernel(const double* __restrict__ mat, int64_t ld,
+                                                          int64_t stride_blocks, int count,
+                                                          double* __restrict__ packed, int64_t ldp,
+                                                          int to_packed) {
+  const int t = blockIdx.x;                // block index
+  const int c = blockIdx.y * 2 + (threadIdx.x >> 7);  // column 0..127 (2 per workgroup)
+  const int r = threadIdx.x & 127;
+  const int64_t mi = (int64_t)t * stride_blocks * 128 + r + (int64_t)c * ld;
+  const int64_t pi = (int64_t)t * 128 + r + (int64_t)c * ldp;
+  if (t < count) {
+    if (to_packed) packed[pi] = mat[mi];
+    else const_cast<double*>(mat)[mi] = packed[pi];
+  }
+}
+
 // alpha = W^T v with W = L^-1 lower triangular, column-major: alpha_j = sum_{k>=j} W[k + j*ld] v_k
 __global__ __launch_bounds__(256) void wt_v_kernel(const double* W, int64_t ld, const double* v,
                                                    int64_t n, double* alpha) {

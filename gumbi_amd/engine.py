@@ -177,6 +177,17 @@ _SIGNATURES = {
     "gmb_blk_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                   C.c_int32, C.c_int64]),
+    "gmb_blk_gemm_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                       C.c_int32, C.c_int64, C.c_int32]),
+    "gmb_blk_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                               C.c_int32]),
+    "gmb_factor_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p)]),
+    "gmb_begin_external_factorization": (C.c_int, [C.c_void_p]),
+    "gmb_local_logdet_info": (C.c_int, [C.c_void_p, _DBL_P, C.POINTER(C.c_int64)]),
+    "gmb_finish_external_factorization": (C.c_int, [C.c_void_p, C.c_double, C.c_int64]),
     "gmb_blk_kbuild": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
 }
 
@@ -386,6 +397,36 @@ class Engine:
         self._check(self._lib.gmb_blk_gemm_nt(self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda,
                                               C.c_void_p(b_ptr), ldb, m, n, k, alpha, beta, tri, tri_shift),
                     "gmb_blk_gemm_nt")
+
+    def blk_gemm_strided(self, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, m, n, k, alpha, beta, tri=0, tri_off=0,
+                         nblk_stride=1):
+        self._check(self._lib.gmb_blk_gemm_strided(self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda,
+                                                   C.c_void_p(b_ptr), ldb, m, n, k, alpha, beta, tri, tri_off,
+                                                   nblk_stride), "gmb_blk_gemm_strided")
+
+    def blk_pack(self, mat_ptr, ld, stride_blocks, count, packed_ptr, ldp, to_packed=True):
+        self._check(self._lib.gmb_blk_pack(self._h, C.c_void_p(mat_ptr), ld, stride_blocks, count,
+                                           C.c_void_p(packed_ptr), ldp, int(bool(to_packed))), "gmb_blk_pack")
+
+    def factor_buffers(self) -> dict:
+        A, inv, scal, info = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ld, Nr, Np = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.gmb_factor_buffers(self._h, C.byref(A), C.byref(ld), C.byref(Nr), C.byref(Np),
+                                                 C.byref(inv), C.byref(scal), C.byref(info)), "gmb_factor_buffers")
+        return dict(A=A.value, ld=ld.value, Nr=Nr.value, Np=Np.value, invL=inv.value, scal=scal.value,
+                    info=info.value)
+
+    def begin_external_factorization(self):
+        self._check(self._lib.gmb_begin_external_factorization(self._h), "gmb_begin_external_factorization")
+
+    def local_logdet_info(self):
+        ld, info = C.c_double(), C.c_int64()
+        self._check(self._lib.gmb_local_logdet_info(self._h, C.byref(ld), C.byref(info)), "gmb_local_logdet_info")
+        return ld.value, info.value
+
+    def finish_external_factorization(self, logdet: float, info: int):
+        self._check(self._lib.gmb_finish_external_factorization(self._h, float(logdet), int(info)),
+                    "gmb_finish_external_factorization")
 
     def blk_kbuild(self, out_ptr, ldo, i0, ni, j0, nj):
         self._check(self._lib.gmb_blk_kbuild(self._h, C.c_void_p(out_ptr), ldo, i0, ni, j0, nj), "gmb_blk_kbuild")

@@ -191,6 +191,29 @@ int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, doubl
 int gmb_blk_gemm_nt(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda,
                     const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha,
                     double beta, int32_t tri, int64_t tri_shift);
+/* As gmb_blk_gemm_nt, for one rank of the block-cyclic row partition: the n index walks 128-row
+ * blocks that are `nblk_stride` blocks apart in memory (B and C both), and `tri` skips tiles whose
+ * last row (n offset + tri_off) lies above their first column (m offset). */
+int gmb_blk_gemm_strided(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda,
+                         const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha,
+                         double beta, int32_t tri, int64_t tri_off, int32_t nblk_stride);
+/* Gather (to_packed = 1) / scatter (0) `count` 128 x 128 blocks between block rows
+ * mat + t*stride_blocks*128 (t < count, leading dimension ld) and a packed (count*128) x 128
+ * column-major buffer (leading dimension ldp) -- the send / receive side of the panel all-gather. */
+int gmb_blk_pack(gmb_engine* e, double* mat, int64_t ld, int64_t stride_blocks, int32_t count,
+                 double* packed, int64_t ldp, int32_t to_packed);
+/* Device pointers of the engine's own resident state, for a driver that runs the factorisation
+ * itself (multi-GPU): factor buffer (Nr x Np column-major, leading dimension ld), the
+ * ceil(N/128) inverse diagonal blocks, the scalar slots ([0] log-det accumulator) and the info word. */
+int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_t* Np, void** invL,
+                       void** scal, void** info);
+/* Bracket an externally driven factorisation: begin resets the accumulators; finish takes the
+ * global log-det and info (after the driver's reductions), extracts v and marks the engine
+ * factorised so that gmb_nlml / gmb_predict work on the resident factor. */
+int gmb_begin_external_factorization(gmb_engine* e);
+/* this rank's partial log-det (sum over the diagonal blocks it factored) and failure word */
+int gmb_local_logdet_info(gmb_engine* e, double* logdet, int64_t* info);
+int gmb_finish_external_factorization(gmb_engine* e, double logdet, int64_t info);
 /* Covariance tile rows [i0,i0+ni) x cols [j0,j0+nj) of Sigma (+noise/jitter on the diagonal)
  * into a column-major buffer: out[(i-i0) + (j-j0)*ldo]. */
 int gmb_blk_kbuild(gmb_engine* e, double* out, int64_t ldo, int64_t i0, int64_t ni, int64_t j0,

@@ -1,0 +1,71 @@
+"""Multi-rank path on real HIP kernels: two processes share the one GPU of the test box and
+exchange panels through ``gloo`` (RCCL refuses two ranks on one device); the 8-GPU RCCL run is the
+driver's SCALE job.  Checks factor, v, NLML and predictions against the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, N, d, M, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gumbi_amd.distributed import DistributedEngine
+        from gumbi_amd.engine import KernelSpec
+        from oracle import gp_oracle as O
+
+        X, y, ls = O.synthetic_table(N, d, seed=5)
+        spec = O.make_spec(d, range(d), kind="Matern52")
+        theta = O.pack_theta(spec, ls, 1.1, 0.3)
+        Xs = np.random.default_rng(1).standard_normal((M, d))
+        eng = DistributedEngine(0)
+        eng.set_data(X, y)
+        eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d)), kind="Matern52"))
+        eng.set_theta(theta)
+        eng.factorize()
+        L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
+        L = np.tril(eng.eng.copy_factor())
+        err_L = np.max(np.abs(L - L_ref)) / np.max(np.abs(L_ref))
+        err_v = np.max(np.abs(eng.eng.copy_v() - v_ref)) / np.max(np.abs(v_ref))
+        err_nl = abs(eng.nlml() - O.nlml(spec, theta, X, y, dist_mode="direct"))
+        mu, var = eng.predict(Xs)
+        mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+        err_mu = np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))
+        err_var = np.max(np.abs(var - var_r))
+        out.put((rank, err_L, err_v, err_nl, err_mu, err_var))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,N", [(2, 700), (2, 512), (3, 1000)])
+def test_two_ranks_one_gpu_match_oracle(gpu, world, N):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, 333, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err_L, err_v, err_nl, err_mu, err_var in results:
+        assert err_L < 1e-10 and err_v < 1e-10 and err_nl < 1e-8
+        assert err_mu < 1e-8 and err_var < 1e-9
