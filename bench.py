@@ -15,9 +15,16 @@ The default workload is BASELINE.json configs[1]: N = 10k, d = 4, RBF-ARD, fp64,
 (100 x 100 over dims 0,1; other dims pinned at 0).  ``value`` = algorithmic GFLOP/s of the whole
 step; ``ms_per_step`` is the fit + predict wall time.  One JSON line is printed by rank 0.
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank currently
-fits its own replica of the workload ("replicas only", weak scaling, no data-path collective);
-the barrier / max-over-ranks timing contract is kept.
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) the timed
+workload shards by independent GPs: every rank runs the same MAP fit + prediction on its own GPU
+(the cross-validation / per-category refit pattern, SURVEY.md section 8e last row) -- weak
+scaling, no data-path collective; the barrier / max-over-ranks timing contract is kept.
+In the same invocation, OUTSIDE the timed steps, the block-cyclic multi-GPU Cholesky
+(gumbi_amd/distributed.py: diagonal-block broadcast + panel all-gather on RCCL) factors ONE large
+covariance matrix (N = 40,960, d = 8, RBF-ARD, fixed hyper-parameters) across all ranks and
+predicts a 10^4 grid sharded over the ranks; its wall time and rate are reported under
+"distributed" in the same JSON line (at --gpus 1 the same problem runs on the single-GPU engine,
+which gives the strong-scaling baseline).  GUMBI_BENCH_NO_DIST=1 skips that section.
 """
 import argparse
 import json
@@ -88,7 +95,7 @@ def step_flops(N, M, n_eval):
     return n_eval * n3 + n3 / 3.0 + float(N) ** 2 * M + 4.0 * N * M
 
 
-def cpu_baseline(cfg, target_seconds=15.0):
+def cpu_baseline(cfg, target_seconds=20.0):
     """Oracle (numpy + LAPACK through scipy) timed on a bounded sample of the same workload:
     one MAP objective+gradient evaluation and one grid prediction at a reduced N chosen (from a
     short probe, cost ~ N^3) to take about ``target_seconds`` on this host."""
@@ -130,6 +137,68 @@ def cpu_baseline(cfg, target_seconds=15.0):
     }
 
 
+DIST_N, DIST_D = 40_960, 8
+
+
+def distributed_section(world, local_rank, dist):
+    """Fixed-theta fit (K-build + Cholesky + v + NLML) and a sharded grid prediction of ONE
+    N = 40,960 GP over all ranks; max-over-ranks wall time."""
+    import torch
+
+    from gumbi_amd import engine as E
+
+    N, d = DIST_N, DIST_D
+    X, y, ls = synthetic_table(N, d)
+    Xs = synthetic_grid(d, 100)
+    theta = np.concatenate([ls, [1.0, 0.2]])
+    spec = E.KernelSpec(D=d, idx_cont=list(range(d)), kind="ExpQuad")
+    if world == 1:
+        eng = E.Engine(local_rank)
+        predict = lambda: eng.predict(Xs)  # noqa: E731
+    else:
+        from gumbi_amd.distributed import DistributedEngine
+
+        eng = DistributedEngine(local_rank)
+        predict = lambda: eng.predict(Xs)  # noqa: E731
+    eng.set_data(X, y)
+    eng.set_kernel(spec)
+    eng.set_theta(theta)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.factorize()  # warm-up (allocations, code objects, RCCL channels)
+    sync()
+    t0 = time.perf_counter()
+    eng.factorize()
+    nlml = eng.nlml()
+    sync()
+    t1 = time.perf_counter()
+    mu, var = predict()
+    sync()
+    t2 = time.perf_counter()
+    on_dev = dist is None or dist.get_backend() == "nccl"
+    times = torch.tensor([t1 - t0, t2 - t1], dtype=torch.float64,
+                         device=torch.device("cuda", local_rank) if on_dev else "cpu")
+    if dist is not None:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    fit_s, pred_s = (float(v) for v in times.cpu())
+    eng.close()
+    flops_fit = float(N) ** 3 / 3.0
+    flops_pred = float(N) ** 2 * len(Xs)
+    return {
+        "workload": f"ONE GP, N={N}, d={d}, RBF-ARD fp64, fixed theta; block-cyclic rows over {world} GPU(s)",
+        "fit_fixed_theta_s": round(fit_s, 4),
+        "predict_s": round(pred_s, 4),
+        "fit_tflops": round(flops_fit / fit_s / 1e12, 2),
+        "predict_tflops": round(flops_pred / pred_s / 1e12, 2),
+        "nlml": float(nlml),
+        "results_finite": bool(np.all(np.isfinite(mu)) and np.all(var > 0)),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,11 +218,17 @@ def main():
     dist = None
     import torch
 
+    if os.environ.get("GUMBI_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0  # test hook: several ranks share GPU 0 (needs GUMBI_BENCH_BACKEND=gloo)
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GUMBI_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from gumbi_amd import engine
 
@@ -192,9 +267,16 @@ def main():
     eng.set_profiling(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    dist_info = None
+    if os.environ.get("GUMBI_BENCH_NO_DIST") != "1" and args.config == "c2":
+        try:
+            dist_info = distributed_section(world, local_rank, dist)
+        except Exception as err:  # never lose the headline line to the side measurement
+            dist_info = {"error": f"{type(err).__name__}: {err}"[:300]}
 
     flops_total = sum(step_flops(cfg["N"], M, n) for n in n_evals) * world
     mean_host = mean_dev.cpu().numpy()
@@ -221,7 +303,7 @@ def main():
                 "workload": cfg["label"],
                 "N": cfg["N"], "d": cfg["d"], "kernel": cfg["kernel"], "M": M,
                 "map_evals_per_step": n_evals,
-                "parallelism": "1 GPU" if world == 1 else f"{world} replicas (one GP per GPU)",
+                "parallelism": "1 GPU" if world == 1 else f"{world} independent GPs, one per GPU (no data-path collective)",
             },
             "fit_predict_seconds": round(elapsed / args.steps, 4),
             "roofline": {
@@ -248,6 +330,8 @@ def main():
             out["roofline"]["mfma_only_microbench_tflops"] = round(tf, 2)  # sustained ceiling under DVFS
         except Exception:
             pass
+        if dist_info is not None:
+            out["distributed"] = dist_info
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out, ensure_ascii=False))
