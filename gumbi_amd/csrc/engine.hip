@@ -113,6 +113,17 @@ struct gmb_engine {
   std::vector<EventPair> evs;
   bool naive_leaf = false;
   bool small_tiles = true;
+
+  // concurrency inside one factorisation / gradient: `cur` is the stream the launch helpers use;
+  // it is `stream` except inside the look-ahead Cholesky (panel chain on aux[0]) and the
+  // level-parallel triangular inverse (independent merges dealt over stream + aux[0..2])
+  hipStream_t cur = nullptr;
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> sync_pool;
+  size_t sync_next = 0;
+  bool lookahead = true;
+  bool par_inverse = true;
+  int panel_blocks = 8;
 };
 
 namespace {
@@ -193,12 +204,12 @@ void ev_begin(gmb_engine* e, int kind, double flops, int mt = 0, int nt = 0, int
   (void)hipEventCreate(&p.b);
   p.kind = kind;
   p.flops = flops;
-  (void)hipEventRecord(p.a, e->stream);
+  (void)hipEventRecord(p.a, e->cur);
   e->evs.push_back(p);
 }
 void ev_end(gmb_engine* e) {
   if (!e->profiling) return;
-  (void)hipEventRecord(e->evs.back().b, e->stream);
+  (void)hipEventRecord(e->evs.back().b, e->cur);
 }
 void ev_collect(gmb_engine* e) {  // stream already synchronised
   static FILE* trace = nullptr;
@@ -272,13 +283,13 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
            g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (wtm << 8) | (wtn << 12));
   const dim3 grid(nblocks), block(256);
   if (wtm == 4 && wtn == 4)
-    hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, block, 0, e->stream, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, block, 0, e->cur, g);
   else if (wtm == 2)
-    hipLaunchKernelGGL((gemm_f64_kernel<2, 2>), grid, block, 0, e->stream, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<2, 2>), grid, block, 0, e->cur, g);
   else if (wtn == 2)
-    hipLaunchKernelGGL((gemm_f64_kernel<4, 2>), grid, block, 0, e->stream, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<4, 2>), grid, block, 0, e->cur, g);
   else
-    hipLaunchKernelGGL((gemm_f64_kernel<4, 1>), grid, block, 0, e->stream, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<4, 1>), grid, block, 0, e->cur, g);
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -287,9 +298,9 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
 int launch_leaf(gmb_engine* e, const LeafArgs& a) {
   ev_begin(e, 1, 0.0);
   if (e->naive_leaf)
-    hipLaunchKernelGGL(potrf_leaf_naive_kernel, dim3(1), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(potrf_leaf_naive_kernel, dim3(1), dim3(256), 0, e->cur, a);
   else
-    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(256), 0, e->cur, a);
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -507,6 +518,72 @@ int chol_cols(gmb_engine* e, int c0, int c1) {
   return chol_cols(e, mid, c1);
 }
 
+// ---- cross-stream ordering helpers -----------------------------------------------------------
+hipEvent_t next_sync_event(gmb_engine* e) {
+  if (e->sync_next == e->sync_pool.size()) {
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    e->sync_pool.push_back(ev);
+  }
+  return e->sync_pool[e->sync_next++];
+}
+// everything enqueued on `from` so far happens before anything enqueued on `to` from now on
+int order_after(gmb_engine* e, hipStream_t from, hipStream_t to) {
+  if (from == to) return GMB_OK;
+  hipEvent_t ev = next_sync_event(e);
+  HIP_TRY(e, hipEventRecord(ev, from));
+  HIP_TRY(e, hipStreamWaitEvent(to, ev, 0));
+  return GMB_OK;
+}
+
+// ---- Cholesky with panel look-ahead -------------------------------------------------------------
+// Right-looking over panels of `panel_blocks` block columns.  The panel itself is factored by the
+// recursion above (leaves + small GEMMs: a latency-bound serial chain); the trailing update by
+// panel p is split into U1 (the columns of panel p+1) and U2 (everything to the right of it):
+//   main stream:  U1(p)            U2(p)  ------------------->  U1(p+1)  U2(p+1) ...
+//   aux  stream:        wait U1(p); factor panel p+1 ----------> signal
+// so the next panel's serial chain runs beside the long-k MFMA update instead of after it.
+int chol_lookahead(gmb_engine* e) {
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  const int w = e->panel_blocks;
+  hipStream_t mainS = e->stream, auxS = e->aux[0];
+  e->sync_next = 0;
+  int rc;
+  e->cur = mainS;
+  if ((rc = chol_cols(e, 0, std::min(w, nct)))) return rc;
+  for (int c0 = 0; c0 < nct; c0 += w) {
+    const int c1 = std::min(c0 + w, nct);
+    const int n0 = c1, n1 = std::min(c1 + w, nct);
+    if (n0 >= nct) break;
+    auto update = [&](int col_lo, int col_hi) {
+      GemmArgs g{};
+      g.C = e->dA + (int64_t)col_lo * TILE + (int64_t)col_lo * TILE * e->ld;
+      g.ldc = e->ld;
+      g.A = e->dA + (int64_t)col_lo * TILE + (int64_t)c0 * TILE * e->ld;
+      g.lda = e->ld;
+      g.B = g.A;
+      g.ldb = e->ld;
+      g.mt = col_hi - col_lo;
+      g.nt = nrt - col_lo;
+      g.k = (c1 - c0) * TILE;
+      g.alpha = -1.0;
+      g.beta = 1.0;
+      g.tri = 1;
+      return launch_gemm(e, g, 0);
+    };
+    e->cur = mainS;
+    if ((rc = update(n0, n1))) return rc;                 // U1
+    if ((rc = order_after(e, mainS, auxS))) return rc;
+    e->cur = auxS;
+    if ((rc = chol_cols(e, n0, n1))) return rc;           // panel p+1, beside U2
+    e->cur = mainS;
+    if (n1 < nct && (rc = update(n1, nct))) return rc;    // U2
+    if ((rc = order_after(e, auxS, mainS))) return rc;
+  }
+  e->cur = mainS;
+  return GMB_OK;
+}
+
 // ---- predict recursion: V <- W L^-T over column blocks [c0, c1) ------------------------------
 int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1) {
   if (c1 - c0 == 1) {
@@ -555,13 +632,59 @@ int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1) {
 //     T^T = U_A B^T (scratch, mirrored region of dW),  W21 = -W_C T,  U12 = W21^T (transpose).
 int launch_transpose(gmb_engine* e, const double* src, int64_t lds_, double* dst, int64_t ldd, int rows,
                      int cols) {
-  hipLaunchKernelGGL(transpose_kernel, dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, e->stream, src,
+  hipLaunchKernelGGL(transpose_kernel, dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, e->cur, src,
                      lds_, dst, ldd, rows, cols);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
 }
 
-int winv_cols(gmb_engine* e, int c0, int c1) {
+int winv_node(gmb_engine* e, int c0, int c1, bool recurse);
+
+int winv_cols(gmb_engine* e, int c0, int c1) { return winv_node(e, c0, c1, true); }
+
+// The two halves of a node are independent (both read only L and the inv(L_kk) blocks), so the
+// whole recursion tree can be executed level by level, bottom-up, with the nodes of a level dealt
+// round-robin over four streams: the many small GEMMs at the bottom of the tree (a few tiles
+// each) run side by side instead of one after the other.
+struct InvNode {
+  int c0, c1;
+};
+void collect_inv_nodes(int c0, int c1, int depth, std::vector<std::vector<InvNode>>& levels) {
+  if ((int)levels.size() <= depth) levels.resize(depth + 1);
+  levels[depth].push_back(InvNode{c0, c1});
+  if (c1 - c0 > 1) {
+    const int mid = c0 + (c1 - c0 + 1) / 2;
+    collect_inv_nodes(c0, mid, depth + 1, levels);
+    collect_inv_nodes(mid, c1, depth + 1, levels);
+  }
+}
+int winv_levels(gmb_engine* e, int nt) {
+  std::vector<std::vector<InvNode>> levels;
+  collect_inv_nodes(0, nt, 0, levels);
+  hipStream_t streams[4] = {e->stream, e->aux[0], e->aux[1], e->aux[2]};
+  int rc;
+  for (int a = 1; a < 4; ++a)
+    if ((rc = order_after(e, streams[0], streams[a]))) return rc;
+  for (int depth = (int)levels.size() - 1; depth >= 0; --depth) {
+    int idx = 0;
+    for (const InvNode& nd : levels[depth]) {
+      e->cur = streams[levels[depth].size() > 1 ? (idx++ & 3) : 0];
+      if ((rc = winv_node(e, nd.c0, nd.c1, false))) {
+        e->cur = e->stream;
+        return rc;
+      }
+    }
+    e->cur = e->stream;
+    for (int a = 1; a < 4; ++a)
+      if ((rc = order_after(e, streams[a], streams[0]))) return rc;
+    if (depth > 0)
+      for (int a = 1; a < 4; ++a)
+        if ((rc = order_after(e, streams[0], streams[a]))) return rc;
+  }
+  return GMB_OK;
+}
+
+int winv_node(gmb_engine* e, int c0, int c1, bool recurse) {
   const int64_t ldw = e->Np, lda = e->ld;
   double* W = e->dW;
   double* A = e->dA;
@@ -569,13 +692,15 @@ int winv_cols(gmb_engine* e, int c0, int c1) {
     const double* inv = e->dInv + (int64_t)c0 * TILE * TILE;
     HIP_TRY(e, hipMemcpy2DAsync(W + (int64_t)c0 * TILE + (int64_t)c0 * TILE * ldw, ldw * sizeof(double), inv,
                                 TILE * sizeof(double), TILE * sizeof(double), TILE, hipMemcpyDeviceToDevice,
-                                e->stream));
+                                e->cur));
     return launch_transpose(e, inv, TILE, A + (int64_t)c0 * TILE + (int64_t)c0 * TILE * lda, lda, TILE, TILE);
   }
   const int mid = c0 + (c1 - c0 + 1) / 2;
   int rc;
-  if ((rc = winv_cols(e, c0, mid))) return rc;
-  if ((rc = winv_cols(e, mid, c1))) return rc;
+  if (recurse) {
+    if ((rc = winv_node(e, c0, mid, true))) return rc;
+    if ((rc = winv_node(e, mid, c1, true))) return rc;
+  }
   const int n1 = mid - c0, n2 = c1 - mid;
   {  // T^T[j][r] = sum_{k>=j} U_A[j][k] * B[r][k]   -> scratch at W[c0.., mid..]
     GemmArgs g{};
@@ -648,7 +773,12 @@ int grad_impl(gmb_engine* e, double* grad) {
   const int nt = (int)(e->Np / TILE);
   // 1. W = L^-1 (dW, lower) and U = L^-T (factor buffer, upper); the factor is consumed from here on
   e->factor_consumed = true;
-  if ((rc = winv_cols(e, 0, nt))) return rc;
+  e->sync_next = 0;
+  if (e->par_inverse) {
+    if ((rc = winv_levels(e, nt))) return rc;
+  } else if ((rc = winv_cols(e, 0, nt))) {
+    return rc;
+  }
   // 2. alpha = W^T v = Sigma^-1 y   (before Sigma^-1 overwrites W)
   hipLaunchKernelGGL(wt_v_kernel, dim3((unsigned)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->dW, e->Np,
                      e->dv, e->N, e->dalpha);
@@ -801,6 +931,18 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   e->naive_leaf = nl && nl[0] == '1';
   const char* st = getenv("GMB_SMALL_TILES");  // tuning switch: 0 forces the 128 x 128 tiling
   e->small_tiles = !(st && st[0] == '0');
+  const char* la = getenv("GMB_LOOKAHEAD");    // tuning switches for the multi-stream schedules
+  e->lookahead = !(la && la[0] == '0');
+  const char* pi = getenv("GMB_PAR_INVERSE");
+  e->par_inverse = !(pi && pi[0] == '0');
+  const char* pb = getenv("GMB_PANEL_BLOCKS");
+  if (pb && atoi(pb) > 0) e->panel_blocks = atoi(pb);
+  e->cur = e->stream;
+  for (auto& s2 : e->aux)
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) {
+      gmb_destroy(e);
+      return GMB_EHIP;
+    }
   if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
     gmb_destroy(e);
@@ -819,6 +961,9 @@ void gmb_destroy(gmb_engine* e) {
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto s2 : e->aux)
+    if (s2) (void)hipStreamDestroy(s2);
+  for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -962,7 +1107,11 @@ int gmb_factorize(gmb_engine* e) {
   tk.stop();
   // 2. Cholesky
   PhaseTimer tc(e);
-  if ((rc = chol_cols(e, 0, (int)(e->Np / TILE)))) return rc;
+  if (e->lookahead && e->Np / TILE > e->panel_blocks) {
+    if ((rc = chol_lookahead(e))) return rc;
+  } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE)))) {
+    return rc;
+  }
   // 3. v = L^-1 y is row N of the factor
   hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
                      e->dscal + 1);
@@ -1174,10 +1323,15 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
-  const int blocks = 256 * 8, iters = 4000;
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100);  // warm-up
+  // tuning knobs for ceiling experiments: resident blocks per CU and operand magnitude (0 = idle datapath)
+  const char* eb = getenv("GMB_PEAK_BLOCKS_PER_CU");
+  const char* ez = getenv("GMB_PEAK_SCALE");
+  const int per_cu = (eb && atoi(eb) > 0) ? atoi(eb) : 8;
+  const double scale = ez ? atof(ez) : 1.0;
+  const int blocks = 256 * per_cu, iters = 4000;
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100, scale);  // warm-up
   (void)hipEventRecord(a, 0);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, scale);
   (void)hipEventRecord(b, 0);
   int rc = GMB_OK;
   if (hipEventSynchronize(b) != hipSuccess || hipGetLastError() != hipSuccess) rc = GMB_EHIP;

@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 
 // MFMA-only microbenchmark: `iters` rounds of 8 independent v_mfma_f64_16x16x4_f64 per wave, no
 // memory traffic -- measures the f64 matrix peak the roofline is priced against.
-__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* sink, int iters) {
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* sink, int iters, double scale) {
   d4 acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  const double a = scale * (1.0 + 1e-9 * threadIdx.x), b = scale * (1.0 - 1e-9 * threadIdx.x);
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll

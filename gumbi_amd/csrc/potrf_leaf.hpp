@@ -31,14 +31,19 @@ constexpr int LB = 128;  // leaf block edge
 constexpr int LP = 130;  // LDS pitch (doubles)
 constexpr int SB = 16;   // sub-panel width
 
-__device__ __forceinline__ double readlane_f64(double v, int src) {
+// Broadcast one lane's value to every lane.  ds_bpermute keeps the result in a VGPR: the
+// v_readlane form returns SGPR pairs, and the ~250 multipliers of a 16 x 16 block overflowed the
+// scalar file (521 SGPR spills, each a v_writelane + v_readlane round trip).  `idx4` is the source
+// lane times 4, held in a VGPR the optimiser cannot see through (it would fold a constant index
+// straight back into v_readlane).
+__device__ __forceinline__ double bcast_f64(double v, int idx4) {
   union {
     double d;
     int i[2];
   } u;
   u.d = v;
-  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
-  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  u.i[0] = __builtin_amdgcn_ds_bpermute(idx4, u.i[0]);
+  u.i[1] = __builtin_amdgcn_ds_bpermute(idx4, u.i[1]);
   return u.d;
 }
 
@@ -93,41 +98,64 @@ __device__ __forceinline__ void factor_diag16(double* S, double* dinv_s, double*
                                               int32_t* info, int64_t row0) {
   const int lane = threadIdx.x & 63;
   const int rr = lane < SB ? lane : SB - 1;
+  int lidx[SB];  // 4 * source lane, opaque (see bcast_f64)
+#pragma unroll
+  for (int c = 0; c < SB; ++c) {
+    lidx[c] = c << 2;
+    asm volatile("" : "+v"(lidx[c]));
+  }
   double d[SB];
 #pragma unroll
   for (int c = 0; c < SB; ++c) d[c] = S[(c0 + c) * LP + c0 + rr];
   double rl[SB];
   double x[SB];  // X = L^-1, column `rr` per lane:  x[a] = ((a == j) - sum_{k<a} L[a][k] x[k]) / L[a][a]
+  int badcol = -1;
+  // The pivot chain is the critical path: keep it free of LDS-crossbar round trips.  Every lane
+  // tracks its OWN diagonal entry (dg -= L[r][c]^2 needs no other lane), the next pivot is one
+  // v_readlane of dg away, and the multiplier broadcasts / rank-1 updates trail one column behind.
+  double dg = 0.0;
+#pragma unroll
+  for (int c = 0; c < SB; ++c) dg = (rr == c) ? d[c] : dg;
 #pragma unroll
   for (int c = 0; c < SB; ++c) {
-    double piv = readlane_f64(d[c], c);
-    if (!(piv > 0.0)) {  // also catches NaN; wave-uniform
-      if (lane == 0 && c0 + c < nv) atomicCAS(info, 0, (int)(row0 + c0 + c + 1));
-      piv = 1.0;
+    double piv;
+    {
+      union {
+        double dd;
+        int i[2];
+      } u;
+      u.dd = dg;
+      u.i[0] = __builtin_amdgcn_readlane(u.i[0], c);
+      u.i[1] = __builtin_amdgcn_readlane(u.i[1], c);
+      piv = u.dd;
     }
+    const bool bad = !(piv > 0.0);  // also catches NaN; identical in every lane
+    badcol = (bad && badcol < 0) ? c : badcol;
+    piv = bad ? 1.0 : piv;
     // row c of L is final here (its entries sit in lane c, registers 0..c-1): start row c of the
     // inverse -- independent of the pivot's sqrt chain, so it fills that latency
     double t = (c == rr) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < c; ++k) t = fma(-readlane_f64(d[k], c), x[k], t);
+    for (int k = 0; k < c; ++k) t = fma(-bcast_f64(d[k], lidx[c]), x[k], t);
     double l;
     sqrt_rsqrt(piv, l, rl[c]);
     x[c] = t * rl[c];
     d[c] = (rr == c) ? l : d[c] * rl[c];
+    dg = fma(-d[c], d[c], dg);
 #pragma unroll
     for (int c2 = c + 1; c2 < SB; ++c2) {
-      const double m = readlane_f64(d[c], c2);  // L[c2][c]
+      const double m = bcast_f64(d[c], lidx[c2]);  // L[c2][c]
       d[c2] = fma(-d[c], m, d[c2]);
     }
   }
+  if (badcol >= 0 && lane == 0 && c0 + badcol < nv) atomicCAS(info, 0, (int)(row0 + c0 + badcol + 1));
 #pragma unroll
-  for (int c = 0; c < SB; ++c) {
+  for (int c = 0; c < SB; ++c)
     if (lane == c) rdiag[c0 + c] = rl[c];
-    if (lane < SB) {
-      if (c <= lane) S[(c0 + c) * LP + c0 + lane] = d[c];   // L_ss, row `lane`
-    }
-  }
   if (lane < SB) {
+#pragma unroll
+    for (int c = 0; c < SB; ++c)
+      if (c <= lane) S[(c0 + c) * LP + c0 + lane] = d[c];   // L_ss, row `lane`
 #pragma unroll
     for (int a = 0; a < SB; ++a) {
       dinv_s[lane * SB + a] = x[a];                          // X[a][lane], column-major
@@ -192,7 +220,9 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) S[(c0 + kq + 4 * r) * LP + rw + r16] = acc[r];
     }
+    LEAF_STAMP(8 + 3 * s);
     __syncthreads();
+    LEAF_STAMP(9 + 3 * s);
     // (C) rank-16 update of the remaining lower triangle.  Wave 0 takes the next diagonal tile
     //     first and factors it straight away, hiding that dependent chain behind the other
     //     waves' MFMA tiles.
@@ -224,6 +254,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
         }
       }
     }
+    LEAF_STAMP(10 + 3 * s);
     __syncthreads();
   }
 
