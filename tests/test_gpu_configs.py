@@ -1,0 +1,156 @@
+"""BASELINE.json configurations beyond C2 on the MI355X: C3 (N = 50k, d = 8, Matern-5/2 ARD) and
+C4 (2-output ICM, N = 20k, d = 4 -> stacked 40k x 5), each as a mid-size direct comparison with
+the oracle plus size-independent properties at the full size; and ``cross_validate`` (SURVEY
+section 8f row 3) end to end."""
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def make_engine(spec, theta, X, y):
+    from gumbi_amd.engine import Engine, KernelSpec
+
+    eng = Engine(0)
+    eng.set_data(X, y)
+    eng.set_kernel(KernelSpec(D=spec["D"], idx_cont=spec["idx_cont"], kind=spec["kind"], ard=spec["ard"],
+                              idx_lin=spec["idx_lin"], coreg=spec["coreg"], out_col=spec["out_col"],
+                              n_out=spec["n_out"], hetero_noise=spec["hetero_noise"]))
+    eng.set_theta(theta)
+    return eng
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def sampled_rows_check(eng, spec, theta, X, rows):
+    """(L L^T)[rows][:, rows] == Sigma[rows][:, rows] using only `rows` of the resident factor."""
+    N = X.shape[0]
+    Lr = np.stack([eng.copy_factor(int(r), 1, 0, N)[0] for r in rows])
+    for a, ra in enumerate(rows):
+        Lr[a, ra + 1:] = 0.0
+    S = O.cov_full(spec, theta, X[rows], X[rows], dist_mode="direct")
+    S[np.diag_indices_from(S)] += O.noise_diag(spec, theta, X[rows]) + spec["jitter"]
+    assert rel(Lr @ Lr.T, S) < 1e-10
+
+
+def icm_problem(n, d, seed=2021):
+    """SURVEY.md section 8d C4 generator: same X for both outputs, stacked output-major."""
+    rng = np.random.default_rng(seed)
+    Xc = rng.standard_normal((n, d))
+    ls = np.geomspace(0.7, 2.0, d)
+    W = np.array([[1.0, 0.0], [0.6, 0.8]])
+    kappa = np.array([0.1, 0.1])
+    B = W @ W.T + np.diag(kappa)
+    f = np.stack([np.sum(np.sin(Xc / ls + p), axis=1) / np.sqrt(d) for p in range(2)])
+    F = np.linalg.cholesky(B) @ f
+    noise_sd = 0.2 * np.sqrt(np.array([1.0, 2.25]))
+    Y = F + noise_sd[:, None] * rng.standard_normal((2, n))
+    X = np.vstack([np.column_stack([Xc, np.full(n, p)]) for p in range(2)])
+    y = np.concatenate([(Y[p] - Y[p].mean()) / Y[p].std(ddof=1) for p in range(2)])
+    spec = O.make_spec(d + 1, range(d), kind="ExpQuad", out_col=d, n_out=2, hetero_noise=True)
+    Wn = np.array([[1.0, 0.0], [1.5, 0.0]])
+    theta = O.pack_theta(spec, ls, 1.0, 0.2, W_out=W, kappa_out=kappa, W_noise=Wn, kappa_noise=[1e-3, 1e-3])
+    return X, y, spec, theta
+
+
+def test_c3_midsize_parity(gpu):
+    N, d = 4000, 8
+    X, y, ls = O.synthetic_table(N, d)
+    spec = O.make_spec(d, range(d), kind="Matern52")
+    theta = O.pack_theta(spec, ls, 1.0, 0.2)
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    Xs = O.synthetic_grid(d, res=30)
+    mu, var = eng.predict(Xs)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs)  # PyMC-faithful distance expansion
+    assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-9
+    assert np.isclose(eng.nlml(), O.nlml(spec, theta, X, y), rtol=1e-10)
+    val, g = eng.nlml(grad=True)
+    _, g_r = O.nlml_and_grad(spec, theta, X, y)
+    assert np.max(np.abs(g - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
+
+
+def test_c3_full_size_properties(gpu):
+    """N = 50k, d = 8, Matern-5/2 ARD: 20 GB factor on one GPU."""
+    N, d = 50_000, 8
+    X, y, ls = O.synthetic_table(N, d)
+    spec = O.make_spec(d, range(d), kind="Matern52")
+    sigma = 0.2
+    theta = O.pack_theta(spec, ls, 1.0, sigma)
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    tm = eng.timings()
+    rows = np.sort(np.random.default_rng(3).choice(N, 5, replace=False))
+    sampled_rows_check(eng, spec, theta, X, rows)
+    Xs = O.synthetic_grid(d, res=20)
+    mu, var = eng.predict(Xs, with_noise=True)
+    mu0, var0 = eng.predict(Xs, with_noise=False)
+    assert np.array_equal(mu, mu0) and np.allclose(var - var0, sigma**2, rtol=0, atol=1e-14)
+    assert np.all(np.isfinite(mu)) and np.all(var0 > 0) and np.all(var0 <= 1.0 + 1e-9)
+    # K-build bandwidth sanity: 10 GB written; must be far above anything a re-read pattern gives
+    assert tm["kbuild_bytes"] / (tm["kbuild_ms"] * 1e-3) > 1.0e12
+    nl = eng.nlml()
+    assert np.isfinite(nl)
+    eng.close()
+
+
+def test_c4_midsize_parity_and_frontend_correlation(gpu):
+    X, y, spec, theta = icm_problem(1500, 4)
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    rng = np.random.default_rng(0)
+    Xs1 = rng.standard_normal((200, 4))
+    Xs = np.vstack([np.column_stack([Xs1, np.full(200, p)]) for p in range(2)])
+    mu, var = eng.predict(Xs)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs)
+    assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-9
+    val, g = eng.nlml(grad=True)
+    val_r, g_r = O.nlml_and_grad(spec, theta, X, y)
+    assert np.isclose(val, val_r, rtol=1e-10)
+    assert np.max(np.abs(g - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
+
+
+def test_c4_full_size_properties(gpu):
+    """2-output ICM, N = 20k, d = 4: the stacked 40k x 5 system (K = B (x) K_x + D (x) I)."""
+    n, d = 20_000, 4
+    X, y, spec, theta = icm_problem(n, d)
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    rows = np.array([5, 7_777, 19_999, 20_000, 31_234, 39_999])
+    sampled_rows_check(eng, spec, theta, X, rows)
+    Xs1 = O.synthetic_grid(d, res=15)
+    Xs = np.vstack([np.column_stack([Xs1, np.full(len(Xs1), p)]) for p in range(2)])
+    mu, var = eng.predict(Xs, with_noise=True)
+    _, var0 = eng.predict(Xs, with_noise=False)
+    nz = O.noise_diag(spec, theta, Xs)
+    assert np.allclose(var - var0, nz, rtol=0, atol=1e-13)
+    assert nz[0] != nz[-1]  # heteroskedastic across outputs
+    assert np.all(var0 > 0)
+    eng.close()
+
+
+def test_cross_validate_runs_on_gpu(gpu):
+    import gumbi_amd as gmb
+
+    stdzr = gmb.Standardizer(
+        **{"d": {"μ": -0.307, "σ2": 0.158**2}, "X": {"μ": -0.282, "σ2": 1.0}, "Y": {"μ": 4.48, "σ2": 0.75**2}},
+        log_vars=["d", "Y"], logit_vars=["X"])
+    es = pd.read_pickle(GOLD / "test_dataset.pkl")
+    ds = gmb.DataSet.from_tidy(es, names_column="Parameter", stdzr=stdzr)
+    gp = gmb.GP(ds, outputs="d")
+    gp.specify_model(continuous_dims=["X", "Y"])
+    gp.build_model()
+    res = gp.cross_validate(n_train=50, seed=3, maxeval=40)
+    assert set(res) == {"train", "test"}
+    assert res["train"]["errors"].shape == (50,) and res["test"]["errors"].shape == (16,)
+    assert np.all(np.isfinite(res["train"]["NLPDs"])) and np.all(np.isfinite(res["test"]["NLPDs"]))
+    # natural-space errors of 'd' (values ~0.5-0.9) stay small on both splits
+    assert np.mean(np.abs(res["train"]["errors"])) < 0.1 and np.mean(np.abs(res["test"]["errors"])) < 0.1
