@@ -113,6 +113,7 @@ struct gmb_engine {
   std::vector<EventPair> evs;
   bool naive_leaf = false;
   bool small_tiles = true;
+  int gemm_variant = 0;
 
   // concurrency inside one factorisation / gradient: `cur` is the stream the launch helpers use;
   // it is `stream` except inside the look-ahead Cholesky (panel chain on aux[0]) and the
@@ -266,30 +267,34 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
     nact += g.nt - f;
   }
   const bool in_place = (const double*)g.C == g.B;  // the block must own every column of its rows
-  int wtm = 4, wtn = 4;
+  // variant: 0 = 128x128 / 4 waves, 1 = 64x64, 2 = 128x64, 3 = 128x32, 4 = 128x128 / 8 waves, 5 = 128x256 / 8 waves
+  int variant = e->gemm_variant;
   if (in_place) {
     if (g.mt != 1) return fail(e, GMB_EINVAL, "internal: in-place GEMM needs m == 128");
-    if (nact < 64) wtn = 1; else if (nact < 128) wtn = 2;
+    variant = nact < 64 ? 3 : (nact < 128 ? 2 : 0);
   } else if (nact < 192 && e->small_tiles) {
-    wtm = wtn = 2;
+    variant = 1;
+  } else if (variant == 5 && (g.nt % 2 || g.nblk_stride != 1 || g.tri)) {
+    variant = 0;
   }
-  const int bm = 32 * wtm, bn = 32 * wtn;
-  g.mt = g_in.mt * (TILE / bm);
-  g.nt = g_in.nt * (TILE / bn);
+  static const int BMs[6] = {128, 64, 128, 128, 128, 128}, BNs[6] = {128, 64, 64, 32, 128, 256};
+  const int bm = BMs[variant], bn = BNs[variant];
+  g.mt = g_in.mt * TILE / bm;
+  g.nt = g_in.nt * TILE / bn;
   double flops = 0.0;
   const int nblocks = gemm_schedule(g, bm, bn, &flops);
   if (nblocks <= 0) return GMB_OK;
   ev_begin(e, ev_kind, flops, g_in.mt, g_in.nt, g.k,
-           g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (wtm << 8) | (wtn << 12));
-  const dim3 grid(nblocks), block(256);
-  if (wtm == 4 && wtn == 4)
-    hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, block, 0, e->cur, g);
-  else if (wtm == 2)
-    hipLaunchKernelGGL((gemm_f64_kernel<2, 2>), grid, block, 0, e->cur, g);
-  else if (wtn == 2)
-    hipLaunchKernelGGL((gemm_f64_kernel<4, 2>), grid, block, 0, e->cur, g);
-  else
-    hipLaunchKernelGGL((gemm_f64_kernel<4, 1>), grid, block, 0, e->cur, g);
+           g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (variant << 8));
+  const dim3 grid(nblocks);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, g); break;
+    case 1: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2>), grid, dim3(256), 0, e->cur, g); break;
+    case 2: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 2, 2>), grid, dim3(256), 0, e->cur, g); break;
+    case 3: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2>), grid, dim3(256), 0, e->cur, g); break;
+    case 4: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 2, 4>), grid, dim3(512), 0, e->cur, g); break;
+    default: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 4, 2>), grid, dim3(512), 0, e->cur, g); break;
+  }
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -931,6 +936,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   e->naive_leaf = nl && nl[0] == '1';
   const char* st = getenv("GMB_SMALL_TILES");  // tuning switch: 0 forces the 128 x 128 tiling
   e->small_tiles = !(st && st[0] == '0');
+  const char* gv = getenv("GMB_GEMM_VARIANT");  // tuning: 0 = 128x128/4 waves, 4 = 128x128/8 waves, 5 = 128x256/8 waves
+  if (gv && (gv[0] == '4' || gv[0] == '5')) e->gemm_variant = gv[0] - '0';
   const char* la = getenv("GMB_LOOKAHEAD");    // tuning switches for the multi-stream schedules
   e->lookahead = !(la && la[0] == '0');
   const char* pi = getenv("GMB_PAR_INVERSE");
@@ -938,11 +945,20 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   const char* pb = getenv("GMB_PANEL_BLOCKS");
   if (pb && atoi(pb) > 0) e->panel_blocks = atoi(pb);
   e->cur = e->stream;
-  for (auto& s2 : e->aux)
-    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) {
+  // the auxiliary streams carry the latency-bound panel chain of the look-ahead Cholesky: give
+  // them the highest queue priority so their (few) workgroups are placed ahead of the bulk update's
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  const char* ap = getenv("GMB_AUX_PRIORITY");
+  const bool use_prio = !(ap && ap[0] == '0');
+  for (auto& s2 : e->aux) {
+    hipError_t st2 = use_prio ? hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio_hi)
+                              : hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    if (st2 != hipSuccess) {
       gmb_destroy(e);
       return GMB_EHIP;
     }
+  }
   if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
     gmb_destroy(e);
@@ -1326,9 +1342,9 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
   // tuning knobs for ceiling experiments: resident blocks per CU and operand magnitude (0 = idle datapath)
   const char* eb = getenv("GMB_PEAK_BLOCKS_PER_CU");
   const char* ez = getenv("GMB_PEAK_SCALE");
-  const int per_cu = (eb && atoi(eb) > 0) ? atoi(eb) : 8;
+  const int per_cu = (eb && atoi(eb) > 0) ? atoi(eb) : 2;
   const double scale = ez ? atof(ez) : 1.0;
-  const int blocks = 256 * per_cu, iters = 4000;
+  const int blocks = 256 * per_cu, iters = 2000;
   hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100, scale);  // warm-up
   (void)hipEventRecord(a, 0);
   hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, scale);
@@ -1344,8 +1360,8 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
   (void)hipFree(sink);
   if (rc) return rc;
   // block 0 times its own MFMA stream with s_memtime; 2 waves share each SIMD at this occupancy
-  if (cycles_per_mfma) *cycles_per_mfma = hsink[1] / ((double)iters * 8.0);
-  const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  if (cycles_per_mfma) *cycles_per_mfma = hsink[1] / ((double)iters * 16.0);
+  const double flops = (double)blocks * 4.0 * (double)iters * 16.0 * 2.0 * 16 * 16 * 4;
   *tflops = flops / ((double)ms * 1e-3) / 1e12;
   return GMB_OK;
 }

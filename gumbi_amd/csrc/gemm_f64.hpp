@@ -94,12 +94,14 @@ __host__ __device__ __forceinline__ int gemm_first_tn(int64_t T, int bn, int str
 // then keeps its 128 accumulator registers + staging in 207 VGPRs (no AGPRs, no spills) and the
 // second workgroup's MFMAs fill the first one's barrier / staging bubbles: 39 -> 52 TF/s on the
 // whole N = 30k Cholesky, 44 -> 59 TF/s on the predict GEMMs (measured A/B on MI355X).
-template <int WTM, int WTN>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
-  constexpr int BM = 32 * WTM, BN = 32 * WTN;   // block tile: 4 waves as 2 x 2, wave tile 16*WTM x 16*WTN
+template <int WGM, int WGN, int WTM, int WTN, int OCC>
+__global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WGM * WGN;                      // threads: WGM x WGN waves
+  constexpr int BM = 16 * WTM * WGM, BN = 16 * WTN * WGN; // block tile; wave tile 16*WTM x 16*WTN
   constexpr int PA = BM + 16, PB = BN + 16;     // LDS pitches, % 32 == 16 -> conflict-free ds_read_b64
-  constexpr int LA = BM / 2, RA = 256 / LA, NA = KT / RA;  // staging: lanes per k-row, rows per pass, passes
-  constexpr int LB_ = BN / 2, RB = 256 / LB_, NB = KT / RB;
+  constexpr int LA = BM / 2, RA = NT / LA, NA = KT / RA;  // staging: lanes per k-row, rows per pass, passes
+  constexpr int LB_ = BN / 2, RB = NT / LB_, NB = KT / RB;
+  static_assert(NA >= 1 && NB >= 1 && NA * RA == KT && NB * RB == KT, "staging must tile the k-tile");
   __shared__ double lds[2][KT * (PA + PB)];
 
   // compact index of this block's tile within its XCD's run, then (tm, tn) by walking the rows
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int r16 = lane & 15, kq = lane >> 4;
 
   int k_lo = g.klo_m * tm * BM + g.klo_n * tn * BN;
@@ -224,21 +226,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
 }
 
-// MFMA-only microbenchmark: `iters` rounds of 8 independent v_mfma_f64_16x16x4_f64 per wave, no
-// memory traffic -- measures the f64 matrix peak the roofline is priced against.
-__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* sink, int iters, double scale) {
-  d4 acc[8];
+// MFMA-only microbenchmark: the GEMM's own register pattern (4 x 4 independent accumulators fed
+// by 4 + 4 operand registers) with no memory traffic -- the f64 matrix rate a kernel of this shape
+// can sustain, i.e. the practical ceiling the roofline is compared with.
+__global__ __launch_bounds__(256, 2) void mfma_f64_peak_kernel(double* sink, int iters, double scale) {
+  d4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-  const double a = scale * (1.0 + 1e-9 * threadIdx.x), b = scale * (1.0 - 1e-9 * threadIdx.x);
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  double a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = scale * (1.0 + 1e-9 * (threadIdx.x + i));
+    b[i] = scale * (1.0 - 1e-9 * (threadIdx.x + 7 * i));
+  }
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
   const long long t1 = __builtin_readcyclecounter();
   if (s == 12345.678) sink[0] = s;  // keep the chain alive without a store on the timed path
   if (blockIdx.x == 0 && threadIdx.x == 0) sink[1] = (double)(t1 - t0);
