@@ -67,7 +67,8 @@ struct LeafArgs {
   double* A;        // diagonal block (0,0), column-major
   int64_t lda;
   int32_t nvalid;   // columns < nvalid are real, the rest identity padding
-  double* invL;     // 128 x 128 column-major out: inverse of the (identity-padded) factor
+  double* dinv16;   // 8 x (16 x 16) column-major out: inverses of the diagonal 16 x 16 sub-blocks of the
+                    // identity-padded factor (what trsm_strip_kernel and leaf_invert_kernel consume)
   double* logdet;   // += sum_{c<nvalid} log L_cc
   int32_t* info;    // set to row0 + c + 1 of the first non-positive pivot (0 = ok)
   int64_t row0;     // global index of the block's first row (for info)
@@ -344,20 +345,17 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     __syncthreads();
     if (tid == 0 && g.logdet) atomicAdd(g.logdet, red[0] + red[1] + red[2] + red[3]);
   }
-  if (g.invL == nullptr) return;
+  if (g.dinv16 == nullptr) return;
   LEAF_STAMP(3);
-
-  // ---- inversion ----------------------------------------------------------------------------
   if (nv < LB) {
     // Only the last diagonal block of a matrix is ragged.  Its panel rows (the y row, padding)
-    // are not part of the triangular factor and the padding is identity: rebuild the affected
-    // state the slow way.
+    // are not part of the triangular factor and the padding is identity: rebuild the sub-block
+    // inverses of the identity-padded factor the slow way.
     __syncthreads();
     for (int idx = tid; idx < LB * LB; idx += 256) {
       const int c = idx >> 7, r = idx & 127;
       if (c < nv && r >= nv) S[c * LP + r] = 0.0;
       if (c >= nv && r >= c) S[c * LP + r] = (r == c) ? 1.0 : 0.0;
-      if (r < c) S[c * LP + r] = 0.0;  // drop the X_ss transposes stored during factorisation
     }
     if (tid >= nv && tid < LB) rdiag[tid] = 1.0;
     __syncthreads();
@@ -368,19 +366,78 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
       for (int a = 0; a < SB; ++a) {
         double t = (a == j) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < a; ++k) t -= S[(c0 + k) * LP + c0 + a] * xc[k];
-        xc[a] = t * rdiag[c0 + a];
+        for (int k = 0; k < a; ++k)
+          if (k >= j) t -= S[(c0 + k) * LP + c0 + a] * xc[k];
+        xc[a] = (a < j) ? 0.0 : t * rdiag[c0 + a];
       }
 #pragma unroll
       for (int a = 0; a < SB; ++a) dinv[s][j * SB + a] = xc[a];
     }
-    __syncthreads();
-    if (tid < LB) {
-      const int s = tid >> 4, j = tid & 15, c0 = s * SB;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 8 * SB * SB; idx += 256) g.dinv16[idx] = dinv[idx >> 8][idx & 255];
+  LEAF_STAMP(4);
+}
+
+// ---- inverse of a factored diagonal block (off the factorisation's critical path) ----------
+// One workgroup per diagonal block: X = inv(L_kk) (identity-padded) from L_kk and its eight
+// 16 x 16 sub-block inverses, block diagonal by block diagonal on the matrix pipe:
+//   X_ij = -X_ii (sum_{j<=k<i} L_ik X_kj).
+// Only the hyper-parameter gradient needs these (W = inv(L) is assembled from them).
+struct InvArgs {
+  const double* L;       // first diagonal block of the factor (column-major, leading dimension lda)
+  int64_t lda;
+  int64_t blk_stride;    // elements between consecutive diagonal blocks (128 * (lda + 1) in the factor buffer)
+  const double* dinv16;  // nblk x 8 x 256
+  double* invL;          // nblk x 128 x 128 out, column-major, identity-padded
+  int64_t n;             // real rows of the whole matrix from the first block on (ragged last block)
+};
+
+__global__ __launch_bounds__(256) void leaf_invert_kernel(InvArgs g) {
+  __shared__ double S[LB * LP];
+  __shared__ double dinv[8][SB * SB];
+  __shared__ double rdiag[LB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.x;
+  const int64_t left = g.n - (int64_t)b * LB;
+  const int nv = left < LB ? (int)left : LB;
+  const double* A = g.L + (int64_t)b * g.blk_stride;
+  const double* dsrc = g.dinv16 + (int64_t)b * 8 * SB * SB;
+  double* out = g.invL + (int64_t)b * LB * LB;
+  {
+    d2 buf[32];
 #pragma unroll
-      for (int a = 0; a < SB; ++a)
-        if (a > j) S[(c0 + a) * LP + c0 + j] = dinv[s][j * SB + a];
+    for (int i = 0; i < 32; ++i) {
+      const int p = tid + 256 * i;
+      const int c = p >> 6, r = (p & 63) * 2;
+      buf[i] = *reinterpret_cast<const d2*>(A + r + (int64_t)c * g.lda);
     }
+    for (int idx = tid; idx < 8 * SB * SB; idx += 256) dinv[idx >> 8][idx & 255] = dsrc[idx];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int p = tid + 256 * i;
+      const int c = p >> 6, r = (p & 63) * 2;
+      d2 v = buf[i];
+      if (c >= nv || r >= nv) v[0] = 0.0;
+      if (c >= nv || r + 1 >= nv) v[1] = 0.0;
+      if (r < c) v[0] = 0.0;
+      if (r + 1 < c) v[1] = 0.0;
+      S[c * LP + r] = v[0];
+      S[c * LP + r + 1] = v[1];
+    }
+  }
+  __syncthreads();
+  // the sub-block inverses go (transposed) into the empty upper triangles of the diagonal
+  // sub-blocks, the layout the sweep below reads X_kj in; the diagonal itself into rdiag
+  if (tid < LB) {
+    const int s = tid >> 4, j = tid & 15, c0 = s * SB;
+    rdiag[tid] = dinv[s][j * SB + j];
+#pragma unroll
+    for (int a = 0; a < SB; ++a)
+      if (a > j) S[(c0 + a) * LP + c0 + j] = dinv[s][j * SB + a];
   }
   __syncthreads();
   for (int dist = 1; dist < LB / SB; ++dist) {
@@ -415,7 +472,6 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     }
     __syncthreads();
   }
-  LEAF_STAMP(4);
   // X[p][q] (p > q) sits at S[p*LP + q]; diagonal in rdiag
 #pragma unroll 8
   for (int idx = tid; idx < LB * LB; idx += 256) {
@@ -423,16 +479,14 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     double v = 0.0;
     if (p == q) v = rdiag[p];
     else if (p > q) v = S[p * LP + q];
-    g.invL[p + q * LB] = v;
+    out[p + q * LB] = v;
   }
-  LEAF_STAMP(5);
 }
 
 // Plain reference leaf (one column at a time, no MFMA) -- selected with GMB_LEAF_NAIVE=1 to
 // cross-check the blocked leaf on hardware.  Same contract as potrf_leaf_kernel.
 __global__ __launch_bounds__(256) void potrf_leaf_naive_kernel(LeafArgs g) {
   __shared__ double S[LB * (LB + 1)];
-  __shared__ double X[LB * 16];  // inverse computed in 8 column strips of 16
   const int tid = threadIdx.x;
   const int nv = g.nvalid;
   const int P = LB + 1;
@@ -471,7 +525,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_naive_kernel(LeafArgs g) {
     for (int c = 0; c < nv; ++c) lg += log(S[c * P + c]);
     atomicAdd(g.logdet, lg);
   }
-  if (g.invL == nullptr) return;
+  if (g.dinv16 == nullptr) return;
   __syncthreads();
   if (nv < LB) {
     for (int idx = tid; idx < LB * LB; idx += 256) {
@@ -481,21 +535,15 @@ __global__ __launch_bounds__(256) void potrf_leaf_naive_kernel(LeafArgs g) {
     }
   }
   __syncthreads();
-  for (int strip = 0; strip < 8; ++strip) {
-    if (tid < 16) {
-      const int q = strip * 16 + tid;
-      for (int p = 0; p < LB; ++p) {
-        double t = (p == q) ? 1.0 : 0.0;
-        for (int k = q; k < p; ++k) t -= S[k * P + p] * X[k * 16 + tid];
-        X[p * 16 + tid] = (p < q) ? 0.0 : t / S[p * P + p];
-      }
+  if (tid < LB) {  // column j of the inverse of diagonal sub-block s, by forward substitution
+    const int s = tid >> 4, j = tid & 15, c0 = s * 16;
+    double xc[16];
+    for (int a = 0; a < 16; ++a) {
+      double t = (a == j) ? 1.0 : 0.0;
+      for (int k = j; k < a; ++k) t -= S[(c0 + k) * P + c0 + a] * xc[k];
+      xc[a] = (a < j) ? 0.0 : t / S[(c0 + a) * P + c0 + a];
     }
-    __syncthreads();
-    for (int idx = tid; idx < LB * 16; idx += 256) {
-      const int p = idx >> 4, qq = idx & 15;
-      g.invL[p + (strip * 16 + qq) * LB] = X[p * 16 + qq];
-    }
-    __syncthreads();
+    for (int a = 0; a < 16; ++a) g.dinv16[s * 256 + j * 16 + a] = xc[a];
   }
 }
 

@@ -1,0 +1,76 @@
+// Triangular solve of a row strip against one factored 128 x 128 diagonal block, on the matrix
+// pipe and without shared memory:
+//
+//     B  <-  B inv(L_kk)^T          B: nrows x 128 (column-major, rows contiguous)
+//
+// This is the step between two consecutive diagonal-block factorisations of the Cholesky
+// (panel rows below the block), the leaf of the predict solve V <- K_* L^-T, and the packed
+// row solve of the multi-GPU driver.  Each wavefront owns 16 rows.  Written for rows as columns
+// (Y = B^T, 128 x 16), the solve L_kk X = Y is a blocked forward substitution over the eight
+// 16 x 16 sub-blocks:
+//
+//     X_s = inv(L_ss) (Y_s - sum_{t<s} L_st X_t)
+//
+// Every X_t lives in the v_mfma_f64_16x16x4 accumulator layout (lane = row of B, register =
+// sub-block row), which is exactly the B-operand layout of the next product, so the eight tiles
+// never leave registers: 144 MFMAs per wavefront, operands L_st / inv(L_ss) read straight from
+// global memory (the block is shared by every wavefront of the launch and sits in L2).
+// inv(L_ss) are the sub-block inverses the leaf factorisation already has (potrf_leaf.hpp); the
+// 128 x 128 inverse is not needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmb {
+
+struct TrsmArgs {
+  double* B;             // in/out
+  int64_t ldb;
+  int64_t nrows;         // multiple of 16
+  const double* L;       // factored diagonal block, column-major
+  int64_t ldl;
+  const double* dinv16;  // 8 x (16 x 16) column-major sub-block inverses (identity-padded)
+  int32_t nvalid;        // rows/columns >= nvalid of the block are identity padding (whatever
+                         // the buffer holds there -- the y row of the factor buffer -- is ignored)
+};
+
+__global__ __launch_bounds__(256) void trsm_strip_kernel(TrsmArgs g) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (r0 >= g.nrows) return;
+  double* Bp = g.B + r0 + r16;
+  d4 X[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X[s][q] = Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const bool live = 16 * s + r16 < g.nvalid;
+    const double* Lrow = g.L + 16 * s + r16;
+    d4 y = X[s];
+#pragma unroll
+    for (int t = 0; t < s; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double a = Lrow[(int64_t)(16 * t + 4 * kk + kq) * g.ldl];
+        a = live ? -a : 0.0;
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[t][kk], y, 0, 0, 0);
+      }
+    d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double a = g.dinv16[s * 256 + (4 * kk + kq) * 16 + r16];
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y[kk], x, 0, 0, 0);
+    }
+    X[s] = x;
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb] = X[s][q];
+}
+
+}  // namespace gmb
