@@ -30,6 +30,7 @@
 #include "gemm_f64.hpp"
 #include "gradient.hpp"
 #include "potrf_leaf.hpp"
+#include "trsm_strip.hpp"
 
 using namespace gmb;
 
@@ -58,8 +59,8 @@ struct gmb_engine {
   double* dX = nullptr;
   double* dy = nullptr;
   double* dA = nullptr;
-  double* dInv = nullptr;
-  int64_t cap_A = 0, cap_inv = 0;
+  double* dDinv16 = nullptr; // 8 x (16 x 16) sub-block inverses per diagonal block (triangular solves)
+  int64_t cap_A = 0, cap_dinv16 = 0;
 
   // kernel + parameters
   gmb_kernel_spec spec{};
@@ -234,7 +235,8 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
         e->tm.chol_gemm_launches += 1;
         break;
       case 1: e->tm.chol_leaf_ms += t; break;
-      case 2: e->tm.chol_trsm_ms += t; break;
+      case 2:
+      case 5: e->tm.chol_trsm_ms += t; break;
       case 3:
         e->tm.predict_gemm_ms += t;
         e->tm.predict_gemm_flops += p.flops;
@@ -295,6 +297,25 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
     case 4: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 2, 4>), grid, dim3(512), 0, e->cur, g); break;
     default: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 4, 2>), grid, dim3(512), 0, e->cur, g); break;
   }
+  ev_end(e);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+// B <- B inv(L_kk)^T on `nrows` rows (multiple of 16): one wavefront per 16 rows
+int launch_trsm_strip(gmb_engine* e, double* B, int64_t ldb, int64_t nrows, const double* L, int64_t ldl,
+                      const double* dinv16, int nvalid, int ev_kind) {
+  if (nrows <= 0) return GMB_OK;
+  TrsmArgs t;
+  t.B = B;
+  t.ldb = ldb;
+  t.nrows = nrows;
+  t.L = L;
+  t.ldl = ldl;
+  t.dinv16 = dinv16;
+  t.nvalid = nvalid;
+  ev_begin(e, ev_kind, (double)nrows * TILE * TILE);
+  hipLaunchKernelGGL(trsm_strip_kernel, dim3((unsigned)((nrows / 16 + 3) / 4)), dim3(256), 0, e->cur, t);
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -477,27 +498,16 @@ int chol_leaf(gmb_engine* e, int c) {
   a.A = e->dA + (int64_t)c * TILE + (int64_t)c * TILE * e->ld;
   a.lda = e->ld;
   a.nvalid = (int)std::min<int64_t>(TILE, e->N - (int64_t)c * TILE);
-  a.invL = e->dInv + (int64_t)c * TILE * TILE;
+  a.dinv16 = e->dDinv16 + (int64_t)c * 8 * 256;
   a.logdet = e->dscal;
   a.info = e->dinfo;
   a.row0 = (int64_t)c * TILE;
   a.dbg = nullptr;
   int rc = launch_leaf(e, a);
   if (rc) return rc;
-  // panel rows below the diagonal block:  P <- P inv(L_cc)^T   (in place, one row tile per block)
-  GemmArgs g{};
-  g.C = e->dA + (int64_t)(c + 1) * TILE + (int64_t)c * TILE * e->ld;
-  g.ldc = e->ld;
-  g.A = a.invL;
-  g.lda = TILE;
-  g.B = g.C;
-  g.ldb = e->ld;
-  g.mt = 1;
-  g.nt = (int)(e->Nr / TILE) - (c + 1);
-  g.k = TILE;
-  g.alpha = 1.0;
-  g.beta = 0.0;
-  return launch_gemm(e, g, 2);
+  // panel rows below the diagonal block:  P <- P inv(L_cc)^T   (in place, 16 rows per wavefront)
+  return launch_trsm_strip(e, e->dA + (int64_t)(c + 1) * TILE + (int64_t)c * TILE * e->ld, e->ld,
+                           e->Nr - (int64_t)(c + 1) * TILE, a.A, e->ld, a.dinv16, a.nvalid, 5);
 }
 
 int chol_cols(gmb_engine* e, int c0, int c1) {
@@ -591,21 +601,10 @@ int chol_lookahead(gmb_engine* e) {
 
 // ---- predict recursion: V <- W L^-T over column blocks [c0, c1) ------------------------------
 int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1) {
-  if (c1 - c0 == 1) {
-    GemmArgs g{};
-    g.C = V + (int64_t)c0 * TILE * ldz;
-    g.ldc = ldz;
-    g.A = e->dInv + (int64_t)c0 * TILE * TILE;
-    g.lda = TILE;
-    g.B = g.C;
-    g.ldb = ldz;
-    g.mt = 1;
-    g.nt = ntm;
-    g.k = TILE;
-    g.alpha = 1.0;
-    g.beta = 0.0;
-    return launch_gemm(e, g, 3);
-  }
+  if (c1 - c0 == 1)
+    return launch_trsm_strip(e, V + (int64_t)c0 * TILE * ldz, ldz, (int64_t)ntm * TILE,
+                             e->dA + (int64_t)c0 * TILE * (e->ld + 1), e->ld, e->dDinv16 + (int64_t)c0 * 8 * 256,
+                             (int)std::min<int64_t>(TILE, e->N - (int64_t)c0 * TILE), 6);
   const int mid = c0 + (c1 - c0 + 1) / 2;
   int rc = trsm_cols(e, V, ldz, ntm, c0, mid);
   if (rc) return rc;
@@ -693,13 +692,7 @@ int winv_node(gmb_engine* e, int c0, int c1, bool recurse) {
   const int64_t ldw = e->Np, lda = e->ld;
   double* W = e->dW;
   double* A = e->dA;
-  if (c1 - c0 == 1) {
-    const double* inv = e->dInv + (int64_t)c0 * TILE * TILE;
-    HIP_TRY(e, hipMemcpy2DAsync(W + (int64_t)c0 * TILE + (int64_t)c0 * TILE * ldw, ldw * sizeof(double), inv,
-                                TILE * sizeof(double), TILE * sizeof(double), TILE, hipMemcpyDeviceToDevice,
-                                e->cur));
-    return launch_transpose(e, inv, TILE, A + (int64_t)c0 * TILE + (int64_t)c0 * TILE * lda, lda, TILE, TILE);
-  }
+  if (c1 - c0 == 1) return GMB_OK;  // leaf_invert_kernel wrote both diagonal blocks already
   const int mid = c0 + (c1 - c0 + 1) / 2;
   int rc;
   if (recurse) {
@@ -776,6 +769,22 @@ int grad_impl(gmb_engine* e, double* grad) {
   if (!e->dgpart && (rc = alloc(e, &e->dgpart, (int64_t)GACC_DOUBLES))) return rc;
   PhaseTimer tg(e);
   const int nt = (int)(e->Np / TILE);
+  // 0. inverses of all diagonal factor blocks, one workgroup each (kept off the Cholesky's chain)
+  {
+    InvArgs ia;
+    ia.L = e->dA;
+    ia.lda = e->ld;
+    ia.blk_stride = (int64_t)TILE * (e->ld + 1);
+    ia.dinv16 = e->dDinv16;
+    ia.invL = nullptr;
+    ia.n = e->N;
+    ia.W = e->dW;
+    ia.ldw = e->Np;
+    ia.U = e->dA;
+    ia.ldu = e->ld;
+    hipLaunchKernelGGL(leaf_invert_kernel, dim3(nt), dim3(256), 0, e->stream, ia);
+    HIP_TRY(e, hipGetLastError());
+  }
   // 1. W = L^-1 (dW, lower) and U = L^-T (factor buffer, upper); the factor is consumed from here on
   e->factor_consumed = true;
   e->sync_next = 0;
@@ -972,7 +981,7 @@ void gmb_destroy(gmb_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->dX,   e->dy,   e->dA,   e->dInv,  e->xs,    e->xl,   e->cat,    e->dtabs,
+  void* ptrs[] = {e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv,  e->dV,    e->dXs,  e->txs,    e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
   for (void* p : ptrs)
@@ -1018,7 +1027,7 @@ int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t l
   if ((rc = alloc(e, &e->dX, N * (int64_t)D))) return rc;
   if ((rc = alloc(e, &e->dy, e->Np))) return rc;
   if ((rc = ensure(e, &e->dA, &e->cap_A, e->Nr * e->Np))) return rc;
-  if ((rc = ensure(e, &e->dInv, &e->cap_inv, (e->Np / TILE) * (int64_t)TILE * TILE))) return rc;
+  if ((rc = ensure(e, &e->dDinv16, &e->cap_dinv16, (e->Np / TILE) * (int64_t)8 * 256))) return rc;
   if ((rc = alloc(e, &e->dv, e->Np))) return rc;
   const hipMemcpyKind kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   HIP_TRY(e, hipMemcpy2DAsync(e->dX, D * sizeof(double), X, ldx * sizeof(double), D * sizeof(double), N,
@@ -1367,7 +1376,7 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
 }
 
 // ---- block-level operations (multi-GPU driver) ---------------------------------------------
-int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, double* invLkk,
+int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, double* dinv16,
                   double* logdet_accum, int32_t* info) {
   if (!e || !Akk || nvalid < 1 || nvalid > TILE || lda < TILE) return fail(e, GMB_EINVAL, "bad potrf block");
   HIP_TRY(e, hipSetDevice(e->device));
@@ -1375,12 +1384,38 @@ int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, doubl
   a.A = Akk;
   a.lda = lda;
   a.nvalid = nvalid;
-  a.invL = invLkk;
+  a.dinv16 = dinv16;
   a.logdet = logdet_accum;
   a.info = info ? info : e->dinfo;
   a.row0 = 0;
   a.dbg = getenv("GMB_LEAF_DBG") ? logdet_accum + 1 : nullptr;  // tuning: stamps after the log-det slot
   return launch_leaf(e, a);
+}
+
+int gmb_blk_invert(gmb_engine* e, const double* Lkk, int64_t lda, int32_t nvalid, const double* dinv16,
+                   double* invLkk) {
+  if (!e || !Lkk || !dinv16 || !invLkk || nvalid < 1 || nvalid > TILE || lda < TILE)
+    return fail(e, GMB_EINVAL, "bad invert block");
+  HIP_TRY(e, hipSetDevice(e->device));
+  InvArgs ia{};
+  ia.L = Lkk;
+  ia.lda = lda;
+  ia.blk_stride = 0;
+  ia.dinv16 = dinv16;
+  ia.invL = invLkk;
+  ia.n = nvalid;
+  hipLaunchKernelGGL(leaf_invert_kernel, dim3(1), dim3(256), 0, e->stream, ia);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+int gmb_blk_trsm(gmb_engine* e, double* B, int64_t ldb, int64_t nrows, const double* Lkk, int64_t ldl,
+                 const double* dinv16, int32_t nvalid) {
+  if (!e || !B || !Lkk || !dinv16 || nrows < 0 || nrows % 16 || ldb < nrows || ldl < TILE || nvalid < 1 ||
+      nvalid > TILE)
+    return fail(e, GMB_EINVAL, "bad trsm arguments (rows must be a multiple of 16)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  return launch_trsm_strip(e, B, ldb, nrows, Lkk, ldl, dinv16, nvalid, 5);
 }
 
 int gmb_blk_gemm_nt(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
@@ -1444,7 +1479,7 @@ int gmb_blk_pack(gmb_engine* e, double* mat, int64_t ld, int64_t stride_blocks, 
   return GMB_OK;
 }
 
-int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_t* Np, void** invL, void** scal,
+int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_t* Np, void** dinv16, void** scal,
                        void** info) {
   int rc = require_ready(e, false);
   if (rc) return rc;
@@ -1452,7 +1487,7 @@ int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_
   if (ld) *ld = e->ld;
   if (Nr) *Nr = e->Nr;
   if (Np) *Np = e->Np;
-  if (invL) *invL = e->dInv;
+  if (dinv16) *dinv16 = e->dDinv16;
   if (scal) *scal = e->dscal;
   if (info) *info = e->dinfo;
   return GMB_OK;

@@ -389,8 +389,12 @@ struct InvArgs {
   int64_t lda;
   int64_t blk_stride;    // elements between consecutive diagonal blocks (128 * (lda + 1) in the factor buffer)
   const double* dinv16;  // nblk x 8 x 256
-  double* invL;          // nblk x 128 x 128 out, column-major, identity-padded
+  double* invL;          // optional: nblk x 128 x 128 out, column-major, identity-padded
   int64_t n;             // real rows of the whole matrix from the first block on (ragged last block)
+  double* W;             // optional: X_b into diagonal block b of a lower-triangular matrix ...
+  int64_t ldw;
+  double* U;             // ... and X_b^T over diagonal block b of an upper-triangular one (may be the
+  int64_t ldu;           // factor buffer itself: a workgroup reads its whole block before it writes)
 };
 
 __global__ __launch_bounds__(256) void leaf_invert_kernel(InvArgs g) {
@@ -406,7 +410,6 @@ __global__ __launch_bounds__(256) void leaf_invert_kernel(InvArgs g) {
   const int nv = left < LB ? (int)left : LB;
   const double* A = g.L + (int64_t)b * g.blk_stride;
   const double* dsrc = g.dinv16 + (int64_t)b * 8 * SB * SB;
-  double* out = g.invL + (int64_t)b * LB * LB;
   {
     d2 buf[32];
 #pragma unroll
@@ -479,7 +482,18 @@ __global__ __launch_bounds__(256) void leaf_invert_kernel(InvArgs g) {
     double v = 0.0;
     if (p == q) v = rdiag[p];
     else if (p > q) v = S[p * LP + q];
-    out[p + q * LB] = v;
+    if (g.invL) g.invL[(int64_t)b * LB * LB + p + q * LB] = v;
+    if (g.W) g.W[(int64_t)b * LB * (g.ldw + 1) + p + (int64_t)q * g.ldw] = v;
+  }
+  if (g.U) {
+#pragma unroll 8
+    for (int idx = tid; idx < LB * LB; idx += 256) {
+      const int q = idx >> 7, p = idx & 127;  // U[p][q] = X[q][p]
+      double v = 0.0;
+      if (p == q) v = rdiag[p];
+      else if (q > p) v = S[q * LP + p];
+      g.U[(int64_t)b * LB * (g.ldu + 1) + p + (int64_t)q * g.ldu] = v;
+    }
   }
 }
 

@@ -6,8 +6,9 @@ Partition.  Block = 128 rows.  Rank g of G owns block row
 it builds them (covariance tiles need no communication -- X is replicated), solves them against each
 finished diagonal block and applies every trailing update to them.  What is exchanged:
 
-* per block column k: the owner factors the diagonal block and **broadcasts** ``[L_kk | inv(L_kk)]``
-  (2 x 128 KiB); every rank solves its rows of the panel; one **all-gather** delivers the finished
+* per block column k: the owner factors the diagonal block and **broadcasts** ``L_kk`` with the
+  inverses of its eight 16 x 16 diagonal sub-blocks (128 + 16 KiB, what the strip solve
+  ``gmb_blk_trsm`` consumes); every rank solves its rows of the panel; one **all-gather** delivers the finished
   panel column to all ranks (the north star's "panel broadcast" -- with one sender per block row the
   all-gather is what drives all xGMI links at once);
 * at the end: an all-reduce of the log-determinant partials and of the failure flag.
@@ -37,6 +38,7 @@ import numpy as np
 __all__ = ["BlockCyclicCholesky", "TorchComm", "HipBlockOps", "DistributedEngine", "owned_blocks"]
 
 BLK = 128
+DINV = 8 * 16 * 16  # doubles in the sub-block inverses of one diagonal block
 
 
 def owned_blocks(rank: int, world: int, start: int, stop: int):
@@ -164,10 +166,11 @@ class HipBlockOps:
         self.eng = engine
         self.device = device
         b = engine.factor_buffers()
-        self.A, self.ld, self.Nr, self.Np, self.inv, self.scal, self.info = (
-            b["A"], b["ld"], b["Nr"], b["Np"], b["invL"], b["scal"], b["info"])
+        self.A, self.ld, self.Nr, self.Np, self.dinv, self.scal, self.info = (
+            b["A"], b["ld"], b["Nr"], b["Np"], b["dinv16"], b["scal"], b["info"])
         self.N = engine.N
-        self._stage = torch.zeros(2 * BLK * BLK, dtype=torch.float64, device=device)
+        # broadcast unit of one block column: [L_kk (128 x 128) | its eight 16 x 16 sub-block inverses]
+        self._stage = torch.zeros(BLK * BLK + DINV, dtype=torch.float64, device=device)
         self._send = self._recv = None
         self._cap = 0
 
@@ -184,7 +187,7 @@ class HipBlockOps:
 
     def potrf(self, k):
         nvalid = min(BLK, self.N - k * BLK)
-        self.eng.blk_potrf(self._a(k * BLK, k * BLK), self.ld, nvalid, self.inv + 8 * k * BLK * BLK, self.scal,
+        self.eng.blk_potrf(self._a(k * BLK, k * BLK), self.ld, nvalid, self.dinv + 8 * k * DINV, self.scal,
                            self.info)
 
     def diag_stage(self):
@@ -192,12 +195,12 @@ class HipBlockOps:
 
     def diag_to_stage(self, k):
         self.eng.blk_pack(self._a(k * BLK, k * BLK), self.ld, 1, 1, self._stage.data_ptr(), BLK, True)
-        inv = self.torch.as_tensor(_RawDeviceArray(self.inv + 8 * k * BLK * BLK, BLK * BLK), device=self.device)
+        inv = self.torch.as_tensor(_RawDeviceArray(self.dinv + 8 * k * DINV, DINV), device=self.device)
         self._stage[BLK * BLK:].copy_(inv)
 
     def stage_to_diag(self, k):
         self.eng.blk_pack(self._a(k * BLK, k * BLK), self.ld, 1, 1, self._stage.data_ptr(), BLK, False)
-        inv = self.torch.as_tensor(_RawDeviceArray(self.inv + 8 * k * BLK * BLK, BLK * BLK), device=self.device)
+        inv = self.torch.as_tensor(_RawDeviceArray(self.dinv + 8 * k * DINV, DINV), device=self.device)
         inv.copy_(self._stage[BLK * BLK:])
 
     def panel_buffers(self, maxcnt, G):
@@ -213,9 +216,9 @@ class HipBlockOps:
             self.eng.blk_pack(self._a(first * BLK, k * BLK), self.ld, G, cnt, send.data_ptr(), maxcnt * BLK, True)
 
     def solve_packed(self, k, cnt, send, maxcnt):
-        p = send.data_ptr()
-        self.eng.blk_gemm_strided(p, maxcnt * BLK, self.inv + 8 * k * BLK * BLK, BLK, p, maxcnt * BLK, BLK,
-                                  cnt * BLK, BLK, 1.0, 0.0)
+        nvalid = min(BLK, self.N - k * BLK)
+        self.eng.blk_trsm(send.data_ptr(), maxcnt * BLK, cnt * BLK, self._a(k * BLK, k * BLK), self.ld,
+                          self.dinv + 8 * k * DINV, nvalid)
 
     def unpack_panel(self, k, first, cnt, G, recv, r, maxcnt):
         src = recv.data_ptr() + 8 * r * maxcnt * BLK * BLK

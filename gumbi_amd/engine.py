@@ -174,6 +174,9 @@ _SIGNATURES = {
     "gmb_copy_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _DBL_P]),
     "gmb_copy_v": (C.c_int, [C.c_void_p, _DBL_P]),
     "gmb_blk_potrf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gmb_blk_trsm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                               C.c_int32]),
     "gmb_blk_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                   C.c_int32, C.c_int64]),
@@ -388,10 +391,22 @@ class Engine:
         return out
 
     # -- block-level operations (device pointers) --------------------------------------------------------
-    def blk_potrf(self, a_ptr, lda, nvalid, inv_ptr, logdet_ptr=0, info_ptr=0):
-        self._check(self._lib.gmb_blk_potrf(self._h, C.c_void_p(a_ptr), lda, nvalid, C.c_void_p(inv_ptr),
+    def blk_potrf(self, a_ptr, lda, nvalid, dinv16_ptr, logdet_ptr=0, info_ptr=0):
+        """Factor a 128 x 128 block in place; ``dinv16_ptr`` (8 x 256 doubles) receives the inverses of
+        its 16 x 16 diagonal sub-blocks, the operand of :meth:`blk_trsm` / :meth:`blk_invert`."""
+        self._check(self._lib.gmb_blk_potrf(self._h, C.c_void_p(a_ptr), lda, nvalid,
+                                            C.c_void_p(dinv16_ptr) if dinv16_ptr else None,
                                             C.c_void_p(logdet_ptr) if logdet_ptr else None,
                                             C.c_void_p(info_ptr) if info_ptr else None), "gmb_blk_potrf")
+
+    def blk_invert(self, l_ptr, lda, nvalid, dinv16_ptr, inv_ptr):
+        self._check(self._lib.gmb_blk_invert(self._h, C.c_void_p(l_ptr), lda, nvalid, C.c_void_p(dinv16_ptr),
+                                             C.c_void_p(inv_ptr)), "gmb_blk_invert")
+
+    def blk_trsm(self, b_ptr, ldb, nrows, l_ptr, ldl, dinv16_ptr, nvalid=128):
+        """B <- B inv(L)^T in place on ``nrows`` (multiple of 16) rows."""
+        self._check(self._lib.gmb_blk_trsm(self._h, C.c_void_p(b_ptr), ldb, nrows, C.c_void_p(l_ptr), ldl,
+                                           C.c_void_p(dinv16_ptr), nvalid), "gmb_blk_trsm")
 
     def blk_gemm_nt(self, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, m, n, k, alpha, beta, tri=0, tri_shift=0):
         self._check(self._lib.gmb_blk_gemm_nt(self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda,
@@ -413,7 +428,7 @@ class Engine:
         ld, Nr, Np = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._lib.gmb_factor_buffers(self._h, C.byref(A), C.byref(ld), C.byref(Nr), C.byref(Np),
                                                  C.byref(inv), C.byref(scal), C.byref(info)), "gmb_factor_buffers")
-        return dict(A=A.value, ld=ld.value, Nr=Nr.value, Np=Np.value, invL=inv.value, scal=scal.value,
+        return dict(A=A.value, ld=ld.value, Nr=Nr.value, Np=Np.value, dinv16=inv.value, scal=scal.value,
                     info=info.value)
 
     def begin_external_factorization(self):

@@ -184,8 +184,19 @@ int gmb_copy_v(const gmb_engine* e, double* out); /* v = L^-1 y, length N, host 
  * partition can be driven from one process per GPU with the panel
  * broadcast done by RCCL through torch.distributed.  All matrices are column-major float64 in
  * device memory with the given leading dimensions; sizes must be multiples of 128. */
-int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, double* invLkk,
+/* Factor one 128 x 128 diagonal block in place (lower triangle; columns >= nvalid are identity
+ * padding and are left alone).  dinv16 (optional, 8 x 256 doubles) receives the column-major
+ * inverses of the eight 16 x 16 diagonal sub-blocks of the identity-padded factor: the operands
+ * gmb_blk_trsm and gmb_blk_invert need.  *logdet_accum += sum log L_cc; *info = first bad pivot. */
+int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, double* dinv16,
                   double* logdet_accum, int32_t* info);
+/* invLkk (128 x 128 column-major, identity-padded) = inverse of a block factored by gmb_blk_potrf. */
+int gmb_blk_invert(gmb_engine* e, const double* Lkk, int64_t lda, int32_t nvalid,
+                   const double* dinv16, double* invLkk);
+/* B <- B inv(Lkk)^T in place: B is nrows x 128 (nrows a multiple of 16, leading dimension ldb);
+ * rows / columns >= nvalid of the block act as identity whatever the buffer holds there. */
+int gmb_blk_trsm(gmb_engine* e, double* B, int64_t ldb, int64_t nrows, const double* Lkk,
+                 int64_t ldl, const double* dinv16, int32_t nvalid);
 /* C[n + m*ldc] = beta*C + alpha * sum_k A[m + k*lda] * B[n + k*ldb];  tri != 0 skips tiles that
  * lie strictly above the diagonal of the (n, m) index space shifted by tri_shift tiles. */
 int gmb_blk_gemm_nt(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda,
@@ -204,9 +215,10 @@ int gmb_blk_pack(gmb_engine* e, double* mat, int64_t ld, int64_t stride_blocks, 
                  double* packed, int64_t ldp, int32_t to_packed);
 /* Device pointers of the engine's own resident state, for a driver that runs the factorisation
  * itself (multi-GPU): factor buffer (Nr x Np column-major, leading dimension ld), the
- * ceil(N/128) inverse diagonal blocks, the scalar slots ([0] log-det accumulator) and the info word. */
-int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_t* Np, void** invL,
-                       void** scal, void** info);
+ * ceil(N/128) x 8 x 256 sub-block inverses of the diagonal blocks (see gmb_blk_potrf), the scalar
+ * slots ([0] log-det accumulator) and the info word. */
+int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_t* Np,
+                       void** dinv16, void** scal, void** info);
 /* Bracket an externally driven factorisation: begin resets the accumulators; finish takes the
  * global log-det and info (after the driver's reductions), extracts v and marks the engine
  * factorised so that gmb_nlml / gmb_predict work on the resident factor. */

@@ -115,11 +115,13 @@ def test_potrf_leaf_block(gpu, naive, nvalid):
     block[np.arange(nvalid, 128), np.arange(nvalid, 128)] = 1.0
     dev = torch.device("cuda:0")
     tA = torch.tensor(block.T.copy(), device=dev)  # column-major
+    tD = torch.zeros(8 * 256, dtype=torch.float64, device=dev)
     tI = torch.zeros((128, 128), dtype=torch.float64, device=dev)
     tL = torch.zeros(1, dtype=torch.float64, device=dev)
     tinfo = torch.zeros(1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    eng.blk_potrf(tA.data_ptr(), 128, nvalid, tI.data_ptr(), tL.data_ptr(), tinfo.data_ptr())
+    eng.blk_potrf(tA.data_ptr(), 128, nvalid, tD.data_ptr(), tL.data_ptr(), tinfo.data_ptr())
+    eng.blk_invert(tA.data_ptr(), 128, nvalid, tD.data_ptr(), tI.data_ptr())
     torch.cuda.synchronize()
     out = tA.cpu().numpy().T
     L = np.linalg.cholesky(S)
@@ -129,11 +131,35 @@ def test_potrf_leaf_block(gpu, naive, nvalid):
         want_rows = np.linalg.solve(L, P.T).T  # P L^-T
         assert rel(out[nvalid:, :nvalid], want_rows) < 1e-12
     assert np.isclose(float(tL.cpu()[0]), np.sum(np.log(np.diag(L))), rtol=1e-13)
+    Lpad = np.eye(128)
+    Lpad[:nvalid, :nvalid] = L
+    # inverses of the eight 16 x 16 diagonal sub-blocks of the identity-padded factor (column-major)
+    d16 = tD.cpu().numpy().reshape(8, 16, 16).transpose(0, 2, 1)
+    for s_ in range(8):
+        sl = slice(16 * s_, 16 * s_ + 16)
+        want = np.linalg.inv(Lpad[sl, sl])
+        assert np.max(np.abs(d16[s_] - want)) < 1e-12 * np.max(np.abs(want))
+        assert np.all(np.triu(d16[s_], 1) == 0.0)
     inv = tI.cpu().numpy().T
-    want_inv = np.eye(128)
-    want_inv[:nvalid, :nvalid] = np.linalg.inv(L)
+    want_inv = np.linalg.inv(Lpad)
     assert np.max(np.abs(inv - want_inv)) < 1e-11 * np.max(np.abs(want_inv))
     assert np.all(np.triu(inv, 1) == 0.0)
+    # strip solve B <- B inv(L)^T on rows that are not a multiple of the workgroup's 64
+    rows, ldb = 208, 256
+    B = rng.standard_normal((rows, 128))
+    if nvalid < 128:
+        B[:, nvalid:] = 0.0
+    tB = torch.zeros((128, ldb), dtype=torch.float64, device=dev)  # column-major rows x 128, ld = ldb
+    tB[:, :rows] = torch.tensor(B.T.copy(), device=dev)
+    guard = torch.full((128, ldb - rows), 7.0, dtype=torch.float64, device=dev)
+    tB[:, rows:] = guard
+    torch.cuda.synchronize()
+    eng.blk_trsm(tB.data_ptr(), ldb, rows, tA.data_ptr(), 128, tD.data_ptr(), nvalid)
+    torch.cuda.synchronize()
+    got = tB.cpu().numpy().T
+    want = np.linalg.solve(Lpad, B.T).T
+    assert np.max(np.abs(got[:rows] - want)) < 1e-12 * max(1.0, np.max(np.abs(want)))
+    assert np.all(got[rows:] == 7.0)
 
 
 def test_potrf_leaf_flags_indefinite_block(gpu):
@@ -146,10 +172,10 @@ def test_potrf_leaf_flags_indefinite_block(gpu):
     block[40, 40] = -1.0
     dev = torch.device("cuda:0")
     tA = torch.tensor(block, device=dev)
-    tI = torch.zeros((128, 128), dtype=torch.float64, device=dev)
+    tD = torch.zeros(8 * 256, dtype=torch.float64, device=dev)
     tinfo = torch.zeros(1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    eng.blk_potrf(tA.data_ptr(), 128, 128, tI.data_ptr(), 0, tinfo.data_ptr())
+    eng.blk_potrf(tA.data_ptr(), 128, 128, tD.data_ptr(), 0, tinfo.data_ptr())
     torch.cuda.synchronize()
     assert int(tinfo.cpu()[0]) == 41
 
