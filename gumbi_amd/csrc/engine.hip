@@ -47,6 +47,8 @@ struct EventPair {
 
 }  // namespace
 
+constexpr int SCHED_RING = 1024;  // persistent launches per factorisation (8 tile counters each)
+
 struct gmb_engine {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -121,6 +123,14 @@ struct gmb_engine {
   // level-parallel triangular inverse (independent merges dealt over stream + aux[0..2])
   hipStream_t cur = nullptr;
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  // bulk updates that run beside the chain are launched as persistent grids of `persist_wgs`
+  // whole-compute-unit workgroups (compute units minus `reserve_cus`); their tile counters come
+  // from a ring that is zeroed once per factorisation
+  int reserve_cus = 16;
+  int chol_scheme = 0;  // 0 = full-height panel chain on the aux stream, 1 = square chain + bulk row solve
+  int persist_wgs = 0;
+  int32_t* dsched = nullptr;
+  int sched_next = 0;
   std::vector<hipEvent_t> sync_pool;
   size_t sync_next = 0;
   bool lookahead = true;
@@ -257,7 +267,7 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
 // ---- kernel launch helpers ----------------------------------------------------------------
 // `g_in` describes the product in 128-tile units (mt, nt) and elements (k); pick the block tile so
 // that the launch fills the chip, convert, schedule and launch.
-int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
+int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persistent = false) {
   if (g_in.mt <= 0 || g_in.nt <= 0 || g_in.k <= 0) return GMB_OK;
   GemmArgs g = g_in;
   // tiles the 128 x 128 tiling would compute
@@ -279,7 +289,13 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   } else if (variant == 5 && (g.nt % 2 || g.nblk_stride != 1 || g.tri)) {
     variant = 0;
   }
-  static const int BMs[6] = {128, 64, 128, 128, 128, 128}, BNs[6] = {128, 64, 64, 32, 128, 256};
+  // 6 = 256 x 128 / 8 waves, 106 KB of LDS: ONE workgroup per compute unit by construction -- the
+  // persistent bulk update, whose grid of (compute units - reserve_cus) workgroups then leaves
+  // whole compute units to the concurrent chain (a leaf sharing its unit with GEMM waves ran 4x slower)
+  const bool persist = persistent && e->persist_wgs > 0 && !in_place && g_in.mt % 2 == 0 &&
+                       e->sched_next < SCHED_RING;
+  if (persist) variant = 6;
+  static const int BMs[7] = {128, 64, 128, 128, 128, 128, 256}, BNs[7] = {128, 64, 64, 32, 128, 256, 128};
   const int bm = BMs[variant], bn = BNs[variant];
   g.mt = g_in.mt * TILE / bm;
   g.nt = g_in.nt * TILE / bn;
@@ -288,13 +304,20 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   if (nblocks <= 0) return GMB_OK;
   ev_begin(e, ev_kind, flops, g_in.mt, g_in.nt, g.k,
            g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (variant << 8));
-  const dim3 grid(nblocks);
+  int nlaunch = nblocks;
+  g.sched = nullptr;
+  if (persist) {
+    g.sched = e->dsched + 8 * (e->sched_next++);
+    nlaunch = std::min(nblocks, e->persist_wgs);
+  }
+  const dim3 grid(nlaunch);
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, g); break;
     case 1: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2>), grid, dim3(256), 0, e->cur, g); break;
     case 2: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 2, 2>), grid, dim3(256), 0, e->cur, g); break;
     case 3: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2>), grid, dim3(256), 0, e->cur, g); break;
     case 4: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 2, 4>), grid, dim3(512), 0, e->cur, g); break;
+    case 6: hipLaunchKernelGGL((gemm_f64_kernel<4, 2, 4, 4, 2, true>), grid, dim3(512), 0, e->cur, g); break;
     default: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 4, 2>), grid, dim3(512), 0, e->cur, g); break;
   }
   ev_end(e);
@@ -493,7 +516,9 @@ int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int6
 PointSet train_set(const gmb_engine* e) { return PointSet{e->xs, e->xl, e->cat, e->N, e->Nr}; }
 
 // ---- Cholesky recursion -------------------------------------------------------------------
-int chol_leaf(gmb_engine* e, int c) {
+// `rend`: block row where the panel solve / updates stop (the whole matrix, or the end of a
+// diagonal square when the rows below are solved later in bulk)
+int chol_leaf(gmb_engine* e, int c, int rend) {
   LeafArgs a;
   a.A = e->dA + (int64_t)c * TILE + (int64_t)c * TILE * e->ld;
   a.lda = e->ld;
@@ -507,13 +532,13 @@ int chol_leaf(gmb_engine* e, int c) {
   if (rc) return rc;
   // panel rows below the diagonal block:  P <- P inv(L_cc)^T   (in place, 16 rows per wavefront)
   return launch_trsm_strip(e, e->dA + (int64_t)(c + 1) * TILE + (int64_t)c * TILE * e->ld, e->ld,
-                           e->Nr - (int64_t)(c + 1) * TILE, a.A, e->ld, a.dinv16, a.nvalid, 5);
+                           (int64_t)(rend - c - 1) * TILE, a.A, e->ld, a.dinv16, a.nvalid, 5);
 }
 
-int chol_cols(gmb_engine* e, int c0, int c1) {
-  if (c1 - c0 == 1) return chol_leaf(e, c0);
+int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
+  if (c1 - c0 == 1) return chol_leaf(e, c0, rend);
   const int mid = c0 + (c1 - c0 + 1) / 2;
-  int rc = chol_cols(e, c0, mid);
+  int rc = chol_cols(e, c0, mid, rend);
   if (rc) return rc;
   GemmArgs g{};
   g.C = e->dA + (int64_t)mid * TILE + (int64_t)mid * TILE * e->ld;
@@ -523,14 +548,14 @@ int chol_cols(gmb_engine* e, int c0, int c1) {
   g.B = g.A;
   g.ldb = e->ld;
   g.mt = c1 - mid;
-  g.nt = (int)(e->Nr / TILE) - mid;
+  g.nt = rend - mid;
   g.k = (mid - c0) * TILE;
   g.alpha = -1.0;
   g.beta = 1.0;
   g.tri = 1;
   rc = launch_gemm(e, g, 0);
   if (rc) return rc;
-  return chol_cols(e, mid, c1);
+  return chol_cols(e, mid, c1, rend);
 }
 
 // ---- cross-stream ordering helpers -----------------------------------------------------------
@@ -551,26 +576,25 @@ int order_after(gmb_engine* e, hipStream_t from, hipStream_t to) {
   return GMB_OK;
 }
 
-// ---- Cholesky with panel look-ahead -------------------------------------------------------------
-// Right-looking over panels of `panel_blocks` block columns.  The panel itself is factored by the
-// recursion above (leaves + small GEMMs: a latency-bound serial chain); the trailing update by
-// panel p is split into U1 (the columns of panel p+1) and U2 (everything to the right of it):
-//   main stream:  U1(p)            U2(p)  ------------------->  U1(p+1)  U2(p+1) ...
-//   aux  stream:        wait U1(p); factor panel p+1 ----------> signal
-// so the next panel's serial chain runs beside the long-k MFMA update instead of after it.
-int chol_lookahead(gmb_engine* e) {
+int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip);
+
+// Full-height variant: the panel chain (leaf, strip solve and updates over ALL rows below) runs on
+// the auxiliary stream beside U2; U1 = the next panel's columns over all rows.
+int chol_lookahead_full(gmb_engine* e) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
   const int w = e->panel_blocks;
   hipStream_t mainS = e->stream, auxS = e->aux[0];
   e->sync_next = 0;
+  e->sched_next = 0;
+  HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
   int rc;
   e->cur = mainS;
-  if ((rc = chol_cols(e, 0, std::min(w, nct)))) return rc;
+  if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
   for (int c0 = 0; c0 < nct; c0 += w) {
     const int c1 = std::min(c0 + w, nct);
     const int n0 = c1, n1 = std::min(c1 + w, nct);
     if (n0 >= nct) break;
-    auto update = [&](int col_lo, int col_hi) {
+    auto update = [&](int col_lo, int col_hi, bool bulk = false) {
       GemmArgs g{};
       g.C = e->dA + (int64_t)col_lo * TILE + (int64_t)col_lo * TILE * e->ld;
       g.ldc = e->ld;
@@ -584,29 +608,106 @@ int chol_lookahead(gmb_engine* e) {
       g.alpha = -1.0;
       g.beta = 1.0;
       g.tri = 1;
-      return launch_gemm(e, g, 0);
+      return launch_gemm(e, g, 0, bulk);
     };
     e->cur = mainS;
     if ((rc = update(n0, n1))) return rc;                 // U1
     if ((rc = order_after(e, mainS, auxS))) return rc;
     e->cur = auxS;
-    if ((rc = chol_cols(e, n0, n1))) return rc;           // panel p+1, beside U2
+    if ((rc = chol_cols(e, n0, n1, nrt))) return rc;           // panel p+1, beside U2
     e->cur = mainS;
-    if (n1 < nct && (rc = update(n1, nct))) return rc;    // U2
+    if (n1 < nct && (rc = update(n1, nct, true))) return rc;    // U2
     if ((rc = order_after(e, auxS, mainS))) return rc;
   }
   e->cur = mainS;
   return GMB_OK;
 }
 
+
+// ---- Cholesky with panel look-ahead -------------------------------------------------------------
+// Right-looking over panels of `panel_blocks` block columns [c0, c1).  Only the panel's diagonal
+// SQUARE is factored by the latency-bound chain (leaf, strip solve, small updates); everything
+// else is bulk MFMA work:
+//
+//   main :  square(p) | solve rows below: A[c1:, c0:c1] L_pp^-T | U1(p): next square | square(p+1) ...
+//   bulk :                                                       | wait U1; U2(p): rest of the trailing update
+//
+// square(p+1) needs only U1(p), so the chain of the next panel runs beside U2(p).  For that to
+// happen the chain's kernels must actually find a compute unit while U2's grid is resident (the
+// leaf needs 150 KB of LDS, i.e. an EMPTY compute unit; a GEMM workgroup of U2 holds its unit for
+// hundreds of microseconds, so a late kernel waits that long for a slot): U2 is launched as a
+// PERSISTENT grid of whole-compute-unit workgroups, `reserve_cus` fewer than the chip has compute
+// units, that draw their tiles from per-XCD counters.  The streams are ordered with events.
+int chol_lookahead(gmb_engine* e) {
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  const int w = e->panel_blocks;
+  hipStream_t mainS = e->stream, bulkS = e->aux[2];
+  e->sync_next = 0;
+  e->sched_next = 0;
+  HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
+  int rc;
+  e->cur = mainS;
+  for (int c0 = 0; c0 < nct; c0 += w) {
+    const int c1 = std::min(c0 + w, nct), c2 = std::min(c1 + w, nct);
+    // the panel's diagonal square (for the last panel: including the y row block, if separate)
+    const int rend = (c1 == nct) ? nrt : c1;
+    if ((rc = chol_cols(e, c0, c1, rend))) return rc;
+    if (c1 == nct) break;
+    // rows below the square, once the previous bulk update has reached them
+    if ((rc = order_after(e, bulkS, mainS))) return rc;
+    if ((rc = trsm_cols(e, e->dA + (int64_t)c1 * TILE, e->ld, nrt - c1, c0, c1, 2, 5))) return rc;
+    GemmArgs g{};
+    g.lda = g.ldb = g.ldc = e->ld;
+    g.k = (c1 - c0) * TILE;
+    g.alpha = -1.0;
+    g.beta = 1.0;
+    g.tri = 1;
+    // U1: the next diagonal square (with the y row block when it closes the matrix)
+    const int r2 = (c2 == nct) ? nrt : c2;
+    g.C = e->dA + (int64_t)c1 * TILE + (int64_t)c1 * TILE * e->ld;
+    g.A = e->dA + (int64_t)c1 * TILE + (int64_t)c0 * TILE * e->ld;
+    g.B = g.A;
+    g.mt = c2 - c1;
+    g.nt = r2 - c1;
+    if ((rc = launch_gemm(e, g, 0))) return rc;
+    if (r2 < nrt) {
+      // U2: rows [c2, nrt) x columns [c1, nct) of the trailing matrix, on the bulk stream
+      if ((rc = order_after(e, mainS, bulkS))) return rc;
+      e->cur = bulkS;
+      g.C = e->dA + (int64_t)c2 * TILE + (int64_t)c1 * TILE * e->ld;
+      g.B = e->dA + (int64_t)c2 * TILE + (int64_t)c0 * TILE * e->ld;
+      g.mt = (nct - c1) & ~1;  // the persistent tiling is 256 columns wide
+      g.nt = nrt - c2;
+      g.tri_off = (c2 - c1) * TILE;
+      rc = launch_gemm(e, g, 0, true);
+      if (!rc && ((nct - c1) & 1)) {  // odd block column left over: the last one
+        const int cl = nct - 1, rl = std::max(c2, cl);
+        g.C = e->dA + (int64_t)rl * TILE + (int64_t)cl * TILE * e->ld;
+        g.A = e->dA + (int64_t)cl * TILE + (int64_t)c0 * TILE * e->ld;
+        g.B = e->dA + (int64_t)rl * TILE + (int64_t)c0 * TILE * e->ld;
+        g.mt = 1;
+        g.nt = nrt - rl;
+        g.tri = 0;
+        g.tri_off = 0;
+        rc = launch_gemm(e, g, 0);
+        g.tri = 1;
+      }
+      e->cur = mainS;
+      if (rc) return rc;
+    }
+  }
+  e->cur = mainS;
+  return order_after(e, bulkS, mainS);
+}
+
 // ---- predict recursion: V <- W L^-T over column blocks [c0, c1) ------------------------------
-int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1) {
+int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip) {
   if (c1 - c0 == 1)
     return launch_trsm_strip(e, V + (int64_t)c0 * TILE * ldz, ldz, (int64_t)ntm * TILE,
                              e->dA + (int64_t)c0 * TILE * (e->ld + 1), e->ld, e->dDinv16 + (int64_t)c0 * 8 * 256,
-                             (int)std::min<int64_t>(TILE, e->N - (int64_t)c0 * TILE), 6);
+                             (int)std::min<int64_t>(TILE, e->N - (int64_t)c0 * TILE), kind_strip);
   const int mid = c0 + (c1 - c0 + 1) / 2;
-  int rc = trsm_cols(e, V, ldz, ntm, c0, mid);
+  int rc = trsm_cols(e, V, ldz, ntm, c0, mid, kind_gemm, kind_strip);
   if (rc) return rc;
   GemmArgs g{};
   g.C = V + (int64_t)mid * TILE * ldz;
@@ -620,9 +721,9 @@ int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1) {
   g.k = (mid - c0) * TILE;
   g.alpha = -1.0;
   g.beta = 1.0;
-  rc = launch_gemm(e, g, 3);
+  rc = launch_gemm(e, g, kind_gemm);
   if (rc) return rc;
-  return trsm_cols(e, V, ldz, ntm, mid, c1);
+  return trsm_cols(e, V, ldz, ntm, mid, c1, kind_gemm, kind_strip);
 }
 
 // ---- NLML gradient ---------------------------------------------------------------------------
@@ -954,16 +1055,34 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   const char* pb = getenv("GMB_PANEL_BLOCKS");
   if (pb && atoi(pb) > 0) e->panel_blocks = atoi(pb);
   e->cur = e->stream;
-  // the auxiliary streams carry the latency-bound panel chain of the look-ahead Cholesky: give
-  // them the highest queue priority so their (few) workgroups are placed ahead of the bulk update's
+  // aux[0], aux[1]: highest queue priority (independent merges of the triangular inverse);
+  // aux[2]: LOWEST priority -- it carries the bulk trailing updates of the look-ahead Cholesky,
+  // whose workgroups must not be placed ahead of the latency-bound chain on the main stream.
+  // (No fifth stream: beyond four hardware queues the runtime multiplexes streams and every
+  // kernel of the process slows down -- measured.)
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   const char* ap = getenv("GMB_AUX_PRIORITY");
   const bool use_prio = !(ap && ap[0] == '0');
-  for (auto& s2 : e->aux) {
-    hipError_t st2 = use_prio ? hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio_hi)
-                              : hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+  for (int a = 0; a < 3; ++a) {
+    hipError_t st2 = use_prio ? hipStreamCreateWithPriority(&e->aux[a], hipStreamNonBlocking, a == 2 ? prio_lo : prio_hi)
+                              : hipStreamCreateWithFlags(&e->aux[a], hipStreamNonBlocking);
     if (st2 != hipSuccess) {
+      gmb_destroy(e);
+      return GMB_EHIP;
+    }
+  }
+  {
+    const char* cs = getenv("GMB_CHOL_SCHEME");
+    if (cs) e->chol_scheme = atoi(cs);
+    const char* rs = getenv("GMB_RESERVE_CUS");  // tuning: 0 = ordinary (chip-filling) bulk launches
+    if (rs) e->reserve_cus = atoi(rs);
+    hipDeviceProp_t prop;
+    if (e->reserve_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      const int wgs = prop.multiProcessorCount - e->reserve_cus;
+      e->persist_wgs = wgs >= 64 ? (wgs / 8) * 8 : 0;
+    }
+    if (hipMalloc((void**)&e->dsched, SCHED_RING * 8 * sizeof(int32_t)) != hipSuccess) {
       gmb_destroy(e);
       return GMB_EHIP;
     }
@@ -981,7 +1100,7 @@ void gmb_destroy(gmb_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
+  void* ptrs[] = {e->dsched, e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv,  e->dV,    e->dXs,  e->txs,    e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
   for (void* p : ptrs)
@@ -1133,8 +1252,8 @@ int gmb_factorize(gmb_engine* e) {
   // 2. Cholesky
   PhaseTimer tc(e);
   if (e->lookahead && e->Np / TILE > e->panel_blocks) {
-    if ((rc = chol_lookahead(e))) return rc;
-  } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE)))) {
+    if ((rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : chol_lookahead(e)))) return rc;
+  } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) {
     return rc;
   }
   // 3. v = L^-1 y is row N of the factor
@@ -1235,7 +1354,7 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
       a.mode = COV_CROSS;
       if ((rc = launch_cov(e, a))) return rc;
     }
-    if ((rc = trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, (int)(e->Np / TILE)))) return rc;
+    if ((rc = trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, (int)(e->Np / TILE), 3, 6))) return rc;
     {
       KssArgs k{};
       k.p = e->cp;

@@ -61,6 +61,11 @@ struct GemmArgs {
   // XCD-balanced schedule (filled by gemm_schedule): the computed tiles, enumerated row-major
   // (tm outer, tn inner), are cut into 8 contiguous runs of equal WORK; block b serves run b % 8.
   int32_t xstart[9];
+  // Persistent mode (sched != nullptr): the grid is SMALLER than the tile list and every workgroup
+  // keeps drawing the next tile of its XCD's run from sched[xcd] (8 zero-initialised counters)
+  // until the run is exhausted.  The launch then occupies exactly gridDim.x workgroup slots for
+  // its whole duration and leaves the rest of the chip to concurrent latency-bound kernels.
+  int32_t* sched;
 };
 
 // XCD-aware tile order.  The dispatcher places block b on XCD b % 8 (observed, speed only), and
@@ -94,7 +99,7 @@ __host__ __device__ __forceinline__ int gemm_first_tn(int64_t T, int bn, int str
 // then keeps its 128 accumulator registers + staging in 207 VGPRs (no AGPRs, no spills) and the
 // second workgroup's MFMAs fill the first one's barrier / staging bubbles: 39 -> 52 TF/s on the
 // whole N = 30k Cholesky, 44 -> 59 TF/s on the predict GEMMs (measured A/B on MI355X).
-template <int WGM, int WGN, int WTM, int WTN, int OCC>
+template <int WGM, int WGN, int WTM, int WTN, int OCC, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs g) {
   constexpr int NT = 64 * WGM * WGN;                      // threads: WGM x WGN waves
   constexpr int BM = 16 * WTM * WGM, BN = 16 * WTN * WGN; // block tile; wave tile 16*WTM x 16*WTN
@@ -104,11 +109,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs 
   static_assert(NA >= 1 && NB >= 1 && NA * RA == KT && NB * RB == KT, "staging must tile the k-tile");
   __shared__ double lds[2][KT * (PA + PB)];
 
+  __shared__ int next_tile;
+  const int xcd = blockIdx.x & 7;
+  for (int round = 0;; ++round) {
   // compact index of this block's tile within its XCD's run, then (tm, tn) by walking the rows
   int tm, tn;
   {
-    const int xcd = blockIdx.x & 7;
-    int ci = g.xstart[xcd] + (blockIdx.x >> 3);
+    int ci;
+    if constexpr (PERSIST) {
+      if (threadIdx.x == 0) next_tile = atomicAdd(&g.sched[xcd], 1);
+      __syncthreads();
+      ci = g.xstart[xcd] + next_tile;
+      __syncthreads();
+    } else {
+      if (round) return;
+      ci = g.xstart[xcd] + (blockIdx.x >> 3);
+    }
     if (ci >= g.xstart[xcd + 1]) return;
     if (!g.tri) {
       tm = ci / g.nt;
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs 
         for (int j = 0; j < WTN; ++j) row[j * 16] = g.beta * c[j] + g.alpha * acc[i][j][r];
       }
   }
+  }  // persistent tile loop
 }
 
 // MFMA-only microbenchmark: the GEMM's own register pattern (4 x 4 independent accumulators fed

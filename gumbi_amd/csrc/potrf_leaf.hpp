@@ -115,8 +115,11 @@ __device__ __forceinline__ double rl_sgpr(double v, int lane_const) {
   return u.d;
 }
 
-__device__ __forceinline__ void factor_diag16_mfma(double* S, double* dinv_s, double* rdiag, int c0, int nv,
-                                                   int32_t* info, int64_t row0) {
+// `Sd` / `pitch`: the block column that holds the sub-block (its first row is the sub-block's
+// first row, see the packed layout below).
+// `gdinv` (may be null): global copy of the dense inverse, for the solves of later kernels.
+__device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double* dinv_s, double* gdinv,
+                                                   double* rdiag, int c0, int nv, int32_t* info, int64_t row0) {
   const int lane = threadIdx.x & 63;
   const int r16 = lane & 15, kq = lane >> 4;
   // gather indices (bytes): lane 16 k' + r16, opaque so the compiler keeps them as bpermutes
@@ -132,7 +135,7 @@ __device__ __forceinline__ void factor_diag16_mfma(double* S, double* dinv_s, do
   for (int r = 0; r < 4; ++r) {
     const int m = kq + 4 * r;
     const int hi = m > r16 ? m : r16, lo = m > r16 ? r16 : m;
-    acc[r] = S[(c0 + lo) * LP + c0 + hi];
+    acc[r] = Sd[lo * pitch + hi];
   }
   double Lcol[4], coef[4][4], rinv[4][4];
   int badcol = -1;
@@ -224,20 +227,34 @@ __device__ __forceinline__ void factor_diag16_mfma(double* S, double* dinv_s, do
     Xrow[q] = xq;              // X[4q + kq][r16]
     if (q < 3) e = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lcol[q], xq, e, 0, 0, 0);
   }
-  // results: L_ss (lower) and X_ss^T (strict upper) into S, dense X_ss into dinv_s, 1/diag
+  // results: L_ss (lower) into the block, dense X_ss into dinv_s, 1/diag
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int col = 4 * q + kq;          // Lcol[q]: L[r16][col];  Xrow[q]: X[col][r16]
-    if (r16 >= col) S[(c0 + col) * LP + c0 + r16] = Lcol[q];
+    if (r16 >= col) Sd[col * pitch + r16] = Lcol[q];
     dinv_s[r16 * SB + col] = Xrow[q];    // column-major X: X[a = col][j = r16] at j*16 + a
-    if (col > r16) S[(c0 + col) * LP + c0 + r16] = Xrow[q];
+    if (gdinv) gdinv[r16 * SB + col] = Xrow[q];
     if (r16 == 0) rdiag[c0 + col] = kq == 0 ? rinv[q][0] : (kq == 1 ? rinv[q][1] : (kq == 2 ? rinv[q][2] : rinv[q][3]));
   }
 }
 
+// Packed LDS layout of the lower block triangle: block column s (columns 16s .. 16s+15) keeps
+// rows 16s .. 127 only, column pitch 130 - 16s.  76 KB instead of 133 KB for the full square, which
+// (with a single 2 KB buffer for the current sub-block inverse) brings the kernel to 79 KB of LDS:
+// it then fits on a compute unit NEXT TO one resident GEMM workgroup (74 KB) and no longer has to
+// wait for a compute unit to drain completely while a trailing update occupies the chip (that
+// wait was the whole duration of the update).
+__host__ __device__ constexpr int pk_off(int s) { return 16 * s * (138 - 8 * s); }
+__host__ __device__ constexpr int pk_pitch(int s) { return LP - 16 * s; }
+constexpr int PK_SIZE = pk_off(8);  // 9472 doubles
+__device__ __forceinline__ int pk(int r, int c) {
+  const int s = c >> 4;
+  return pk_off(s) + (c & 15) * pk_pitch(s) + r - 16 * s;
+}
+
 __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
-  __shared__ double S[LB * LP];        // 133,120 B
-  __shared__ double dinv[8][SB * SB];  //  16,384 B  dense X_ii, column-major
+  __shared__ double S[PK_SIZE];        //  75,776 B
+  __shared__ double dinv[SB * SB];     //   2,048 B  dense X_ss of the current sub-panel, column-major
   __shared__ double rdiag[LB];         //   1,024 B  1 / L_cc  (= X_cc)
   __shared__ double red[4];
 
@@ -246,68 +263,90 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
   const int wave = tid >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int nv = g.nvalid;
+  // sub-block inverses go straight to global memory as they are produced (a ragged block
+  // rebuilds them at the end instead)
+  double* gd = (g.dinv16 && nv == LB) ? g.dinv16 : nullptr;
+  // the block column chain waits for this kernel: its waves go first on a compute unit it shares
+  __builtin_amdgcn_s_setprio(3);
   LEAF_STAMP(0);
 
-  // ---- load: lower triangle of real columns, identity elsewhere, zeros above the diagonal ----
-  // (8 independent loads in flight per thread: the block is read once, latency-bound otherwise)
+  // ---- load: lower block triangle of real columns, identity elsewhere, zeros above the diagonal
   {
-    // all 32 16-byte loads of a thread are issued before the first use (one latency, not 64)
+    // all 16-byte loads of a thread are issued before the first use (one latency, not 32)
     d2 buf[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       const int p = tid + 256 * i;            // pair index: column p / 64, rows 2 (p % 64), +1
       const int c = p >> 6, r = (p & 63) * 2;
-      buf[i] = *reinterpret_cast<const d2*>(g.A + r + (int64_t)c * g.lda);
+      if (r >= (c & ~15)) buf[i] = *reinterpret_cast<const d2*>(g.A + r + (int64_t)c * g.lda);
     }
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       const int p = tid + 256 * i;
       const int c = p >> 6, r = (p & 63) * 2;
-      d2 v = buf[i];
-      if (c >= nv) v = d2{0.0, 0.0};
-      if (r < c) v[0] = 0.0;
-      if (r + 1 < c) v[1] = 0.0;
-      if (c >= nv && r == c) v[0] = 1.0;
-      if (c >= nv && r + 1 == c) v[1] = 1.0;
-      S[c * LP + r] = v[0];
-      S[c * LP + r + 1] = v[1];
+      if (r >= (c & ~15)) {
+        d2 v = buf[i];
+        if (c >= nv) v = d2{0.0, 0.0};
+        if (r < c) v[0] = 0.0;
+        if (r + 1 < c) v[1] = 0.0;
+        if (c >= nv && r == c) v[0] = 1.0;
+        if (c >= nv && r + 1 == c) v[1] = 1.0;
+        const int a = pk(r, c);
+        S[a] = v[0];
+        S[a + 1] = v[1];
+      }
     }
   }
   __syncthreads();
   LEAF_STAMP(1);
 
+  // finished block column s goes back to global memory while the factorisation continues
+  auto write_back = [&](int s, int first, int nthreads) {
+    const int c0 = s * SB, h = LB - c0;
+    const double* Sd = &S[pk_off(s)];
+    const int pitch = pk_pitch(s);
+    for (int idx = first; idx < SB * h; idx += nthreads) {
+      const int cl = idx / h, rl = idx - cl * h;
+      if (c0 + cl < nv && rl >= cl) g.A[c0 + rl + (int64_t)(c0 + cl) * g.lda] = Sd[cl * pitch + rl];
+    }
+  };
+
   // ---- factorisation: right-looking over 16-column sub-panels with one-step look-ahead -------
-  if (wave == 0) factor_diag16_mfma(S, dinv[0], rdiag, 0, nv, g.info, g.row0);
+  if (wave == 0) factor_diag16_mfma(&S[0], pk_pitch(0), dinv, gd, rdiag, 0, nv, g.info, g.row0);
   __syncthreads();
   for (int s = 0; s < LB / SB - 1; ++s) {
     const int c0 = s * SB;
+    double* Sd = &S[pk_off(s)];      // block column s, first row c0
+    const int pitch = pk_pitch(s);
     // (B) sub-panel rows below the diagonal sub-block:  P <- P X_ss^T  (MFMA, in place per tile)
     for (int tr = s + 1 + wave; tr < LB / SB; tr += 4) {
-      const int rw = tr * SB;
+      const int rw = tr * SB - c0;
       d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-      acc = mfma_tile_k16(dinv[s], SB, &S[c0 * LP + rw], LP, acc);
+      acc = mfma_tile_k16(dinv, SB, &Sd[rw], pitch, acc);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[(c0 + kq + 4 * r) * LP + rw + r16] = acc[r];
+      for (int r = 0; r < 4; ++r) Sd[(kq + 4 * r) * pitch + rw + r16] = acc[r];
     }
     LEAF_STAMP(8 + 3 * s);
     __syncthreads();
     LEAF_STAMP(9 + 3 * s);
     // (C) rank-16 update of the remaining lower triangle.  Wave 0 takes the next diagonal tile
     //     first and factors it straight away, hiding that dependent chain behind the other
-    //     waves' MFMA tiles.
+    //     waves' MFMA tiles (and their write-back of the finished block column).
     {
       const int n = LB / SB - 1 - s;  // remaining block rows
       if (wave == 0) {
-        const int cc = (s + 1) * SB;
+        const int cc = SB;            // offset of block row s + 1 inside block column s
+        double* Sn = &S[pk_off(s + 1)];
+        const int pn = pk_pitch(s + 1);
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-        acc = mfma_tile_k16(&S[c0 * LP + cc], LP, &S[c0 * LP + cc], LP, acc);
+        acc = mfma_tile_k16(&Sd[cc], pitch, &Sd[cc], pitch, acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S[(cc + kq + 4 * r) * LP + cc + r16] -= acc[r];
+        for (int r = 0; r < 4; ++r) Sn[(kq + 4 * r) * pn + r16] -= acc[r];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        factor_diag16_mfma(S, dinv[s + 1], rdiag, cc, nv, g.info, g.row0);
+        factor_diag16_mfma(Sn, pn, dinv, gd ? gd + (s + 1) * SB * SB : nullptr, rdiag, c0 + SB, nv, g.info, g.row0);
       } else {
         const int ntile = n * (n + 1) / 2;
         for (int t = wave; t < ntile; t += 3) {  // t = 0 is the diagonal tile wave 0 owns
@@ -317,12 +356,16 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
             ++tc;
           }
           const int tr = tc + rem;
-          const int cc = (s + 1 + tc) * SB, rw = (s + 1 + tr) * SB;
+          const int sc = s + 1 + tc;                         // destination block column
+          const int cc = (1 + tc) * SB, rw = (1 + tr) * SB;  // offsets inside block column s
           d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-          acc = mfma_tile_k16(&S[c0 * LP + cc], LP, &S[c0 * LP + rw], LP, acc);
+          acc = mfma_tile_k16(&Sd[cc], pitch, &Sd[rw], pitch, acc);
+          double* dst = &S[pk_off(sc)] + (tr - tc) * SB + r16;
+          const int pd = pk_pitch(sc);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) S[(cc + kq + 4 * r) * LP + rw + r16] -= acc[r];
+          for (int r = 0; r < 4; ++r) dst[(kq + 4 * r) * pd] -= acc[r];
         }
+        write_back(s, tid - 64, 192);
       }
     }
     LEAF_STAMP(10 + 3 * s);
@@ -330,52 +373,49 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
   }
 
   LEAF_STAMP(2);
-  // ---- write the factor back (real columns only), accumulate log-det ------------------------
-#pragma unroll 8
-  for (int idx = tid; idx < LB * LB; idx += 256) {
-    const int c = idx >> 7, r = idx & 127;
-    if (c < nv && r >= c) g.A[r + (int64_t)c * g.lda] = S[c * LP + r];
-  }
+  // ---- last block column back, accumulate log-det -------------------------------------------
+  write_back(LB / SB - 1, tid, 256);
   {
     double lg = 0.0;
-    if (tid < nv) lg = log(S[tid * LP + tid]);
+    if (tid < nv) lg = -log(rdiag[tid]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
     if (lane == 0) red[wave] = lg;
     __syncthreads();
     if (tid == 0 && g.logdet) atomicAdd(g.logdet, red[0] + red[1] + red[2] + red[3]);
   }
-  if (g.dinv16 == nullptr) return;
   LEAF_STAMP(3);
-  if (nv < LB) {
+  if (g.dinv16 && nv < LB) {
     // Only the last diagonal block of a matrix is ragged.  Its panel rows (the y row, padding)
-    // are not part of the triangular factor and the padding is identity: rebuild the sub-block
+    // are not part of the triangular factor and the padding is identity: build the sub-block
     // inverses of the identity-padded factor the slow way.
     __syncthreads();
     for (int idx = tid; idx < LB * LB; idx += 256) {
       const int c = idx >> 7, r = idx & 127;
-      if (c < nv && r >= nv) S[c * LP + r] = 0.0;
-      if (c >= nv && r >= c) S[c * LP + r] = (r == c) ? 1.0 : 0.0;
+      if (r >= (c & ~15)) {
+        if (c < nv && r >= nv) S[pk(r, c)] = 0.0;
+        if (c >= nv) S[pk(r, c)] = (r == c) ? 1.0 : 0.0;
+      }
     }
     if (tid >= nv && tid < LB) rdiag[tid] = 1.0;
     __syncthreads();
     if (tid < LB) {
-      const int s = tid >> 4, j = tid & 15, c0 = s * SB;
+      const int s = tid >> 4, j = tid & 15;
+      const double* Sd = &S[pk_off(s)];
+      const int pitch = pk_pitch(s);
       double xc[SB];
 #pragma unroll
       for (int a = 0; a < SB; ++a) {
         double t = (a == j) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < a; ++k)
-          if (k >= j) t -= S[(c0 + k) * LP + c0 + a] * xc[k];
-        xc[a] = (a < j) ? 0.0 : t * rdiag[c0 + a];
+          if (k >= j) t -= Sd[k * pitch + a] * xc[k];
+        xc[a] = (a < j) ? 0.0 : t * rdiag[s * SB + a];
       }
 #pragma unroll
-      for (int a = 0; a < SB; ++a) dinv[s][j * SB + a] = xc[a];
+      for (int a = 0; a < SB; ++a) g.dinv16[s * SB * SB + j * SB + a] = xc[a];
     }
   }
-  __syncthreads();
-  for (int idx = tid; idx < 8 * SB * SB; idx += 256) g.dinv16[idx] = dinv[idx >> 8][idx & 255];
   LEAF_STAMP(4);
 }
 

@@ -1,0 +1,27 @@
+"""Workload for a rocprofv3 --kernel-trace timeline: a few factorize / gradient / predict calls
+at one size (argv: N d what), the last of each is what tools/timeline_dump.py looks at."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np  # noqa: E402
+
+from gumbi_amd import engine  # noqa: E402
+from oracle import gp_oracle as O  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+what = sys.argv[3] if len(sys.argv) > 3 else "factorize"
+X, y, ls = O.synthetic_table(N, d)
+Xs = O.synthetic_grid(d)
+e = engine.Engine(0)
+e.set_data(X, y)
+e.set_kernel(engine.KernelSpec(D=d, idx_cont=list(range(d))))
+e.set_theta(np.concatenate([ls, [1.0, 0.2]]))
+for _ in range(3):
+    e.factorize()
+    if what == "grad":
+        e.nlml(grad=True)
+    if what == "predict":
+        e.predict(Xs)
+e.close()
