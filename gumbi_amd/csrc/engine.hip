@@ -117,6 +117,8 @@ struct gmb_engine {
   bool naive_leaf = false;
   bool small_tiles = true;
   int gemm_variant = 0;
+  long long wg_slots = 512;  // resident GEMM workgroups: two per compute unit
+  bool force_variant = false;  // tuning: GMB_GEMM_VARIANT pins the tile shape of every out-of-place GEMM
 
   // concurrency inside one factorisation / gradient: `cur` is the stream the launch helpers use;
   // it is `stream` except inside the look-ahead Cholesky (panel chain on aux[0]) and the
@@ -126,7 +128,7 @@ struct gmb_engine {
   // bulk updates that run beside the chain are launched as persistent grids of `persist_wgs`
   // whole-compute-unit workgroups (compute units minus `reserve_cus`); their tile counters come
   // from a ring that is zeroed once per factorisation
-  int reserve_cus = 16;
+  int reserve_cus = 0;  // off by default: no gain measured at N = 10k, a loss at N = 30k
   int chol_scheme = 0;  // 0 = full-height panel chain on the aux stream, 1 = square chain + bulk row solve
   int persist_wgs = 0;
   int32_t* dsched = nullptr;
@@ -281,13 +283,35 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
   const bool in_place = (const double*)g.C == g.B;  // the block must own every column of its rows
   // variant: 0 = 128x128 / 4 waves, 1 = 64x64, 2 = 128x64, 3 = 128x32, 4 = 128x128 / 8 waves, 5 = 128x256 / 8 waves
   int variant = e->gemm_variant;
-  if (in_place) {
-    if (g.mt != 1) return fail(e, GMB_EINVAL, "internal: in-place GEMM needs m == 128");
-    variant = nact < 64 ? 3 : (nact < 128 ? 2 : 0);
-  } else if (nact < 192 && e->small_tiles) {
-    variant = 1;
-  } else if (variant == 5 && (g.nt % 2 || g.nblk_stride != 1 || g.tri)) {
-    variant = 0;
+  {
+    // Tile shape by a small model: a launch of T tiles on S workgroup slots (two per compute
+    // unit for every shape) takes max(1, T / S + 1/2) tile times -- full rounds plus an expected
+    // half round of tail -- and a tile time is tile flops / intrinsic rate.  Intrinsic rates
+    // measured on MI355X at 8192^3 (TF/s): 128x128 69, 64x64 62, 128x64 62, 128x32 60.  Measured
+    // launch by launch on the N = 10k fit (tools/gpu_variant_compare.py): always-128x128 61.7 ms,
+    // always-64x64 52.2 ms, best shape per launch 51.0 ms.
+    static const double rate[4] = {69.0, 60.0, 61.0, 59.0};
+    static const int per128[4] = {1, 4, 2, 4};  // tiles per 128 x 128 block
+    const double slots = (double)e->wg_slots;
+    auto score = [&](int v) {  // higher is better: 1 / predicted time
+      const double t = (double)(nact * per128[v]);
+      const double rounds = std::max(1.0, t / slots + 0.5);
+      return rate[v] * per128[v] / rounds;
+    };
+    if (in_place) {
+      if (g.mt != 1) return fail(e, GMB_EINVAL, "internal: in-place GEMM needs m == 128");
+      variant = 0;
+      if (score(2) > score(variant)) variant = 2;
+      if (score(3) > score(variant)) variant = 3;
+    } else if (e->force_variant) {
+      if (variant == 5 && (g.nt % 2 || g.nblk_stride != 1 || g.tri)) variant = 0;
+    } else {
+      variant = 0;
+      if (e->small_tiles) {
+        if (score(2) > score(variant)) variant = 2;
+        if (score(1) > score(variant)) variant = 1;
+      }
+    }
   }
   // 6 = 256 x 128 / 8 waves, 106 KB of LDS: ONE workgroup per compute unit by construction -- the
   // persistent bulk update, whose grid of (compute units - reserve_cus) workgroups then leaves
@@ -1047,7 +1071,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   const char* st = getenv("GMB_SMALL_TILES");  // tuning switch: 0 forces the 128 x 128 tiling
   e->small_tiles = !(st && st[0] == '0');
   const char* gv = getenv("GMB_GEMM_VARIANT");  // tuning: 0 = 128x128/4 waves, 4 = 128x128/8 waves, 5 = 128x256/8 waves
-  if (gv && (gv[0] == '4' || gv[0] == '5')) e->gemm_variant = gv[0] - '0';
+  if (gv && gv[0] >= '0' && gv[0] <= '5') e->gemm_variant = gv[0] - '0';
+  e->force_variant = gv != nullptr;
   const char* la = getenv("GMB_LOOKAHEAD");    // tuning switches for the multi-stream schedules
   e->lookahead = !(la && la[0] == '0');
   const char* pi = getenv("GMB_PAR_INVERSE");
@@ -1078,9 +1103,10 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
     const char* rs = getenv("GMB_RESERVE_CUS");  // tuning: 0 = ordinary (chip-filling) bulk launches
     if (rs) e->reserve_cus = atoi(rs);
     hipDeviceProp_t prop;
-    if (e->reserve_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      e->wg_slots = 2LL * prop.multiProcessorCount;
       const int wgs = prop.multiProcessorCount - e->reserve_cus;
-      e->persist_wgs = wgs >= 64 ? (wgs / 8) * 8 : 0;
+      e->persist_wgs = (e->reserve_cus > 0 && wgs >= 64) ? (wgs / 8) * 8 : 0;
     }
     if (hipMalloc((void**)&e->dsched, SCHED_RING * 8 * sizeof(int32_t)) != hipSuccess) {
       gmb_destroy(e);

@@ -16,8 +16,10 @@ def short(name):
 def main(db, max_rows=400):
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, end, queue_id, stream_id, grid_x, workgroup_x from kernels order by start").fetchall()
-    # last cov_tile launch marks the start of the last factorisation
-    last = max(i for i, r in enumerate(rows) if "cov_tile_kernel" in r[0])
+    # last cov_tile launch marks the start of the last factorisation; with a start marker in
+    # argv[3] (substring of a kernel name) the dump starts at that kernel's last-but-N occurrence
+    marker = sys.argv[3] if len(sys.argv) > 3 else "cov_tile_kernel"
+    last = max(i for i, r in enumerate(rows) if marker in r[0])
     rows = rows[last:]
     t0 = rows[0][1]
     tend = max(r[2] for r in rows)
