@@ -110,6 +110,24 @@ struct gmb_engine {
   double* dgpart = nullptr;
   int64_t cap_gpart = 0;
 
+  // cached launch plan of the batched levels of the triangular inverse (static per data set)
+  struct InvLevelPlan {
+    int variant[2] = {0, 0};     // tile shape of the T^T and W21 batches
+    int grid_x[2] = {0, 0};
+    int count = 0;               // nodes on this level
+    int64_t off[2] = {0, 0};     // first descriptor of each batch in dplan_gemm
+    int64_t toff = 0;            // first transpose job in dplan_tr
+    int tr_rows = 0, tr_cols = 0;  // largest transpose
+    double flops[2] = {0.0, 0.0};
+  };
+  std::vector<InvLevelPlan> inv_plan;  // indexed by depth; count == 0 -> level not batched
+  GemmArgs* dplan_gemm = nullptr;
+  TransposeJob* dplan_tr = nullptr;
+  int64_t plan_N = -1, plan_ld = -1, plan_Np = -1;
+  const double* plan_W = nullptr;
+  const double* plan_A = nullptr;
+  bool batch_inverse = true;
+
   // timing
   bool profiling = false;
   gmb_timings tm{};
@@ -269,6 +287,17 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
 // ---- kernel launch helpers ----------------------------------------------------------------
 // `g_in` describes the product in 128-tile units (mt, nt) and elements (k); pick the block tile so
 // that the launch fills the chip, convert, schedule and launch.
+long long gemm_nact128(const GemmArgs& g) {
+  long long nact = 0;
+  const int stride = g.nblk_stride < 1 ? 1 : g.nblk_stride;
+  for (int tm = 0; tm < g.mt; ++tm) {
+    int f = g.tri ? gemm_first_tn((int64_t)tm * TILE - g.tri_off - (TILE - 1), TILE, stride) : 0;
+    f = f > g.nt ? g.nt : f;
+    nact += g.nt - f;
+  }
+  return nact;
+}
+
 int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persistent = false) {
   if (g_in.mt <= 0 || g_in.nt <= 0 || g_in.k <= 0) return GMB_OK;
   GemmArgs g = g_in;
@@ -787,6 +816,9 @@ void collect_inv_nodes(int c0, int c1, int depth, std::vector<std::vector<InvNod
     collect_inv_nodes(mid, c1, depth + 1, levels);
   }
 }
+int build_inv_plan(gmb_engine* e, const std::vector<std::vector<InvNode>>& levels);
+int winv_level_batched(gmb_engine* e, const gmb_engine::InvLevelPlan& lp);
+
 int winv_levels(gmb_engine* e, int nt) {
   std::vector<std::vector<InvNode>> levels;
   collect_inv_nodes(0, nt, 0, levels);
@@ -794,7 +826,16 @@ int winv_levels(gmb_engine* e, int nt) {
   int rc;
   for (int a = 1; a < 4; ++a)
     if ((rc = order_after(e, streams[0], streams[a]))) return rc;
+  const bool batched = e->batch_inverse && build_inv_plan(e, levels) == GMB_OK;
   for (int depth = (int)levels.size() - 1; depth >= 0; --depth) {
+    if (batched && e->inv_plan[depth].count > 0) {
+      e->cur = e->stream;  // every stream was joined into the main one after the previous level
+      if ((rc = winv_level_batched(e, e->inv_plan[depth]))) return rc;
+      if (depth > 0)
+        for (int a = 1; a < 4; ++a)
+          if ((rc = order_after(e, streams[0], streams[a]))) return rc;
+      continue;
+    }
     int idx = 0;
     for (const InvNode& nd : levels[depth]) {
       e->cur = streams[levels[depth].size() > 1 ? (idx++ & 3) : 0];
@@ -813,10 +854,51 @@ int winv_levels(gmb_engine* e, int nt) {
   return GMB_OK;
 }
 
-int winv_node(gmb_engine* e, int c0, int c1, bool recurse) {
+// The two products and the transpose of one merge node [c0, c1) of the inverse tree.
+void winv_node_products(gmb_engine* e, int c0, int c1, GemmArgs& gt, GemmArgs& gw, TransposeJob& tr) {
   const int64_t ldw = e->Np, lda = e->ld;
   double* W = e->dW;
   double* A = e->dA;
+  const int mid = c0 + (c1 - c0 + 1) / 2;
+  const int n1 = mid - c0, n2 = c1 - mid;
+  // T^T[j][r] = sum_{k>=j} U_A[j][k] * B[r][k]   -> scratch at W[c0.., mid..]
+  gt = GemmArgs{};
+  gt.C = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;
+  gt.ldc = ldw;
+  gt.A = A + (int64_t)mid * TILE + (int64_t)c0 * TILE * lda;  // B = L21
+  gt.lda = lda;
+  gt.B = A + (int64_t)c0 * TILE + (int64_t)c0 * TILE * lda;   // U_A (upper triangle of the factor buffer)
+  gt.ldb = lda;
+  gt.mt = n2;
+  gt.nt = n1;
+  gt.k = n1 * TILE;
+  gt.klo_n = 1;
+  gt.alpha = 1.0;
+  gt.beta = 0.0;
+  gt.nblk_stride = 1;
+  // W21[r][j] = -sum_{s<=r} W_C[r][s] * T^T[j][s]
+  gw = GemmArgs{};
+  gw.C = W + (int64_t)mid * TILE + (int64_t)c0 * TILE * ldw;
+  gw.ldc = ldw;
+  gw.A = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;   // T^T
+  gw.lda = ldw;
+  gw.B = W + (int64_t)mid * TILE + (int64_t)mid * TILE * ldw;  // W_C
+  gw.ldb = ldw;
+  gw.mt = n1;
+  gw.nt = n2;
+  gw.k = n2 * TILE;
+  gw.khi_n = 1;
+  gw.alpha = -1.0;
+  gw.beta = 0.0;
+  gw.nblk_stride = 1;
+  // U12 = W21^T into the upper triangle of the factor buffer
+  tr.src = W + (int64_t)mid * TILE + (int64_t)c0 * TILE * ldw;
+  tr.dst = A + (int64_t)c0 * TILE + (int64_t)mid * TILE * lda;
+  tr.rows = n2 * TILE;
+  tr.cols = n1 * TILE;
+}
+
+int winv_node(gmb_engine* e, int c0, int c1, bool recurse) {
   if (c1 - c0 == 1) return GMB_OK;  // leaf_invert_kernel wrote both diagonal blocks already
   const int mid = c0 + (c1 - c0 + 1) / 2;
   int rc;
@@ -824,42 +906,111 @@ int winv_node(gmb_engine* e, int c0, int c1, bool recurse) {
     if ((rc = winv_node(e, c0, mid, true))) return rc;
     if ((rc = winv_node(e, mid, c1, true))) return rc;
   }
-  const int n1 = mid - c0, n2 = c1 - mid;
-  {  // T^T[j][r] = sum_{k>=j} U_A[j][k] * B[r][k]   -> scratch at W[c0.., mid..]
-    GemmArgs g{};
-    g.C = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;
-    g.ldc = ldw;
-    g.A = A + (int64_t)mid * TILE + (int64_t)c0 * TILE * lda;  // B = L21
-    g.lda = lda;
-    g.B = A + (int64_t)c0 * TILE + (int64_t)c0 * TILE * lda;   // U_A (upper triangle of the factor buffer)
-    g.ldb = lda;
-    g.mt = n2;
-    g.nt = n1;
-    g.k = n1 * TILE;
-    g.klo_n = 1;
-    g.alpha = 1.0;
-    g.beta = 0.0;
-    if ((rc = launch_gemm(e, g, 4))) return rc;
+  GemmArgs gt, gw;
+  TransposeJob tr;
+  winv_node_products(e, c0, c1, gt, gw, tr);
+  if ((rc = launch_gemm(e, gt, 4))) return rc;
+  if ((rc = launch_gemm(e, gw, 4))) return rc;
+  return launch_transpose(e, tr.src, e->Np, tr.dst, e->ld, tr.rows, tr.cols);
+}
+
+// ---- batched levels ---------------------------------------------------------------------------
+// Levels of the tree with at least MIN_BATCH_NODES merge nodes run as three launches (all T^T
+// products, all W21 products, all transposes) whose descriptors are built once per data set.
+constexpr int MIN_BATCH_NODES = 4;
+
+int build_inv_plan(gmb_engine* e, const std::vector<std::vector<InvNode>>& levels) {
+  if (e->plan_N == e->N && e->plan_ld == e->ld && e->plan_Np == e->Np && e->plan_W == e->dW && e->plan_A == e->dA)
+    return GMB_OK;
+  std::vector<GemmArgs> hg;
+  std::vector<TransposeJob> ht;
+  e->inv_plan.assign(levels.size(), gmb_engine::InvLevelPlan{});
+  static const int BMs[3] = {128, 64, 128}, BNs[3] = {128, 64, 64};
+  static const double rate[3] = {69.0, 60.0, 61.0};
+  static const int per128[3] = {1, 4, 2};
+  for (size_t depth = 0; depth < levels.size(); ++depth) {
+    std::vector<InvNode> nodes;
+    for (const InvNode& nd : levels[depth])
+      if (nd.c1 - nd.c0 > 1) nodes.push_back(nd);
+    if ((int)nodes.size() < MIN_BATCH_NODES) continue;
+    gmb_engine::InvLevelPlan& lp = e->inv_plan[depth];
+    lp.count = (int)nodes.size();
+    std::vector<GemmArgs> gs[2];
+    lp.toff = (int64_t)ht.size();
+    for (const InvNode& nd : nodes) {
+      GemmArgs gt, gw;
+      TransposeJob tr;
+      winv_node_products(e, nd.c0, nd.c1, gt, gw, tr);
+      gs[0].push_back(gt);
+      gs[1].push_back(gw);
+      ht.push_back(tr);
+      lp.tr_rows = std::max(lp.tr_rows, tr.rows);
+      lp.tr_cols = std::max(lp.tr_cols, tr.cols);
+    }
+    for (int b = 0; b < 2; ++b) {
+      long long nact = 0;
+      for (const GemmArgs& g : gs[b]) nact += gemm_nact128(g);
+      int variant = 0;
+      double best = 0.0;
+      for (int v = 0; v < 3; ++v) {  // the launch_gemm model on the level's total tile count
+        const double t = (double)(nact * per128[v]);
+        const double sc = rate[v] * per128[v] / std::max(1.0, t / (double)e->wg_slots + 0.5);
+        if (sc > best) {
+          best = sc;
+          variant = v;
+        }
+      }
+      lp.variant[b] = variant;
+      lp.off[b] = (int64_t)hg.size();
+      for (GemmArgs g : gs[b]) {
+        g.mt = g.mt * TILE / BMs[variant];
+        g.nt = g.nt * TILE / BNs[variant];
+        double fl = 0.0;
+        const int nb = gemm_schedule(g, BMs[variant], BNs[variant], &fl);
+        g.sched = nullptr;
+        lp.grid_x[b] = std::max(lp.grid_x[b], nb);
+        lp.flops[b] += fl;
+        hg.push_back(g);
+      }
+    }
   }
-  {  // W21[r][j] = -sum_{s<=r} W_C[r][s] * T^T[j][s]
-    GemmArgs g{};
-    g.C = W + (int64_t)mid * TILE + (int64_t)c0 * TILE * ldw;
-    g.ldc = ldw;
-    g.A = W + (int64_t)c0 * TILE + (int64_t)mid * TILE * ldw;   // T^T
-    g.lda = ldw;
-    g.B = W + (int64_t)mid * TILE + (int64_t)mid * TILE * ldw;  // W_C
-    g.ldb = ldw;
-    g.mt = n1;
-    g.nt = n2;
-    g.k = n2 * TILE;
-    g.khi_n = 1;
-    g.alpha = -1.0;
-    g.beta = 0.0;
-    if ((rc = launch_gemm(e, g, 4))) return rc;
+  if (e->dplan_gemm) (void)hipFree(e->dplan_gemm);
+  if (e->dplan_tr) (void)hipFree(e->dplan_tr);
+  e->dplan_gemm = nullptr;
+  e->dplan_tr = nullptr;
+  e->plan_N = -1;
+  if (!hg.empty()) {
+    HIP_TRY(e, hipMalloc((void**)&e->dplan_gemm, hg.size() * sizeof(GemmArgs)));
+    HIP_TRY(e, hipMalloc((void**)&e->dplan_tr, ht.size() * sizeof(TransposeJob)));
+    HIP_TRY(e, hipMemcpy(e->dplan_gemm, hg.data(), hg.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->dplan_tr, ht.data(), ht.size() * sizeof(TransposeJob), hipMemcpyHostToDevice));
   }
-  // U12 = W21^T into the upper triangle of the factor buffer
-  return launch_transpose(e, W + (int64_t)mid * TILE + (int64_t)c0 * TILE * ldw, ldw,
-                          A + (int64_t)c0 * TILE + (int64_t)mid * TILE * lda, lda, n2 * TILE, n1 * TILE);
+  e->plan_N = e->N;
+  e->plan_ld = e->ld;
+  e->plan_Np = e->Np;
+  e->plan_W = e->dW;
+  e->plan_A = e->dA;
+  return GMB_OK;
+}
+
+int winv_level_batched(gmb_engine* e, const gmb_engine::InvLevelPlan& lp) {
+  for (int b = 0; b < 2; ++b) {
+    if (lp.grid_x[b] <= 0) continue;
+    const GemmArgs* batch = e->dplan_gemm + lp.off[b];
+    const dim3 grid(lp.grid_x[b], lp.count);
+    ev_begin(e, 4, lp.flops[b], lp.count, 0, 0, (lp.variant[b] << 8) | 64);
+    switch (lp.variant[b]) {
+      case 0: hipLaunchKernelGGL((gemm_f64_batched_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, batch); break;
+      case 1: hipLaunchKernelGGL((gemm_f64_batched_kernel<2, 2, 2, 2, 2>), grid, dim3(256), 0, e->cur, batch); break;
+      default: hipLaunchKernelGGL((gemm_f64_batched_kernel<2, 2, 4, 2, 2>), grid, dim3(256), 0, e->cur, batch); break;
+    }
+    ev_end(e);
+    HIP_TRY(e, hipGetLastError());
+  }
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((lp.tr_rows + 31) / 32, (lp.tr_cols + 31) / 32, lp.count),
+                     dim3(256), 0, e->cur, e->dplan_tr + lp.toff, e->Np, e->ld);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
 }
 
 template <int KIND>
@@ -1075,6 +1226,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   e->force_variant = gv != nullptr;
   const char* la = getenv("GMB_LOOKAHEAD");    // tuning switches for the multi-stream schedules
   e->lookahead = !(la && la[0] == '0');
+  const char* bi = getenv("GMB_BATCH_INVERSE");  // tuning: 0 = one launch per node on four streams
+  e->batch_inverse = !(bi && bi[0] == '0');
   const char* pi = getenv("GMB_PAR_INVERSE");
   e->par_inverse = !(pi && pi[0] == '0');
   const char* pb = getenv("GMB_PANEL_BLOCKS");
@@ -1126,7 +1279,7 @@ void gmb_destroy(gmb_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->dsched, e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
+  void* ptrs[] = {e->dplan_gemm, e->dplan_tr, e->dsched, e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv,  e->dV,    e->dXs,  e->txs,    e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
   for (void* p : ptrs)

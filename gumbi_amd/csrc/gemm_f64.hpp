@@ -99,8 +99,8 @@ __host__ __device__ __forceinline__ int gemm_first_tn(int64_t T, int bn, int str
 // then keeps its 128 accumulator registers + staging in 207 VGPRs (no AGPRs, no spills) and the
 // second workgroup's MFMAs fill the first one's barrier / staging bubbles: 39 -> 52 TF/s on the
 // whole N = 30k Cholesky, 44 -> 59 TF/s on the predict GEMMs (measured A/B on MI355X).
-template <int WGM, int WGN, int WTM, int WTN, int OCC, bool PERSIST = false>
-__global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs g) {
+template <int WGM, int WGN, int WTM, int WTN, bool PERSIST>
+__device__ __forceinline__ void gemm_f64_body(const GemmArgs& g) {
   constexpr int NT = 64 * WGM * WGN;                      // threads: WGM x WGN waves
   constexpr int BM = 16 * WTM * WGM, BN = 16 * WTN * WGN; // block tile; wave tile 16*WTM x 16*WTN
   constexpr int PA = BM + 16, PB = BN + 16;     // LDS pitches, % 32 == 16 -> conflict-free ds_read_b64
@@ -241,6 +241,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs 
       }
   }
   }  // persistent tile loop
+}
+
+template <int WGM, int WGN, int WTM, int WTN, int OCC, bool PERSIST = false>
+__global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs g) {
+  gemm_f64_body<WGM, WGN, WTM, WTN, PERSIST>(g);
+}
+
+// Batched form: blockIdx.y selects one of several INDEPENDENT products whose descriptors sit in
+// device memory (each with its own schedule; surplus blocks of the shorter ones exit at once).
+// One launch per level of the triangular-inverse tree instead of one per node: at N = 10k the
+// per-node launches of the small levels cost 1.8 ms of a 15.6 ms gradient in launch latency alone.
+template <int WGM, int WGN, int WTM, int WTN, int OCC>
+__global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_batched_kernel(const GemmArgs* __restrict__ batch) {
+  const GemmArgs g = batch[blockIdx.y];  // uniform address, read before any store: scalar loads
+  gemm_f64_body<WGM, WGN, WTM, WTN, false>(g);
 }
 
 // MFMA-only microbenchmark: the GEMM's own register pattern (4 x 4 independent accumulators fed

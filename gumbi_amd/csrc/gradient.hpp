@@ -239,6 +239,26 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
     if (c0 + tx < cols && r0 + j < rows) dst[(c0 + tx) + (int64_t)(r0 + j) * ldd] = tile[tx][j];
 }
 
+// Batched transposes (one level of the inverse tree): blockIdx.z selects the descriptor.
+struct TransposeJob {
+  const double* src;
+  double* dst;
+  int32_t rows, cols;
+};
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const TransposeJob* __restrict__ jobs, int64_t lds_,
+                                                                int64_t ldd) {
+  __shared__ double tile[32][33];
+  const TransposeJob jb = jobs[blockIdx.z];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  if (r0 >= jb.rows || c0 >= jb.cols) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + tx < jb.rows && c0 + j < jb.cols) tile[j][tx] = jb.src[(r0 + tx) + (int64_t)(c0 + j) * lds_];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + tx < jb.cols && r0 + j < jb.rows) jb.dst[(c0 + tx) + (int64_t)(r0 + j) * ldd] = tile[tx][j];
+}
+
 // U = L^-T lives in the upper triangle of the factor buffer; its padding COLUMNS [n, npad) pick up
 // the y row's pollution through the transposes -- reset them to identity.
 __global__ void reset_pad_cols_kernel(double* U, int64_t ld, int64_t n, int64_t npad) {
