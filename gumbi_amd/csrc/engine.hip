@@ -127,6 +127,7 @@ struct gmb_engine {
   const double* plan_W = nullptr;
   const double* plan_A = nullptr;
   bool batch_inverse = true;
+  bool lpt_order = true;
 
   // timing
   bool profiling = false;
@@ -352,6 +353,10 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
   const int bm = BMs[variant], bn = BNs[variant];
   g.mt = g_in.mt * TILE / bm;
   g.nt = g_in.nt * TILE / bn;
+  // triangular operand: dispatch the longest contractions first (see GemmArgs::order)
+  g.order = 0;
+  if (e->lpt_order && !persist && g.nblk_stride == 1 && g.tri_off >= 0 && !g.klo_m && (g.klo_n != 0) != (g.khi_n != 0))
+    g.order = g.klo_n ? 1 : 2;
   double flops = 0.0;
   const int nblocks = gemm_schedule(g, bm, bn, &flops);
   if (nblocks <= 0) return GMB_OK;
@@ -1226,6 +1231,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   e->force_variant = gv != nullptr;
   const char* la = getenv("GMB_LOOKAHEAD");    // tuning switches for the multi-stream schedules
   e->lookahead = !(la && la[0] == '0');
+  const char* lo = getenv("GMB_LPT_ORDER");  // tuning: 0 = XCD-run order for every launch
+  e->lpt_order = !(lo && lo[0] == '0');
   const char* bi = getenv("GMB_BATCH_INVERSE");  // tuning: 0 = one launch per node on four streams
   e->batch_inverse = !(bi && bi[0] == '0');
   const char* pi = getenv("GMB_PAR_INVERSE");

@@ -26,6 +26,7 @@
 // k-tile ahead of the MFMAs (register-staged double buffer, one barrier per k-tile).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 namespace gmb {
@@ -61,6 +62,13 @@ struct GemmArgs {
   // XCD-balanced schedule (filled by gemm_schedule): the computed tiles, enumerated row-major
   // (tm outer, tn inner), are cut into 8 contiguous runs of equal WORK; block b serves run b % 8.
   int32_t xstart[9];
+  // Tile order.  0: the XCD runs above.  1 / 2: block b computes tile b of the list enumerated
+  // n-tile by n-tile (1: tn ascending, 2: tn descending; tm inner).  With a triangular OPERAND the
+  // contraction length depends on tn only (klo_n: longest at tn = 0, khi_n: longest at the last
+  // tn), so these orders dispatch the longest tiles first: a full-k tile of the N = 10k inverse
+  // runs 1.1 ms of a 2.8 ms launch and must not start late.  Consecutive blocks land on
+  // consecutive XCDs, which deals every length class evenly over the 8 XCDs.
+  int32_t order;
   // Persistent mode (sched != nullptr): the grid is SMALLER than the tile list and every workgroup
   // keeps drawing the next tile of its XCD's run from sched[xcd] (8 zero-initialised counters)
   // until the run is exhausted.  The launch then occupies exactly gridDim.x workgroup slots for
@@ -125,22 +133,43 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g) {
       if (round) return;
       ci = g.xstart[xcd] + (blockIdx.x >> 3);
     }
-    if (ci >= g.xstart[xcd + 1]) return;
-    if (!g.tri) {
-      tm = ci / g.nt;
-      tn = ci - tm * g.nt;
+    if (g.order == 0) {
+      if (ci >= g.xstart[xcd + 1]) return;
+      if (!g.tri) {
+        tm = ci / g.nt;
+        tn = ci - tm * g.nt;
+      } else {
+        tm = 0;
+        for (;;) {
+          int first = gemm_first_tn((int64_t)tm * BM - g.tri_off - (BN - 1), BN, g.nblk_stride);
+          first = first > g.nt ? g.nt : first;
+          const int cnt = g.nt - first;
+          if (ci < cnt) {
+            tn = first + ci;
+            break;
+          }
+          ci -= cnt;
+          ++tm;
+        }
+      }
     } else {
-      tm = 0;
+      // n-major list (nblk_stride == 1): n-tile tn holds the m-tiles [0, cnt(tn))
+      ci = blockIdx.x;
+      const int step = g.order == 1 ? 1 : -1;
+      tn = g.order == 1 ? 0 : g.nt - 1;
       for (;;) {
-        int first = gemm_first_tn((int64_t)tm * BM - g.tri_off - (BN - 1), BN, g.nblk_stride);
-        first = first > g.nt ? g.nt : first;
-        const int cnt = g.nt - first;
+        if (tn < 0 || tn >= g.nt) return;
+        int cnt = g.mt;
+        if (g.tri) {
+          const int lim = (tn * BN + BN - 1 + g.tri_off) / BM + 1;
+          cnt = lim < cnt ? lim : cnt;
+        }
         if (ci < cnt) {
-          tn = first + ci;
+          tm = ci;
           break;
         }
         ci -= cnt;
-        ++tm;
+        tn += step;
       }
     }
   }
@@ -308,6 +337,18 @@ inline int gemm_schedule(GemmArgs& g, int bm, int bn, double* flops) {
     if (g.khi_n && (tn + 1) * bn / KT < hi) hi = (tn + 1) * bn / KT;
     return hi > lo ? hi - lo : 0;
   };
+  if (g.order != 0) {  // n-major list in dispatch order: no XCD runs, grid = number of tiles
+    long long nact = 0, funits = 0;
+    for (int tn = 0; tn < g.nt; ++tn) {
+      long long cnt = g.mt;
+      if (g.tri) cnt = std::min<long long>(cnt, ((long long)tn * bn + bn - 1 + g.tri_off) / bm + 1);
+      nact += cnt;
+      funits += cnt * kunits(0, tn);
+    }
+    if (flops) *flops = 2.0 * bm * bn * KT * (double)funits;
+    for (int i = 0; i <= 8; ++i) g.xstart[i] = 0;
+    return (int)nact;
+  }
   static thread_local long long* P = nullptr;
   static thread_local long long* F = nullptr;
   static thread_local int cap = 0;
