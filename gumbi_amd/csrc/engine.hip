@@ -970,6 +970,7 @@ int build_inv_plan(gmb_engine* e, const std::vector<std::vector<InvNode>>& level
       for (GemmArgs g : gs[b]) {
         g.mt = g.mt * TILE / BMs[variant];
         g.nt = g.nt * TILE / BNs[variant];
+        g.order = e->lpt_order ? (b == 0 ? 1 : 2) : 0;
         double fl = 0.0;
         const int nb = gemm_schedule(g, BMs[variant], BNs[variant], &fl);
         g.sched = nullptr;
