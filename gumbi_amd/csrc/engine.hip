@@ -128,6 +128,7 @@ struct gmb_engine {
   const double* plan_A = nullptr;
   bool batch_inverse = true;
   bool lpt_order = true;
+  int bulk_variant = -1;  // tuning: tile shape of the bulk trailing updates that run beside the panel chain
 
   // timing
   bool profiling = false;
@@ -346,6 +347,7 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
   // 6 = 256 x 128 / 8 waves, 106 KB of LDS: ONE workgroup per compute unit by construction -- the
   // persistent bulk update, whose grid of (compute units - reserve_cus) workgroups then leaves
   // whole compute units to the concurrent chain (a leaf sharing its unit with GEMM waves ran 4x slower)
+  if (persistent && !in_place && e->bulk_variant >= 0) variant = e->bulk_variant;
   const bool persist = persistent && e->persist_wgs > 0 && !in_place && g_in.mt % 2 == 0 &&
                        e->sched_next < SCHED_RING;
   if (persist) variant = 6;
@@ -679,6 +681,51 @@ int chol_lookahead_full(gmb_engine* e) {
   }
   e->cur = mainS;
   return GMB_OK;
+}
+
+// Full-height chain on the MAIN stream, U2 on the CU-masked stream (scheme 2).
+int chol_lookahead_masked(gmb_engine* e) {
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  const int w = e->panel_blocks;
+  hipStream_t mainS = e->stream, bulkS = e->aux[2];
+  e->sync_next = 0;
+  e->sched_next = 0;
+  HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
+  int rc;
+  e->cur = mainS;
+  if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
+  for (int c0 = 0; c0 < nct; c0 += w) {
+    const int c1 = std::min(c0 + w, nct);
+    const int n0 = c1, n1 = std::min(c1 + w, nct);
+    if (n0 >= nct) break;
+    auto update = [&](int col_lo, int col_hi, bool bulk = false) {
+      GemmArgs g{};
+      g.C = e->dA + (int64_t)col_lo * TILE + (int64_t)col_lo * TILE * e->ld;
+      g.ldc = e->ld;
+      g.A = e->dA + (int64_t)col_lo * TILE + (int64_t)c0 * TILE * e->ld;
+      g.lda = e->ld;
+      g.B = g.A;
+      g.ldb = e->ld;
+      g.mt = col_hi - col_lo;
+      g.nt = nrt - col_lo;
+      g.k = (c1 - c0) * TILE;
+      g.alpha = -1.0;
+      g.beta = 1.0;
+      g.tri = 1;
+      return launch_gemm(e, g, 0, bulk);
+    };
+    e->cur = mainS;
+    if ((rc = order_after(e, bulkS, mainS))) return rc;   // U2(p-1) reached these columns
+    if ((rc = update(n0, n1))) return rc;                 // U1
+    if ((rc = order_after(e, mainS, bulkS))) return rc;
+    e->cur = bulkS;
+    rc = (n1 < nct) ? update(n1, nct, true) : 0;          // U2, on the compute units its mask allows
+    e->cur = mainS;
+    if (rc) return rc;
+    if ((rc = chol_cols(e, n0, n1, nrt))) return rc;      // panel p+1, beside U2
+  }
+  e->cur = mainS;
+  return order_after(e, bulkS, mainS);
 }
 
 
@@ -1232,6 +1279,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   e->force_variant = gv != nullptr;
   const char* la = getenv("GMB_LOOKAHEAD");    // tuning switches for the multi-stream schedules
   e->lookahead = !(la && la[0] == '0');
+  const char* bv = getenv("GMB_BULK_VARIANT");
+  if (bv && bv[0] >= '0' && bv[0] <= '3') e->bulk_variant = bv[0] - '0';
   const char* lo = getenv("GMB_LPT_ORDER");  // tuning: 0 = XCD-run order for every launch
   e->lpt_order = !(lo && lo[0] == '0');
   const char* bi = getenv("GMB_BATCH_INVERSE");  // tuning: 0 = one launch per node on four streams
@@ -1250,9 +1299,22 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   const char* ap = getenv("GMB_AUX_PRIORITY");
   const bool use_prio = !(ap && ap[0] == '0');
+  const char* mk = getenv("GMB_MASK_CUS");  // tuning: compute units (multiple of 8) the bulk stream leaves free
+  const int mask_cus = mk ? atoi(mk) : 0;
   for (int a = 0; a < 3; ++a) {
-    hipError_t st2 = use_prio ? hipStreamCreateWithPriority(&e->aux[a], hipStreamNonBlocking, a == 2 ? prio_lo : prio_hi)
-                              : hipStreamCreateWithFlags(&e->aux[a], hipStreamNonBlocking);
+    hipError_t st2;
+    hipDeviceProp_t prop;
+    if (a == 2 && mask_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      // mask bit i addresses XCD i % 8 (then shader engine, then CU): clearing the first mask_cus
+      // bits takes mask_cus / 8 compute units from every XCD
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int i = 0; i < ncu; ++i)
+        if (i >= mask_cus) mask[i / 32] |= 1u << (i % 32);
+      st2 = hipExtStreamCreateWithCUMask(&e->aux[a], (uint32_t)mask.size(), mask.data());
+    } else
+    st2 = use_prio ? hipStreamCreateWithPriority(&e->aux[a], hipStreamNonBlocking, a == 2 ? prio_lo : prio_hi)
+                   : hipStreamCreateWithFlags(&e->aux[a], hipStreamNonBlocking);
     if (st2 != hipSuccess) {
       gmb_destroy(e);
       return GMB_EHIP;
@@ -1439,7 +1501,7 @@ int gmb_factorize(gmb_engine* e) {
   // 2. Cholesky
   PhaseTimer tc(e);
   if (e->lookahead && e->Np / TILE > e->panel_blocks) {
-    if ((rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : chol_lookahead(e)))) return rc;
+    if ((rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : (e->chol_scheme == 2 ? chol_lookahead_masked(e) : chol_lookahead(e))))) return rc;
   } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) {
     return rc;
   }
