@@ -1,24 +1,30 @@
 // potrf_leaf.hpp -- diagonal-block leaf of the blocked Cholesky: factor one 128 x 128 block in
-// LDS and produce the inverse of its triangular factor, so that every panel / predict
-// triangular solve against this block becomes a plain MFMA GEMM (gemm_f64.hpp).
+// LDS and produce the inverses of its eight 16 x 16 diagonal sub-blocks, the only "inverse" the
+// strip solves (trsm_strip.hpp) need; plus the batched inversion of whole diagonal blocks that
+// the hyper-parameter gradient uses as the leaves of L^-1.
 //
 // Replaces the unblocked dpotf2 + dtrtri work LAPACK does inside dpotrf / dtrsm for
 // pm.gp.Marginal (call sites gumbi/regression/pymc/GP.py:580, 845-847).
 //
-// One workgroup of 256 threads (4 waves) owns the block.  The block lives column-major in LDS
-// (pitch 130 doubles).  Factorisation is right-looking over 16-column sub-panels:
-//   1. wave 0 factors the 16 x 16 diagonal sub-block in registers (row per lane, pivots and
-//      multipliers moved with v_readlane -- no LDS round trips on the dependent chain);
-//   2. waves 1-3 solve the sub-panel rows by forward substitution (row per thread, the 16 x 16
-//      factor is read with LDS broadcasts);
-//   3. all waves apply the rank-16 update with v_mfma_f64_16x16x4_f64, one 16 x 16 tile per
-//      wave at a time, operands read straight from the column-major block.
+// potrf_leaf_kernel: one workgroup of 256 threads (4 waves) owns the block.  Its lower block
+// triangle lives column-major in LDS in a packed layout (block column s keeps rows 16 s .. 127,
+// 76 KB).  Factorisation is right-looking over 16-column sub-panels:
+//   1. wave 0 factors the 16 x 16 diagonal sub-block on the matrix pipe (factor_diag16_mfma: the
+//      symmetric block sits in one accumulator quad that doubles as a 16 x 4 panel operand; per
+//      4-column step ten v_readlane, a 4 x 4 factor + inverse in uniform arithmetic, four lane
+//      gathers and one rank-4 MFMA) and forms its inverse by forward substitution on the identity;
+//   2. all waves solve the sub-panel rows, P <- P X_ss^T, one 16 x 16 MFMA tile at a time;
+//   3. all waves apply the rank-16 update (MFMA tiles); wave 0 takes the next diagonal tile first
+//      and factors it straight away (one-step look-ahead), the others also write the finished
+//      block column back to global memory.
 // Rows >= nvalid of the block are "panel rows" (the appended y row that carries v = L^-1 y, and
 // zero padding): they are solved but never used as pivots; columns >= nvalid are treated as
 // identity and never written back.
-// Inversion: X = L^-1 by 16 x 16 blocks, block-diagonal by block-diagonal,
-//   X_ij = -X_ii * (sum_{k=j..i-1} L_ik X_kj), both products on MFMA.  X is kept transposed in
-// the (free) upper triangle of the LDS block, X_ii additionally as dense 16 x 16 tiles.
+//
+// leaf_invert_kernel: X = L^-1 by 16 x 16 blocks, block-diagonal by block-diagonal,
+//   X_ij = -X_ii * (sum_{k=j..i-1} L_ik X_kj), both products on MFMA; X is kept transposed in the
+// (free) upper triangle of the full LDS square while it is built.  One workgroup per diagonal
+// block, all blocks in one launch, off the factorisation's critical path.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
