@@ -95,6 +95,28 @@ def step_flops(N, M, n_eval):
     return n_eval * n3 + n3 / 3.0 + float(N) ** 2 * M + 4.0 * N * M
 
 
+def pmc_traffic(config):
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC summary of this same bench command
+    (profiles/*_pmc_bench_<config>_summary.csv, made by tools/gpu_pmc_bench.sh: separate --pmc
+    passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950, WRITE_SIZE as counted).  None when no summary is committed."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(str(ROOT), "profiles", f"*_pmc_bench_{config}_summary.csv")))
+    if not files:
+        return None
+    launches, gbytes = 0, 0.0
+    with open(files[-1]) as fh:
+        for row in csv.DictReader(fh):
+            if "gemm_f64" in row["Kernel"]:
+                launches += int(row["Launches"])
+                gbytes += float(row["FetchGB(x2 corrected)"]) + float(row["WriteGB(raw)"])
+    if launches == 0:
+        return None
+    return {"bytes_per_launch": gbytes * 1e9 / launches, "source": os.path.relpath(files[-1], str(ROOT)), "launches": launches}
+
+
 def cpu_baseline(cfg, target_seconds=20.0):
     """Oracle (numpy + LAPACK through scipy) timed on a bounded sample of the same workload:
     one MAP objective+gradient evaluation and one grid prediction at a reduced N chosen (from a
@@ -113,11 +135,17 @@ def cpu_baseline(cfg, target_seconds=20.0):
         O.predict(spec, theta, X, y, Xs, with_noise=True)
         return time.perf_counter() - t0
 
-    probe_n = min(cfg["N"], 1500)
-    t_probe = run(probe_n)
-    Ns = int(min(cfg["N"], max(probe_n, probe_n * (target_seconds / max(t_probe, 1e-3)) ** (1.0 / 3.0))))
-    Ns = max(128, Ns // 128 * 128) if Ns < cfg["N"] else cfg["N"]
-    dt = run(Ns) if Ns != probe_n else t_probe
+    # grow the sample (cost ~ N^3, but BLAS efficiency also grows with N, so re-scale from each
+    # measurement) until one evaluation takes >= 10 s or the full N is reached
+    Ns = min(cfg["N"], 1500)
+    dt = run(Ns)
+    for _ in range(3):
+        if dt >= 10.0 or Ns >= cfg["N"]:
+            break
+        nxt = int(Ns * (target_seconds / max(dt, 1e-3)) ** (1.0 / 3.0))
+        nxt = min(cfg["N"], max(Ns + 128, nxt // 128 * 128))
+        Ns = nxt
+        dt = run(Ns)
     flops = step_flops(Ns, len(Xs), 1)
     cores = os.cpu_count() or 1
     try:
@@ -331,6 +359,11 @@ def main():
             },
             "results_finite": finite,
         }
+        pt = pmc_traffic(args.config)
+        if pt is not None:
+            out["roofline"]["traffic"] = round(pt["bytes_per_launch"], 1)
+            out["roofline"]["traffic_unit"] = "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = pt["source"]
         try:
             tf, cyc = engine.mfma_f64_peak(local_rank)
             out["roofline"]["mfma_only_microbench_tflops"] = round(tf, 2)  # sustained ceiling under DVFS
@@ -338,7 +371,7 @@ def main():
             pass
         if dist_info is not None:
             out["distributed"] = dist_info
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and os.environ.get("GUMBI_BENCH_NO_CPU") != "1":
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out, ensure_ascii=False))
     if dist is not None:
