@@ -151,6 +151,7 @@ struct gmb_engine {
   int reserve_cus = 0;  // off by default: no gain measured at N = 10k, a loss at N = 30k
   int chol_scheme = 0;  // 0 = full-height panel chain on the aux stream, 1 = square chain + bulk row solve
   int persist_wgs = 0;
+  int reserve_slots = 0;  // tuning: half-CU slots a persistent 128x128 bulk grid leaves free (GMB_RESERVE_SLOTS)
   int32_t* dsched = nullptr;
   int sched_next = 0;
   std::vector<hipEvent_t> sync_pool;
@@ -351,6 +352,10 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
   const bool persist = persistent && e->persist_wgs > 0 && !in_place && g_in.mt % 2 == 0 &&
                        e->sched_next < SCHED_RING;
   if (persist) variant = 6;
+  // alternative: the ordinary 128 x 128 / two-per-CU kernel as a persistent grid that leaves
+  // `reserve_slots` workgroup slots free (the chain kernels then share compute units with it)
+  const bool persist_half = !persist && persistent && e->reserve_slots > 0 && !in_place && variant == 0 &&
+                            e->sched_next < SCHED_RING;
   static const int BMs[7] = {128, 64, 128, 128, 128, 128, 256}, BNs[7] = {128, 64, 64, 32, 128, 256, 128};
   const int bm = BMs[variant], bn = BNs[variant];
   g.mt = g_in.mt * TILE / bm;
@@ -369,6 +374,10 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
   if (persist) {
     g.sched = e->dsched + 8 * (e->sched_next++);
     nlaunch = std::min(nblocks, e->persist_wgs);
+  } else if (persist_half && nblocks > (int)e->wg_slots - e->reserve_slots) {
+    g.sched = e->dsched + 8 * (e->sched_next++);
+    nlaunch = (((int)e->wg_slots - e->reserve_slots) / 8) * 8;
+    variant = 7;
   }
   const dim3 grid(nlaunch);
   switch (variant) {
@@ -378,6 +387,7 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
     case 3: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2>), grid, dim3(256), 0, e->cur, g); break;
     case 4: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 2, 4>), grid, dim3(512), 0, e->cur, g); break;
     case 6: hipLaunchKernelGGL((gemm_f64_kernel<4, 2, 4, 4, 2, true>), grid, dim3(512), 0, e->cur, g); break;
+    case 7: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2, true>), grid, dim3(256), 0, e->cur, g); break;
     default: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 4, 2>), grid, dim3(512), 0, e->cur, g); break;
   }
   ev_end(e);
@@ -1325,6 +1335,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
     if (cs) e->chol_scheme = atoi(cs);
     const char* rs = getenv("GMB_RESERVE_CUS");  // tuning: 0 = ordinary (chip-filling) bulk launches
     if (rs) e->reserve_cus = atoi(rs);
+    const char* rsl = getenv("GMB_RESERVE_SLOTS");
+    if (rsl) e->reserve_slots = atoi(rsl);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
       e->wg_slots = 2LL * prop.multiProcessorCount;

@@ -36,6 +36,7 @@ struct TrsmArgs {
 
 __global__ __launch_bounds__(256) void trsm_strip_kernel(TrsmArgs g) {
   typedef double d4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_s_setprio(3);  // part of the latency-bound chain: go first on a shared compute unit
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
