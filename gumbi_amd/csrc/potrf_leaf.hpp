@@ -83,18 +83,22 @@ struct LeafArgs {
 
 #define LEAF_STAMP(i) do { if (g.dbg && threadIdx.x == 0) g.dbg[i] = (double)wall_clock64(); } while (0)
 
-// sqrt(p) and 1/sqrt(p) from the hardware rsq estimate + two Newton steps and one residual
-// correction (the dependent chain is ~10 FMAs instead of a full sqrt followed by a division)
+// sqrt(p) and 1/sqrt(p) from the hardware rsq estimate (~26 bits) by one coupled (Goldschmidt)
+// step on g ~ sqrt(p), h ~ 1/(2 sqrt(p)) and one residual correction of each.  The pivot chain of
+// the factorisation waits for 1/sqrt(p): five dependent FMAs after v_rsq_f64 (each costs ~20
+// cycles of latency on this chain; three plain Newton steps were nine).
 __device__ __forceinline__ void sqrt_rsqrt(double p, double& l, double& rl) {
-  double y = __builtin_amdgcn_rsq(p);
-  const double h = 0.5 * p;
-  y = y * fma(-h * y, y, 1.5);
-  y = y * fma(-h * y, y, 1.5);
-  double s = p * y;
-  s = fma(0.5 * y, fma(-s, s, p), s);
-  y = y * fma(-h * y, y, 1.5);
-  l = s;
-  rl = y;
+  const double y = __builtin_amdgcn_rsq(p);
+  double g = p * y;
+  double h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, p);   // residual of the square root
+  const double r2 = fma(-h, g, 0.5);  // residual of the half reciprocal
+  const double hh = h + h;
+  l = fma(d, h, g);
+  rl = fma(hh, r2, hh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -124,17 +128,13 @@ __device__ __forceinline__ double rl_sgpr(double v, int lane_const) {
 // `Sd` / `pitch`: the block column that holds the sub-block (its first row is the sub-block's
 // first row, see the packed layout below).
 // `gdinv` (may be null): global copy of the dense inverse, for the solves of later kernels.
+#define D16_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (double)__builtin_readcyclecounter(); } while (0)
 __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double* dinv_s, double* gdinv,
-                                                   double* rdiag, int c0, int nv, int32_t* info, int64_t row0) {
+                                                   double* rdiag, int c0, int nv, int32_t* info, int64_t row0,
+                                                   double* dbg = nullptr) {
+  D16_STAMP(0);
   const int lane = threadIdx.x & 63;
   const int r16 = lane & 15, kq = lane >> 4;
-  // gather indices (bytes): lane 16 k' + r16, opaque so the compiler keeps them as bpermutes
-  int gidx[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    gidx[k] = (16 * k + r16) << 2;
-    asm volatile("" : "+v"(gidx[k]));
-  }
   // symmetric load of D
   d4 acc;
 #pragma unroll
@@ -143,8 +143,9 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     const int hi = m > r16 ? m : r16, lo = m > r16 ? r16 : m;
     acc[r] = Sd[lo * pitch + hi];
   }
-  double Lcol[4], coef[4][4], rinv[4][4];
+  double Lcol[4], ax[4], rinv[4][4];
   int badcol = -1;
+  D16_STAMP(1);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int j0 = 4 * q;
@@ -195,16 +196,19 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     const double x31 = -fma(l32, x21, l31 * r1) * r3;
     const double x30 = -fma(l32, x20, fma(l31, x10, l30 * r0)) * r3;
     rinv[q][0] = r0; rinv[q][1] = r1; rinv[q][2] = r2; rinv[q][3] = r3;
-    // this lane's row of X44 (row kq): coef[q][k'] = X44[kq][k']
-    coef[q][0] = kq == 0 ? r0 : (kq == 1 ? x10 : (kq == 2 ? x20 : x30));
-    coef[q][1] = kq == 1 ? r1 : (kq == 2 ? x21 : (kq == 3 ? x31 : 0.0));
-    coef[q][2] = kq == 2 ? r2 : (kq == 3 ? x32 : 0.0);
-    coef[q][3] = kq == 3 ? r3 : 0.0;
-    // solved panel in operand layout: P[i][k] = sum_k' D[i][j0+k'] X44[k][k'],  i = r16, k = kq
-    const double pold = acc[q];
-    double pn = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pn = fma(coef[q][k], bcast_f64(pold, gidx[k]), pn);
+    // X44 as an MFMA A operand: lane (i = r16, k = kq) holds X44[r16][kq] for r16 < 4, else 0
+    {
+      const double row0 = kq == 0 ? r0 : 0.0;
+      const double row1 = kq == 0 ? x10 : (kq == 1 ? r1 : 0.0);
+      const double row2 = kq == 0 ? x20 : (kq == 1 ? x21 : (kq == 2 ? r2 : 0.0));
+      const double row3 = kq == 0 ? x30 : (kq == 1 ? x31 : (kq == 2 ? x32 : r3));
+      ax[q] = r16 == 0 ? row0 : (r16 == 1 ? row1 : (r16 == 2 ? row2 : (r16 == 3 ? row3 : 0.0)));
+    }
+    // solved panel in operand layout, P[i][k] = sum_k' D[i][j0+k'] X44[k][k'] (i = r16, k = kq), from ONE
+    // MFMA: C[m][n] = sum_e X44[m][e] D[n][j0+e]; acc[q] already is the B operand (D is symmetric),
+    // and C's register 0 (m = kq, n = r16) is P in the operand layout the rank-4 update needs.
+    const d4 pt = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[q], acc[q], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+    double pn = pt[0];
     const int a = r16 - j0;  // row inside the 4 x 4 piece, if 0 <= a < 4
     if (a < 0) pn = 0.0;     // finished rows take no part in the update
     if (a >= 0 && a < 4) {   // the piece's own rows: exactly L44 (no rounding noise above the diagonal)
@@ -216,6 +220,7 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     }
     Lcol[q] = pn;
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pn, pn, acc, 0, 0, 0);
+    D16_STAMP(2 + q);
   }
   if (badcol >= 0 && lane == 0 && c0 + badcol < nv) atomicCAS(info, 0, (int)(row0 + c0 + badcol + 1));
 
@@ -226,12 +231,12 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
   double Xrow[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const double eold = e[q];  // E[4q + kq][r16]
-    double xq = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) xq = fma(coef[q][k], bcast_f64(eold, gidx[k]), xq);
-    Xrow[q] = xq;              // X[4q + kq][r16]
+    // X[4q + kq][r16] = sum_k' X44_q[kq][k'] E[4q + k'][r16]: e[q] is the B operand as it stands
+    const d4 xt = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[q], e[q], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+    const double xq = xt[0];
+    Xrow[q] = xq;
     if (q < 3) e = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lcol[q], xq, e, 0, 0, 0);
+    D16_STAMP(6 + q);
   }
   // results: L_ss (lower) into the block, dense X_ss into dinv_s, 1/diag
 #pragma unroll
@@ -242,6 +247,7 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     if (gdinv) gdinv[r16 * SB + col] = Xrow[q];
     if (r16 == 0) rdiag[c0 + col] = kq == 0 ? rinv[q][0] : (kq == 1 ? rinv[q][1] : (kq == 2 ? rinv[q][2] : rinv[q][3]));
   }
+  D16_STAMP(10);
 }
 
 // Packed LDS layout of the lower block triangle: block column s (columns 16s .. 16s+15) keeps
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
   };
 
   // ---- factorisation: right-looking over 16-column sub-panels with one-step look-ahead -------
-  if (wave == 0) factor_diag16_mfma(&S[0], pk_pitch(0), dinv, gd, rdiag, 0, nv, g.info, g.row0);
+  if (wave == 0) factor_diag16_mfma(&S[0], pk_pitch(0), dinv, gd, rdiag, 0, nv, g.info, g.row0, g.dbg ? g.dbg + 40 : nullptr);
   __syncthreads();
   for (int s = 0; s < LB / SB - 1; ++s) {
     const int c0 = s * SB;
@@ -371,7 +377,8 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) dst[(kq + 4 * r) * pd] -= acc[r];
         }
-        write_back(s, tid - 64, 192);
+        // write-back is deferred to the steps where these waves run out of update tiles
+        if (s >= 3) write_back(s - 3, tid - 64, 192);
       }
     }
     LEAF_STAMP(10 + 3 * s);
@@ -379,8 +386,8 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
   }
 
   LEAF_STAMP(2);
-  // ---- last block column back, accumulate log-det -------------------------------------------
-  write_back(LB / SB - 1, tid, 256);
+  // ---- remaining block columns back, accumulate log-det --------------------------------------
+  for (int s = LB / SB - 4; s < LB / SB; ++s) write_back(s, tid, 256);
   {
     double lg = 0.0;
     if (tid < nv) lg = -log(rdiag[tid]);

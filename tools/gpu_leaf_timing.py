@@ -26,3 +26,7 @@ for s_ in range(7):
     b_done, b_bar, c_done = st[8 + 3 * s_], st[9 + 3 * s_], st[10 + 3 * s_]
     print(f"  step {s_}: phaseB(wave0) {(b_done - t1)/100:.2f} us  barrier-wait {(b_bar - b_done)/100:.2f}  phaseC(wave0: tile+factor16) {(c_done - b_bar)/100:.2f}")
     t1 = c_done
+
+d16 = full[41:52]
+print("diag16 (cycles): load %d | factor steps %s | inverse steps %s | store %d | total %d" % (
+    d16[1] - d16[0], [int(v) for v in np.diff(d16[1:6])], [int(v) for v in np.diff(d16[5:10])], d16[10] - d16[9], d16[10] - d16[0]))
