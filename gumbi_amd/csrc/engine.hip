@@ -31,6 +31,7 @@
 #include "gradient.hpp"
 #include "potrf_leaf.hpp"
 #include "trsm_strip.hpp"
+#include "panel_chain.hpp"
 
 using namespace gmb;
 
@@ -129,6 +130,22 @@ struct gmb_engine {
   bool batch_inverse = true;
   bool lpt_order = true;
   int bulk_variant = -1;  // tuning: tile shape of the bulk trailing updates that run beside the panel chain
+
+  // panel chain as one cooperative kernel (panel_chain.hpp): op lists per panel, built once per data set
+  std::vector<ChainOp>* rec = nullptr;  // recording mode of the launch helpers
+  ChainOp* dchain = nullptr;
+  std::vector<int> chain_off, chain_cnt;  // per panel index
+  ChainSync* dsync = nullptr;
+  unsigned int* dsignal = nullptr;        // stream-memory-op flag (hipMallocSignalMemory)
+  unsigned int chain_seq = 0;
+  int chain_cus = 64;
+  bool chain_kernel = false;
+  int64_t chain_N = -1, chain_ld = -1;
+  const double* chain_A = nullptr;
+  int chain_w = 0;
+  long long* dchain_stamps = nullptr;
+  int chain_dbg_panel = -1;
+  std::vector<ChainOp> chain_host;  // host copy of the op lists (debug prints)
 
   // timing
   bool profiling = false;
@@ -312,6 +329,16 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
     f = f > g.nt ? g.nt : f;
     nact += g.nt - f;
   }
+  if (e->rec) {  // op of the fused panel kernel: 128 x 128 tiles by 8 waves, XCD-run order
+    ChainOp op{};
+    op.type = CHAIN_GEMM;
+    g.order = 0;
+    g.sched = nullptr;
+    op.nblocks = gemm_schedule(g, TILE, TILE, nullptr);
+    op.gemm = g;
+    if (op.nblocks > 0) e->rec->push_back(op);
+    return GMB_OK;
+  }
   const bool in_place = (const double*)g.C == g.B;  // the block must own every column of its rows
   // variant: 0 = 128x128 / 4 waves, 1 = 64x64, 2 = 128x64, 3 = 128x32, 4 = 128x128 / 8 waves, 5 = 128x256 / 8 waves
   int variant = e->gemm_variant;
@@ -407,6 +434,13 @@ int launch_trsm_strip(gmb_engine* e, double* B, int64_t ldb, int64_t nrows, cons
   t.ldl = ldl;
   t.dinv16 = dinv16;
   t.nvalid = nvalid;
+  if (e->rec) {
+    ChainOp op{};
+    op.type = CHAIN_STRIP;
+    op.trsm = t;
+    e->rec->push_back(op);
+    return GMB_OK;
+  }
   ev_begin(e, ev_kind, (double)nrows * TILE * TILE);
   hipLaunchKernelGGL(trsm_strip_kernel, dim3((unsigned)((nrows / 16 + 3) / 4)), dim3(256), 0, e->cur, t);
   ev_end(e);
@@ -415,6 +449,13 @@ int launch_trsm_strip(gmb_engine* e, double* B, int64_t ldb, int64_t nrows, cons
 }
 
 int launch_leaf(gmb_engine* e, const LeafArgs& a) {
+  if (e->rec) {
+    ChainOp op{};
+    op.type = CHAIN_LEAF;
+    op.leaf = a;
+    e->rec->push_back(op);
+    return GMB_OK;
+  }
   ev_begin(e, 1, 0.0);
   if (e->naive_leaf)
     hipLaunchKernelGGL(potrf_leaf_naive_kernel, dim3(1), dim3(256), 0, e->cur, a);
@@ -648,6 +689,59 @@ int order_after(gmb_engine* e, hipStream_t from, hipStream_t to) {
 
 int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip);
 
+// ---- fused panel chain --------------------------------------------------------------------------
+// Op lists of every panel but the first (which runs on the idle chip through ordinary launches),
+// recorded by running the panel recursion with the launch helpers in recording mode.
+int build_chain_plan(gmb_engine* e) {
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  const int w = e->panel_blocks;
+  if (e->chain_N == e->N && e->chain_ld == e->ld && e->chain_A == e->dA && e->chain_w == w && e->dchain) return GMB_OK;
+  std::vector<ChainOp> ops;
+  e->chain_off.clear();
+  e->chain_cnt.clear();
+  int rc = GMB_OK;
+  e->rec = &ops;
+  for (int n0 = 0; n0 < nct && !rc; n0 += w) {
+    const int n1 = std::min(n0 + w, nct);
+    e->chain_off.push_back((int)ops.size());
+    if (n0 > 0) rc = chol_cols(e, n0, n1, nrt);
+    e->chain_cnt.push_back((int)ops.size() - e->chain_off.back());
+  }
+  e->rec = nullptr;
+  if (rc) return rc;
+  if (e->dchain) (void)hipFree(e->dchain);
+  e->dchain = nullptr;
+  e->chain_N = -1;
+  if (ops.empty()) return GMB_EINVAL;
+  HIP_TRY(e, hipMalloc((void**)&e->dchain, ops.size() * sizeof(ChainOp)));
+  HIP_TRY(e, hipMemcpy(e->dchain, ops.data(), ops.size() * sizeof(ChainOp), hipMemcpyHostToDevice));
+  e->chain_host = ops;
+  e->chain_N = e->N;
+  e->chain_ld = e->ld;
+  e->chain_A = e->dA;
+  e->chain_w = w;
+  return GMB_OK;
+}
+
+// Launch the chain of panel index `pi` on `chainS` and hold `bulkS` until its workgroups are resident.
+int launch_panel_chain(gmb_engine* e, int pi, hipStream_t chainS, hipStream_t bulkS) {
+  const unsigned int seq = ++e->chain_seq;
+  ev_begin(e, 1, 0.0);
+  long long* stamps = nullptr;
+  static const char* dbg_env = getenv("GMB_CHAIN_DBG");  // tuning: per-op time stamps of panel index N
+  if (dbg_env && atoi(dbg_env) == pi) {
+    if (!e->dchain_stamps) HIP_TRY(e, hipMalloc((void**)&e->dchain_stamps, 4096 * sizeof(long long)));
+    stamps = e->dchain_stamps;
+    e->chain_dbg_panel = pi;
+  }
+  hipLaunchKernelGGL(panel_chain_kernel, dim3(e->chain_cus), dim3(512), 0, chainS, e->dchain + e->chain_off[pi],
+                     e->chain_cnt[pi], e->dsync, e->dsignal, seq, stamps);
+  ev_end(e);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipStreamWaitValue32(bulkS, e->dsignal, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  return GMB_OK;
+}
+
 // Full-height variant: the panel chain (leaf, strip solve and updates over ALL rows below) runs on
 // the auxiliary stream beside U2; U1 = the next panel's columns over all rows.
 int chol_lookahead_full(gmb_engine* e) {
@@ -658,6 +752,7 @@ int chol_lookahead_full(gmb_engine* e) {
   e->sched_next = 0;
   HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
   int rc;
+  const bool fused = e->chain_kernel && e->dsignal && build_chain_plan(e) == GMB_OK;
   e->cur = mainS;
   if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
   for (int c0 = 0; c0 < nct; c0 += w) {
@@ -684,7 +779,11 @@ int chol_lookahead_full(gmb_engine* e) {
     if ((rc = update(n0, n1))) return rc;                 // U1
     if ((rc = order_after(e, mainS, auxS))) return rc;
     e->cur = auxS;
-    if ((rc = chol_cols(e, n0, n1, nrt))) return rc;           // panel p+1, beside U2
+    if (fused) {                                          // panel p+1 as ONE resident kernel, beside U2
+      if ((rc = launch_panel_chain(e, n0 / w, auxS, mainS))) return rc;
+    } else if ((rc = chol_cols(e, n0, n1, nrt))) {        // ... or as ~24 launches
+      return rc;
+    }
     e->cur = mainS;
     if (n1 < nct && (rc = update(n1, nct, true))) return rc;    // U2
     if ((rc = order_after(e, auxS, mainS))) return rc;
@@ -1343,6 +1442,22 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
       const int wgs = prop.multiProcessorCount - e->reserve_cus;
       e->persist_wgs = (e->reserve_cus > 0 && wgs >= 64) ? (wgs / 8) * 8 : 0;
     }
+    const char* ck = getenv("GMB_CHAIN_KERNEL");
+    e->chain_kernel = ck && ck[0] == '1';
+    const char* cc = getenv("GMB_CHAIN_CUS");
+    if (cc && atoi(cc) > 0) e->chain_cus = atoi(cc);
+    e->chain_cus = std::max(8, std::min(e->chain_cus, (int)(e->wg_slots / 2) - 8));
+    int can_wait = 0;
+    (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device);
+    if (can_wait && hipMalloc((void**)&e->dsync, sizeof(ChainSync)) == hipSuccess &&
+        hipMemset(e->dsync, 0, sizeof(ChainSync)) == hipSuccess) {
+      if (hipExtMallocWithFlags((void**)&e->dsignal, 8, hipMallocSignalMemory) != hipSuccess) {
+        (void)hipGetLastError();
+        e->dsignal = nullptr;
+      } else {
+        (void)hipMemset(e->dsignal, 0, 8);
+      }
+    }
     if (hipMalloc((void**)&e->dsched, SCHED_RING * 8 * sizeof(int32_t)) != hipSuccess) {
       gmb_destroy(e);
       return GMB_EHIP;
@@ -1361,7 +1476,7 @@ void gmb_destroy(gmb_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->dplan_gemm, e->dplan_tr, e->dsched, e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
+  void* ptrs[] = {e->dchain, e->dsync, e->dsignal, e->dplan_gemm, e->dplan_tr, e->dsched, e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv,  e->dV,    e->dXs,  e->txs,    e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
   for (void* p : ptrs)
@@ -1526,7 +1641,28 @@ int gmb_factorize(gmb_engine* e) {
   int32_t info = 0;
   HIP_TRY(e, hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  ChainSync hsync{};
+  if (e->chain_kernel && e->dsync)
+    HIP_TRY(e, hipMemcpyAsync(&hsync, e->dsync, sizeof(ChainSync), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->chain_dbg_panel >= 0 && e->dchain_stamps) {
+    const int pi = e->chain_dbg_panel, n = e->chain_cnt[pi];
+    std::vector<long long> st(2 * n + 1);
+    (void)hipMemcpy(st.data(), e->dchain_stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[chain panel %d: %d ops, total %.1f us]\n", pi, n, (st[2 * n] - st[0]) / 100.0);
+    for (int i = 0; i < n; ++i) {
+      const ChainOp& op = e->chain_host[e->chain_off[pi] + i];
+      fprintf(stderr, "  op %2d type %d  work %7.1f us  barrier %6.1f us  (nblocks %d, rows %lld, k %d)\n", i, op.type,
+              (st[2 * i + 1] - st[2 * i]) / 100.0, (st[2 * i + 2] - st[2 * i + 1]) / 100.0, op.nblocks,
+              (long long)op.trsm.nrows, op.gemm.k);
+    }
+    e->chain_dbg_panel = -1;
+  }
+  if (hsync.abort) {
+    (void)hipMemset(e->dsync, 0, sizeof(ChainSync));
+    ev_collect(e);
+    return fail(e, GMB_EHIP, "panel chain kernel: grid barrier watchdog fired (workgroups not co-resident?)");
+  }
   tm.kbuild_ms = tk.ms();
   tm.chol_ms = tc.ms();
   tm.kbuild_bytes = 8.0 * (double)e->N * (double)(e->N + 1) / 2.0 +

@@ -107,8 +107,10 @@ __host__ __device__ __forceinline__ int gemm_first_tn(int64_t T, int bn, int str
 // then keeps its 128 accumulator registers + staging in 207 VGPRs (no AGPRs, no spills) and the
 // second workgroup's MFMAs fill the first one's barrier / staging bubbles: 39 -> 52 TF/s on the
 // whole N = 30k Cholesky, 44 -> 59 TF/s on the predict GEMMs (measured A/B on MI355X).
+// `vbid`: the block index this call stands for (blockIdx.x in the plain kernels; a fused kernel
+// that walks a tile list with fewer workgroups passes its own counter).
 template <int WGM, int WGN, int WTM, int WTN, bool PERSIST>
-__device__ __forceinline__ void gemm_f64_body(const GemmArgs& g) {
+__device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid) {
   constexpr int NT = 64 * WGM * WGN;                      // threads: WGM x WGN waves
   constexpr int BM = 16 * WTM * WGM, BN = 16 * WTN * WGN; // block tile; wave tile 16*WTM x 16*WTN
   constexpr int PA = BM + 16, PB = BN + 16;     // LDS pitches, % 32 == 16 -> conflict-free ds_read_b64
@@ -118,7 +120,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g) {
   __shared__ double lds[2][KT * (PA + PB)];
 
   __shared__ int next_tile;
-  const int xcd = blockIdx.x & 7;
+  const int xcd = vbid & 7;
   for (int round = 0;; ++round) {
   // compact index of this block's tile within its XCD's run, then (tm, tn) by walking the rows
   int tm, tn;
@@ -131,7 +133,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g) {
       __syncthreads();
     } else {
       if (round) return;
-      ci = g.xstart[xcd] + (blockIdx.x >> 3);
+      ci = g.xstart[xcd] + (vbid >> 3);
     }
     if (g.order == 0) {
       if (ci >= g.xstart[xcd + 1]) return;
@@ -154,7 +156,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g) {
       }
     } else {
       // n-major list (nblk_stride == 1): n-tile tn holds the m-tiles [0, cnt(tn))
-      ci = blockIdx.x;
+      ci = vbid;
       const int step = g.order == 1 ? 1 : -1;
       tn = g.order == 1 ? 0 : g.nt - 1;
       for (;;) {
@@ -274,7 +276,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g) {
 
 template <int WGM, int WGN, int WTM, int WTN, int OCC, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs g) {
-  gemm_f64_body<WGM, WGN, WTM, WTN, PERSIST>(g);
+  gemm_f64_body<WGM, WGN, WTM, WTN, PERSIST>(g, blockIdx.x);
 }
 
 // Batched form: blockIdx.y selects one of several INDEPENDENT products whose descriptors sit in
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs 
 template <int WGM, int WGN, int WTM, int WTN, int OCC>
 __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_batched_kernel(const GemmArgs* __restrict__ batch) {
   const GemmArgs g = batch[blockIdx.y];  // uniform address, read before any store: scalar loads
-  gemm_f64_body<WGM, WGN, WTM, WTN, false>(g);
+  gemm_f64_body<WGM, WGN, WTM, WTN, false>(g, blockIdx.x);
 }
 
 // MFMA-only microbenchmark: the GEMM's own register pattern (4 x 4 independent accumulators fed

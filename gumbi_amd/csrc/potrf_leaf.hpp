@@ -264,11 +264,16 @@ __device__ __forceinline__ int pk(int r, int c) {
   return pk_off(s) + (c & 15) * pk_pitch(s) + r - 16 * s;
 }
 
-__global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
+// NW = wavefronts of the calling workgroup (4: the stand-alone kernel; 8: the whole-CU workgroups of
+// panel_chain_kernel -- the extra waves take update tiles and write-back).  Every thread of the
+// workgroup must call it (workgroup barriers inside).
+template <int NW>
+__device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
+  constexpr int NTH = 64 * NW;
   __shared__ double S[PK_SIZE];        //  75,776 B
   __shared__ double dinv[SB * SB];     //   2,048 B  dense X_ss of the current sub-panel, column-major
   __shared__ double rdiag[LB];         //   1,024 B  1 / L_cc  (= X_cc)
-  __shared__ double red[4];
+  __shared__ double red[NW];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -285,16 +290,17 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
   // ---- load: lower block triangle of real columns, identity elsewhere, zeros above the diagonal
   {
     // all 16-byte loads of a thread are issued before the first use (one latency, not 32)
-    d2 buf[32];
+    constexpr int NL = 8192 / NTH;
+    d2 buf[NL];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int p = tid + 256 * i;            // pair index: column p / 64, rows 2 (p % 64), +1
+    for (int i = 0; i < NL; ++i) {
+      const int p = tid + NTH * i;            // pair index: column p / 64, rows 2 (p % 64), +1
       const int c = p >> 6, r = (p & 63) * 2;
       if (r >= (c & ~15)) buf[i] = *reinterpret_cast<const d2*>(g.A + r + (int64_t)c * g.lda);
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int p = tid + 256 * i;
+    for (int i = 0; i < NL; ++i) {
+      const int p = tid + NTH * i;
       const int c = p >> 6, r = (p & 63) * 2;
       if (r >= (c & ~15)) {
         d2 v = buf[i];
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     double* Sd = &S[pk_off(s)];      // block column s, first row c0
     const int pitch = pk_pitch(s);
     // (B) sub-panel rows below the diagonal sub-block:  P <- P X_ss^T  (MFMA, in place per tile)
-    for (int tr = s + 1 + wave; tr < LB / SB; tr += 4) {
+    for (int tr = s + 1 + wave; tr < LB / SB; tr += NW) {
       const int rw = tr * SB - c0;
       d4 acc = d4{0.0, 0.0, 0.0, 0.0};
       acc = mfma_tile_k16(dinv, SB, &Sd[rw], pitch, acc);
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
         factor_diag16_mfma(Sn, pn, dinv, gd ? gd + (s + 1) * SB * SB : nullptr, rdiag, c0 + SB, nv, g.info, g.row0);
       } else {
         const int ntile = n * (n + 1) / 2;
-        for (int t = wave; t < ntile; t += 3) {  // t = 0 is the diagonal tile wave 0 owns
+        for (int t = wave; t < ntile; t += NW - 1) {  // t = 0 is the diagonal tile wave 0 owns
           int tc = 0, rem = t;
           while (rem >= n - tc) {
             rem -= n - tc;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
           for (int r = 0; r < 4; ++r) dst[(kq + 4 * r) * pd] -= acc[r];
         }
         // write-back is deferred to the steps where these waves run out of update tiles
-        if (s >= 3) write_back(s - 3, tid - 64, 192);
+        if (s >= 3) write_back(s - 3, tid - 64, NTH - 64);
       }
     }
     LEAF_STAMP(10 + 3 * s);
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
 
   LEAF_STAMP(2);
   // ---- remaining block columns back, accumulate log-det --------------------------------------
-  for (int s = LB / SB - 4; s < LB / SB; ++s) write_back(s, tid, 256);
+  for (int s = LB / SB - 4; s < LB / SB; ++s) write_back(s, tid, NTH);
   {
     double lg = 0.0;
     if (tid < nv) lg = -log(rdiag[tid]);
@@ -395,7 +401,12 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
     if (lane == 0) red[wave] = lg;
     __syncthreads();
-    if (tid == 0 && g.logdet) atomicAdd(g.logdet, red[0] + red[1] + red[2] + red[3]);
+    if (tid == 0 && g.logdet) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += red[w];
+      atomicAdd(g.logdet, tot);
+    }
   }
   LEAF_STAMP(3);
   if (g.dinv16 && nv < LB) {
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     // are not part of the triangular factor and the padding is identity: build the sub-block
     // inverses of the identity-padded factor the slow way.
     __syncthreads();
-    for (int idx = tid; idx < LB * LB; idx += 256) {
+    for (int idx = tid; idx < LB * LB; idx += NTH) {
       const int c = idx >> 7, r = idx & 127;
       if (r >= (c & ~15)) {
         if (c < nv && r >= nv) S[pk(r, c)] = 0.0;
@@ -430,7 +441,10 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) {
     }
   }
   LEAF_STAMP(4);
+  __syncthreads();
 }
+
+__global__ __launch_bounds__(256) void potrf_leaf_kernel(LeafArgs g) { potrf_leaf_body<4>(g); }
 
 // ---- inverse of a factored diagonal block (off the factorisation's critical path) ----------
 // One workgroup per diagonal block: X = inv(L_kk) (identity-padded) from L_kk and its eight

@@ -34,13 +34,11 @@ struct TrsmArgs {
                          // the buffer holds there -- the y row of the factor buffer -- is ignored)
 };
 
-__global__ __launch_bounds__(256) void trsm_strip_kernel(TrsmArgs g) {
+// one 16-row slab (rows r0 .. r0+15) by the calling wavefront
+__device__ __forceinline__ void trsm_strip_slab(const TrsmArgs& g, const int64_t r0) {
   typedef double d4 __attribute__((ext_vector_type(4)));
-  __builtin_amdgcn_s_setprio(3);  // part of the latency-bound chain: go first on a shared compute unit
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int r16 = lane & 15, kq = lane >> 4;
-  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
-  if (r0 >= g.nrows) return;
   double* Bp = g.B + r0 + r16;
   d4 X[8];
 #pragma unroll
@@ -72,6 +70,13 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(TrsmArgs g) {
   for (int s = 0; s < 8; ++s)
 #pragma unroll
     for (int q = 0; q < 4; ++q) Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb] = X[s][q];
+}
+
+__global__ __launch_bounds__(256) void trsm_strip_kernel(TrsmArgs g) {
+  __builtin_amdgcn_s_setprio(3);  // part of the latency-bound chain: go first on a shared compute unit
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  if (r0 >= g.nrows) return;
+  trsm_strip_slab(g, r0);
 }
 
 }  // namespace gmb
