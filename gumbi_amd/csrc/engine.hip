@@ -460,7 +460,7 @@ int launch_leaf(gmb_engine* e, const LeafArgs& a) {
   if (e->naive_leaf)
     hipLaunchKernelGGL(potrf_leaf_naive_kernel, dim3(1), dim3(256), 0, e->cur, a);
   else
-    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(256), 0, e->cur, a);
+    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(512), 0, e->cur, a);
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
