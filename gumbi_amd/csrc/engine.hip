@@ -1191,7 +1191,10 @@ int launch_grad_nc(gmb_engine* e, const GradArgs& a, int nblocks) {
 
 constexpr int GACC_DOUBLES = 64 + MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS + 64;
 
-int grad_impl(gmb_engine* e, double* grad) {
+// Device part of the gradient: inverse, alpha, Sigma^-1 and the trace reductions over the block
+// rows shard, shard + nshards, ... of the lower triangle; `h` receives the raw accumulators (they
+// are sums over tiles, so shards of several GPUs add up).
+int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& h) {
   HIP_TRY(e, hipSetDevice(e->device));
   if (e->factor_consumed)
     return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
@@ -1240,17 +1243,22 @@ int grad_impl(gmb_engine* e, double* grad) {
   HIP_TRY(e, hipGetLastError());
   // 3. Sigma^-1 = U U^T (lower triangle) into dW
   {
+    const int owned = shard < nt ? (nt - shard + nshards - 1) / nshards : 0;
     GemmArgs g{};
-    g.C = e->dW;
+    g.C = e->dW + (int64_t)shard * TILE;
     g.ldc = e->Np;
     g.A = e->dA;
     g.lda = e->ld;
-    g.B = e->dA;
+    g.B = e->dA + (int64_t)shard * TILE;
     g.ldb = e->ld;
-    g.mt = g.nt = nt;
+    g.mt = nt;
+    g.nt = owned;
     g.k = (int)e->Np;
     g.klo_n = 1;
+    g.krow_off = shard * TILE;
     g.tri = 1;
+    g.tri_off = shard * TILE;
+    g.nblk_stride = nshards;
     g.alpha = 1.0;
     g.beta = 0.0;
     if ((rc = launch_gemm(e, g, 4))) return rc;
@@ -1270,6 +1278,8 @@ int grad_impl(gmb_engine* e, double* grad) {
   const int n_ls = s.ard ? s.n_cont : 1;
   a.eta = e->theta[n_ls];
   a.acc = e->dgpart;
+  a.row_first = shard;
+  a.row_stride = nshards;
   const int ntab = spec_ntab(s);
   int off = 64;
   for (int t = 0; t < ntab; ++t) {
@@ -1277,8 +1287,9 @@ int grad_impl(gmb_engine* e, double* grad) {
     off += e->cp.tab_levels[t] * e->cp.tab_levels[t];
   }
   const int diag_off = off;  // [sigma, noise table...]
-  const int nblocks = nt * (nt + 1) / 2;
-  switch (e->cp.kind) {
+  int nblocks = 0;
+  for (int i = shard; i < nt; i += nshards) nblocks += i + 1;
+  if (nblocks > 0) switch (e->cp.kind) {
     case GMB_EXPQUAD: rc = launch_grad_nc<0>(e, a, nblocks); break;
     case GMB_MATERN52: rc = launch_grad_nc<1>(e, a, nblocks); break;
     case GMB_MATERN32: rc = launch_grad_nc<2>(e, a, nblocks); break;
@@ -1288,16 +1299,30 @@ int grad_impl(gmb_engine* e, double* grad) {
   if (rc) return rc;
   const double sigma = e->theta[n_ls + 1];
   hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, e->dW, e->Np, e->dalpha,
-                     train_set(e), e->cp, sigma, e->dgpart + diag_off);
+                     train_set(e), e->cp, sigma, e->dgpart + diag_off, shard, nshards);
   HIP_TRY(e, hipGetLastError());
   tg.stop();
-  std::vector<double> h(GACC_DOUBLES);
+  h.assign(GACC_DOUBLES, 0.0);
   HIP_TRY(e, hipMemcpyAsync(h.data(), e->dgpart, GACC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
                             e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   tm.grad_ms = tg.ms();
   ev_collect(e);
-  // 5. chain rule back to the packed natural-scale parameters
+  return GMB_OK;
+}
+
+// Host part: chain rule from the (summed) accumulators back to the packed natural-scale parameters.
+int grad_chain_rule(gmb_engine* e, const std::vector<double>& h, double* grad) {
+  const gmb_kernel_spec& s = e->spec;
+  const int n_ls = s.ard ? s.n_cont : 1;
+  const int ntab = spec_ntab(s);
+  int tab_acc_off[MAX_TABS] = {0};
+  int off = 64;
+  for (int t = 0; t < ntab; ++t) {
+    tab_acc_off[t] = off;
+    off += e->cp.tab_levels[t] * e->cp.tab_levels[t];
+  }
+  const int diag_off = off;
   const double* th = e->theta.data();
   int k = 0;
   for (int i = 0; i < n_ls; ++i) grad[k++] = h[i];
@@ -1309,7 +1334,7 @@ int grad_impl(gmb_engine* e, double* grad) {
   }
   for (int t = 0; t < ntab; ++t) {
     const int L = e->cp.tab_levels[t];
-    const double* G = h.data() + a.tab_acc_off[t];
+    const double* G = h.data() + tab_acc_off[t];
     const double* W = th + k;
     for (int x = 0; x < L; ++x)
       for (int q = 0; q < 2; ++q) {
@@ -1693,8 +1718,34 @@ int gmb_nlml(gmb_engine* e, double* nlml, double* grad) {
   if (rc) return rc;
   if (!nlml) return fail(e, GMB_EINVAL, "nlml output pointer is null");
   *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
-  if (grad) return grad_impl(e, grad);
+  if (grad) {
+    std::vector<double> h;
+    if ((rc = grad_accumulate(e, 0, 1, h))) return rc;
+    return grad_chain_rule(e, h, grad);
+  }
   return GMB_OK;
+}
+
+int32_t gmb_grad_acc_size(void) { return (int32_t)GACC_DOUBLES; }
+
+int gmb_nlml_shard(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc) {
+  int rc = require_ready(e, true);
+  if (rc) return rc;
+  if (!acc || nacc < (int32_t)GACC_DOUBLES || nshards < 1 || shard < 0 || shard >= nshards)
+    return fail(e, GMB_EINVAL, "bad gradient shard arguments");
+  std::vector<double> h;
+  if ((rc = grad_accumulate(e, shard, nshards, h))) return rc;
+  std::memcpy(acc, h.data(), GACC_DOUBLES * sizeof(double));
+  return GMB_OK;
+}
+
+int gmb_nlml_from_acc(gmb_engine* e, const double* acc, int32_t nacc, double* nlml, double* grad) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  if (!acc || !nlml || !grad || nacc < (int32_t)GACC_DOUBLES) return fail(e, GMB_EINVAL, "bad accumulator arguments");
+  *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
+  std::vector<double> h(acc, acc + GACC_DOUBLES);
+  return grad_chain_rule(e, h, grad);
 }
 
 int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_t with_noise,

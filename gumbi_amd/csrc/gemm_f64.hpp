@@ -57,8 +57,12 @@ struct GemmArgs {
   // memory (1 = contiguous).  This is how one rank of the block-cyclic row partition updates
   // only the block rows it owns: noff(tn) = ((tn*BN)/128)*nblk_stride*128 + (tn*BN)%128.
   int32_t nblk_stride;
-  // per-tile contraction range: k_lo = klo_m*tm*BM + klo_n*tn*BN, k_hi = khi_n ? min(k, (tn+1)*BN) : k
+  // per-tile contraction range: k_lo = klo_m*tm*BM + klo_n*R(tn), k_hi = khi_n ? min(k, R(tn)+BN) : k,
+  // R(tn) = noff(tn) + krow_off = the tile's first row in the coordinates of the contraction index
+  // (krow_off = 0 and noff = tn*BN for a contiguous n range; a rank of the block-cyclic partition
+  // passes its first block row's offset)
   int32_t klo_m, klo_n, khi_n;
+  int32_t krow_off;
   // XCD-balanced schedule (filled by gemm_schedule): the computed tiles, enumerated row-major
   // (tm outer, tn inner), are cut into 8 contiguous runs of equal WORK; block b serves run b % 8.
   int32_t xstart[9];
@@ -182,9 +186,10 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
   const int wm = wave / WGN, wn = wave % WGN;
   const int r16 = lane & 15, kq = lane >> 4;
 
-  int k_lo = g.klo_m * tm * BM + g.klo_n * tn * BN;
+  const int krow = (int)gemm_noff(tn, BN, g.nblk_stride) + g.krow_off;
+  int k_lo = g.klo_m * tm * BM + g.klo_n * krow;
   int k_hi = g.k;
-  if (g.khi_n) k_hi = min(k_hi, (tn + 1) * BN);
+  if (g.khi_n) k_hi = min(k_hi, krow + BN);
   if (k_lo > k_hi) k_lo = k_hi;
 
   const int a_row = tid / LA, a_col = 2 * (tid % LA);
@@ -334,9 +339,10 @@ inline int gemm_schedule(GemmArgs& g, int bm, int bn, double* flops) {
     return f > g.nt ? g.nt : f;
   };
   auto kunits = [&](int tm, int tn) {
-    const int lo = (g.klo_m * tm * bm + g.klo_n * tn * bn) / KT;
+    const int krow = (int)gemm_noff(tn, bn, g.nblk_stride < 1 ? 1 : g.nblk_stride) + g.krow_off;
+    const int lo = (g.klo_m * tm * bm + g.klo_n * krow) / KT;
     int hi = KU;
-    if (g.khi_n && (tn + 1) * bn / KT < hi) hi = (tn + 1) * bn / KT;
+    if (g.khi_n && (krow + bn) / KT < hi) hi = (krow + bn) / KT;
     return hi > lo ? hi - lo : 0;
   };
   if (g.order != 0) {  // n-major list in dispatch order: no XCD runs, grid = number of tiles

@@ -36,6 +36,9 @@ struct GradArgs {
   double eta;
   double* acc;      // global accumulators (atomicAdd)
   int32_t tab_acc_off[MAX_TABS];
+  // shard of the lower triangle this launch reduces: block rows row_first, row_first + row_stride, ...
+  // (0, 1 = everything; a rank of the multi-GPU gradient passes (rank, world))
+  int32_t row_first, row_stride;
 };
 
 constexpr int GRAD_MAX_LDS_ACC = 16 + 2 + MAX_LIN + MAX_TABS * 64;  // tables up to 8 levels in LDS
@@ -50,13 +53,14 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
   __shared__ double aj[TILE];
   __shared__ double sacc[GRAD_MAX_LDS_ACC];
 
-  // lower-triangle tile pair (ti >= tj)
-  int tjx = 0, rem = blockIdx.x;
-  while (rem >= a.tiles - tjx) {
-    rem -= a.tiles - tjx;
-    ++tjx;
+  // lower-triangle tile pair (ti >= tj), enumerated block row by owned block row
+  int tix = a.row_first, rem = blockIdx.x;
+  while (rem > tix) {
+    rem -= tix + 1;
+    tix += a.row_stride;
   }
-  const int tix = tjx + rem;
+  if (tix >= a.tiles) return;
+  const int tjx = rem;
   const int64_t gi0 = (int64_t)tix * TILE, gj0 = (int64_t)tjx * TILE;
   const int tid = threadIdx.x;
   const int il = tid & (TILE - 1), jh = tid >> 7;
@@ -195,10 +199,12 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
 //   out[0] += sum_i M_ii * 2 sigma * nmult_i ;  out[1 + a] += sum_{i: out(i) = a} M_ii * sigma^2
 __global__ __launch_bounds__(256) void grad_diag_kernel(const double* Z, int64_t ldz,
                                                         const double* alpha, PointSet pts,
-                                                        CovParams p, double sigma, double* out) {
+                                                        CovParams p, double sigma, double* out, int row_first,
+                                                        int row_stride) {
   __shared__ double red[4];
   double gs = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pts.n; i += (int64_t)gridDim.x * 256) {
+    if ((int)((i >> 7) % row_stride) != row_first) continue;  // block rows of this shard only
     const double a = alpha[i];
     const double m = 0.5 * (Z[i + i * ldz] - a * a);
     double mult = 1.0;

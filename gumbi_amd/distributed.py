@@ -277,8 +277,20 @@ class DistributedEngine:
             driver.factorize()
         return driver
 
-    def nlml(self):
-        return self.eng.nlml()
+    def nlml(self, grad: bool = False):
+        """NLML of the distributed factorisation; with ``grad=True`` also its gradient: every rank inverts
+        the (complete, local) factor, reduces the trace terms over ITS block rows of Sigma^-1
+        (``gmb_nlml_shard``), the accumulators are all-reduced and every rank applies the same chain rule,
+        so all ranks return bit-identical (value, gradient) and an optimiser stays in lock step."""
+        if not grad:
+            return self.eng.nlml()
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            acc = self.eng.nlml_shard(self.comm.rank, self.comm.world)
+            t = torch.as_tensor(acc, device=self.device)
+            self.comm.all_reduce(t, "sum")
+            acc = t.cpu().numpy()
+        return self.eng.nlml_from_acc(acc)
 
     def predict(self, Xs, with_noise=True):
         """Every rank passes the same ``Xs``; rank r predicts ``np.array_split`` slice r and the

@@ -174,6 +174,10 @@ _SIGNATURES = {
     "gmb_copy_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _DBL_P]),
     "gmb_copy_v": (C.c_int, [C.c_void_p, _DBL_P]),
     "gmb_blk_potrf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmb_grad_acc_size": (C.c_int32, []),
+    "gmb_nlml_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]),
+    "gmb_nlml_from_acc": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double)]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gmb_blk_trsm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                C.c_int32]),
@@ -389,6 +393,23 @@ class Engine:
         out = np.empty(self.N, dtype=np.float64)
         self._check(self._lib.gmb_copy_v(self._h, _dptr(out)), "gmb_copy_v")
         return out
+
+    # -- sharded gradient (multi-GPU driver) ---------------------------------------------------------------
+    def nlml_shard(self, shard: int, nshards: int) -> np.ndarray:
+        """Raw gradient accumulators of the block rows ``shard, shard + nshards, ...`` (sum the arrays of
+        all shards, then :meth:`nlml_from_acc`).  Consumes the factor like :meth:`nlml` with ``grad=True``."""
+        n = int(self._lib.gmb_grad_acc_size())
+        acc = np.zeros(n, dtype=np.float64)
+        self._check(self._lib.gmb_nlml_shard(self._h, shard, nshards, _dptr(acc), n), "gmb_nlml_shard")
+        return acc
+
+    def nlml_from_acc(self, acc):
+        acc = np.ascontiguousarray(acc, dtype=np.float64)
+        val = C.c_double()
+        grad = np.empty(self.spec.theta_size(), dtype=np.float64)
+        self._check(self._lib.gmb_nlml_from_acc(self._h, _dptr(acc), acc.size, C.byref(val), _dptr(grad)),
+                    "gmb_nlml_from_acc")
+        return float(val.value), grad
 
     # -- block-level operations (device pointers) --------------------------------------------------------
     def blk_potrf(self, a_ptr, lda, nvalid, dinv16_ptr, logdet_ptr=0, info_ptr=0):

@@ -163,6 +163,16 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
 int gmb_ls_limits(int32_t device, const double* X, int64_t N, int32_t n_cols, int64_t ldx,
                   int32_t ard, double* lower, double* upper);
 
+/* Multi-GPU gradient (every rank holds the complete factor after the block-cyclic Cholesky of
+ * gumbi_amd/distributed.py): rank `shard` of `nshards` computes L^-1 (replicated), its block rows
+ * shard, shard + nshards, ... of Sigma^-1 and the trace reductions over those rows, and returns
+ * the raw accumulators (gmb_grad_acc_size() doubles, host).  They are plain sums over tiles: the
+ * driver all-reduces them and every rank finishes with gmb_nlml_from_acc (chain rule to the packed
+ * parameters, same layout as gmb_nlml's grad).  gmb_nlml(e, &v, grad) == shard 0 of 1 + from_acc. */
+int32_t gmb_grad_acc_size(void);
+int gmb_nlml_shard(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc);
+int gmb_nlml_from_acc(gmb_engine* e, const double* acc, int32_t nacc, double* nlml, double* grad);
+
 /* -- introspection --------------------------------------------------------------------------- */
 int gmb_set_profiling(gmb_engine* e, int32_t on); /* per-launch hipEvent timing of GEMMs */
 int gmb_timings_get(const gmb_engine* e, gmb_timings* out);

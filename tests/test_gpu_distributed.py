@@ -40,7 +40,12 @@ def _worker(rank, world, port, N, d, M, out):
         mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
         err_mu = np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))
         err_var = np.max(np.abs(var - var_r))
-        out.put((rank, err_L, err_v, err_nl, err_mu, err_var))
+        # distributed gradient: every rank must return the same (value, gradient) == the oracle's
+        eng.factorize()
+        val, g = eng.nlml(grad=True)
+        val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+        err_g = max(abs(val - val_r) / abs(val_r), np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r))))
+        out.put((rank, err_L, err_v, err_nl, err_mu, err_var, err_g, g.tobytes()))
         eng.close()
     finally:
         dist.destroy_process_group()
@@ -66,6 +71,8 @@ def test_two_ranks_one_gpu_match_oracle(gpu, world, N):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, err_L, err_v, err_nl, err_mu, err_var in results:
+    for rank, err_L, err_v, err_nl, err_mu, err_var, err_g, gbytes in results:
         assert err_L < 1e-10 and err_v < 1e-10 and err_nl < 1e-8
         assert err_mu < 1e-8 and err_var < 1e-9
+        assert err_g < 1e-8
+    assert len({r[-1] for r in results}) == 1  # bit-identical gradient on every rank (optimisers stay in lock step)

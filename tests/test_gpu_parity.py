@@ -281,6 +281,34 @@ def test_nlml_gradient_matches_oracle(gpu, kind, ard):
         eng.predict(X[:4])  # the factor was consumed by the gradient
 
 
+@pytest.mark.parametrize("nshards", [2, 3, 5])
+def test_sharded_gradient_sums_to_the_full_gradient(gpu, nshards):
+    """gmb_nlml_shard over all shards + gmb_nlml_from_acc == gmb_nlml (the multi-GPU gradient's contract);
+    composite model so that every accumulator class (lengthscales, linear, coregion tables, noise) is hit."""
+    case = "composite_N140"
+    spec = golden_spec(case)
+    X, y, theta = (GOLD[f"{case}/{k}"] for k in ("X", "y", "theta"))
+    rng = np.random.default_rng(3)
+    reps = 3  # > 128 rows so that several block rows exist
+    Xb = np.concatenate([X] * reps)
+    Xb[:, spec["idx_cont"]] += 0.05 * rng.standard_normal((len(Xb), len(spec["idx_cont"])))
+    yb = np.concatenate([y] * reps) + 0.1 * rng.standard_normal(len(Xb))
+    eng = make_engine(spec, theta, Xb, yb)
+    eng.factorize()
+    val, g = eng.nlml(grad=True)
+    acc = 0.0
+    for sh in range(nshards):
+        eng.factorize()  # each shard call consumes the factor, as each rank's engine does
+        acc = acc + eng.nlml_shard(sh, nshards)
+    eng.factorize()
+    val2, g2 = eng.nlml_from_acc(acc)
+    assert val2 == val
+    assert np.max(np.abs(g2 - g)) < 1e-11 * max(1.0, np.max(np.abs(g)))
+    val_r, g_r = O.nlml_and_grad(spec, theta, Xb, yb, dist_mode="direct")
+    assert np.isclose(val2, val_r, rtol=1e-10)
+    assert np.max(np.abs(g2 - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
+
+
 def test_composite_model_gradient_and_prediction(gpu):
     case = "composite_N140"
     spec = golden_spec(case)
