@@ -62,9 +62,14 @@ class HipGP(Regressor):
     """Gaussian-process regression on an MI355X.  Drop-in for ``gumbi.GP`` on the
     ``fit() / prepare_grid() / predict_grid()`` path; see the module docstring."""
 
-    def __init__(self, dataset: DataSet, outputs=None, seed=2021, device=0):
+    def __init__(self, dataset: DataSet, outputs=None, seed=2021, device=0, distributed=None):
+        """``distributed``: ``True`` (default process group) or a ``torch.distributed`` group -- ONE GP
+        spread over the group's GPUs (:class:`gumbi_amd.distributed.DistributedEngine`: block-cyclic
+        Cholesky, sharded gradient and prediction).  Every rank constructs the same GP on the same data
+        and makes the same calls; all ranks obtain identical MAP estimates and predictions."""
         super().__init__(dataset, outputs, seed)
         self.device = device
+        self.distributed = distributed
         self.model = None
         self.gp_dict = None
         self.MAP = None
@@ -205,7 +210,12 @@ class HipGP(Regressor):
         self.model = HipModel(spec, ls_params, blocks, X, y)
         if self.engine is not None:
             self.engine.close()
-        self.engine = Engine(device=self.device)
+        if self.distributed:
+            from ..distributed import DistributedEngine
+
+            self.engine = DistributedEngine(self.device, None if self.distributed is True else self.distributed)
+        else:
+            self.engine = Engine(device=self.device)
         self.engine.set_data(X, y)
         self.engine.set_kernel(spec)
         self.gp_dict = {"total": self.engine}

@@ -76,3 +76,61 @@ def test_two_ranks_one_gpu_match_oracle(gpu, world, N):
         assert err_mu < 1e-8 and err_var < 1e-9
         assert err_g < 1e-8
     assert len({r[-1] for r in results}) == 1  # bit-identical gradient on every rank (optimisers stay in lock step)
+
+
+def _fit_worker(rank, world, port, N, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pandas as pd
+
+        import gumbi_amd as gmb
+        from oracle import gp_oracle as O
+
+        X, y, _ = O.synthetic_table(N, 2, seed=9)
+        df = pd.DataFrame(X, columns=["a", "b"])
+        df["y"] = y
+        grid = np.random.default_rng(2).uniform(-1.5, 1.5, (50, 2))
+
+        def fit(distributed):
+            gp = gmb.GP(gmb.DataSet(df, outputs=["y"]), outputs=["y"], distributed=distributed)
+            gp.specify_model(continuous_dims=["a", "b"])
+            gp.build_model()
+            gp.find_MAP()
+            pts = gp.parray(a=grid[:, 0], b=grid[:, 1])
+            pred = gp.predict_points(pts)
+            res = (gp._theta_fitted.copy(), np.asarray(pred.μ).copy(), np.asarray(pred.σ2).copy(), gp.n_eval)
+            gp.engine.close()
+            return res
+
+        th_d, mu_d, var_d, n_d = fit(True)
+        th_s, mu_s, var_s, n_s = fit(None)  # the same fit on this rank's GPU alone
+        out.put((rank, float(np.max(np.abs(th_d - th_s) / np.maximum(np.abs(th_s), 1e-3))),
+                 float(np.max(np.abs(mu_d - mu_s))), float(np.max(np.abs(var_d - var_s))), n_d, n_s, th_d.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_map_fit_matches_single_gpu_fit(gpu):
+    """GP(..., distributed=True).find_MAP() over two ranks: same optimum and predictions as the
+    single-GPU fit, identical parameters on both ranks."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, 400, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err_th, err_mu, err_var, n_d, n_s, _ in results:
+        assert err_th < 1e-5 and err_mu < 1e-6 and err_var < 1e-6
+    assert results[0][-1] == results[1][-1]
