@@ -169,8 +169,8 @@ DIST_N, DIST_D = 40_960, 8
 
 
 def distributed_section(world, local_rank, dist):
-    """Fixed-theta fit (K-build + Cholesky + v + NLML) and a sharded grid prediction of ONE
-    N = 40,960 GP over all ranks; max-over-ranks wall time."""
+    """Fixed-theta fit (K-build + Cholesky + v + NLML), a sharded grid prediction and one MAP
+    objective+gradient evaluation of ONE N = 40,960 GP over all ranks; max-over-ranks wall time."""
     import torch
 
     from gumbi_amd import engine as E
@@ -207,12 +207,18 @@ def distributed_section(world, local_rank, dist):
     mu, var = predict()
     sync()
     t2 = time.perf_counter()
+    # one MAP objective + gradient evaluation of the same GP (what find_MAP repeats): factorisation,
+    # replicated L^-1, sharded Sigma^-1 + trace reductions, all-reduce of the accumulators
+    eng.factorize()
+    val, grad = eng.nlml(grad=True)
+    sync()
+    t3 = time.perf_counter()
     on_dev = dist is None or dist.get_backend() == "nccl"
-    times = torch.tensor([t1 - t0, t2 - t1], dtype=torch.float64,
+    times = torch.tensor([t1 - t0, t2 - t1, t3 - t2], dtype=torch.float64,
                          device=torch.device("cuda", local_rank) if on_dev else "cpu")
     if dist is not None:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    fit_s, pred_s = (float(v) for v in times.cpu())
+    fit_s, pred_s, eval_s = (float(v) for v in times.cpu())
     eng.close()
     flops_fit = float(N) ** 3 / 3.0
     flops_pred = float(N) ** 2 * len(Xs)
@@ -222,6 +228,9 @@ def distributed_section(world, local_rank, dist):
         "predict_s": round(pred_s, 4),
         "fit_tflops": round(flops_fit / fit_s / 1e12, 2),
         "predict_tflops": round(flops_pred / pred_s / 1e12, 2),
+        "map_eval_s": round(eval_s, 4),
+        "map_eval_tflops": round(float(N) ** 3 / eval_s / 1e12, 2),
+        "grad_finite": bool(np.all(np.isfinite(grad))),
         "nlml": float(nlml),
         "results_finite": bool(np.all(np.isfinite(mu)) and np.all(var > 0)),
     }
