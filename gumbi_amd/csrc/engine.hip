@@ -1194,7 +1194,7 @@ constexpr int GACC_DOUBLES = 64 + MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS + 6
 // Device part of the gradient: inverse, alpha, Sigma^-1 and the trace reductions over the block
 // rows shard, shard + nshards, ... of the lower triangle; `h` receives the raw accumulators (they
 // are sums over tiles, so shards of several GPUs add up).
-int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& h) {
+int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& h, bool external_u = false) {
   HIP_TRY(e, hipSetDevice(e->device));
   if (e->factor_consumed)
     return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
@@ -1210,8 +1210,10 @@ int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& 
   if (!e->dgpart && (rc = alloc(e, &e->dgpart, (int64_t)GACC_DOUBLES))) return rc;
   PhaseTimer tg(e);
   const int nt = (int)(e->Np / TILE);
+  // external_u: the caller (multi-GPU driver) has already put U = L^-T into the upper triangle of
+  // the factor buffer and alpha into dalpha (gmb_inv_rows on every rank + all-gather)
   // 0. inverses of all diagonal factor blocks, one workgroup each (kept off the Cholesky's chain)
-  {
+  if (!external_u) {
     InvArgs ia;
     ia.L = e->dA;
     ia.lda = e->ld;
@@ -1229,14 +1231,16 @@ int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& 
   // 1. W = L^-1 (dW, lower) and U = L^-T (factor buffer, upper); the factor is consumed from here on
   e->factor_consumed = true;
   e->sync_next = 0;
-  if (e->par_inverse) {
-    if ((rc = winv_levels(e, nt))) return rc;
-  } else if ((rc = winv_cols(e, 0, nt))) {
-    return rc;
+  if (!external_u) {
+    if (e->par_inverse) {
+      if ((rc = winv_levels(e, nt))) return rc;
+    } else if ((rc = winv_cols(e, 0, nt))) {
+      return rc;
+    }
+    // 2. alpha = W^T v = Sigma^-1 y   (before Sigma^-1 overwrites W)
+    hipLaunchKernelGGL(wt_v_kernel, dim3((unsigned)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->dW, e->Np,
+                       e->dv, e->N, e->dalpha);
   }
-  // 2. alpha = W^T v = Sigma^-1 y   (before Sigma^-1 overwrites W)
-  hipLaunchKernelGGL(wt_v_kernel, dim3((unsigned)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->dW, e->Np,
-                     e->dv, e->N, e->dalpha);
   if (e->Np > e->N)
     hipLaunchKernelGGL(reset_pad_cols_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, e->stream,
                        e->dA, e->ld, e->N, e->Np);
@@ -1735,6 +1739,56 @@ int gmb_nlml_shard(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, i
     return fail(e, GMB_EINVAL, "bad gradient shard arguments");
   std::vector<double> h;
   if ((rc = grad_accumulate(e, shard, nshards, h))) return rc;
+  std::memcpy(acc, h.data(), GACC_DOUBLES * sizeof(double));
+  return GMB_OK;
+}
+
+// Block rows first, first + stride, ... of U = L^-T into V (device; V[t*128 + i + c*ldv], c < Np):
+// the predict solve V <- V L^-T applied to the matching rows of the identity, and this rank's
+// share alpha_i = sum_k U[i][k] v[k] of alpha = Sigma^-1 y.
+int gmb_inv_rows(gmb_engine* e, int32_t first, int32_t stride, double* V, int64_t ldv, double* alpha_rows) {
+  int rc = require_ready(e, true);
+  if (rc) return rc;
+  const int nt = (int)(e->Np / TILE);
+  if (!V || !alpha_rows || stride < 1 || first < 0 || first >= stride) return fail(e, GMB_EINVAL, "bad inverse-rows arguments");
+  const int owned = first < nt ? (nt - first + stride - 1) / stride : 0;
+  if (ldv < (int64_t)owned * TILE) return fail(e, GMB_EINVAL, "ldv too small for the owned rows");
+  if (owned == 0) return GMB_OK;
+  if (e->factor_consumed) return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemsetAsync(V, 0, (size_t)ldv * e->Np * sizeof(double), e->stream));
+  hipLaunchKernelGGL(identity_rows_kernel, dim3(owned), dim3(TILE), 0, e->stream, V, ldv, first, stride);
+  HIP_TRY(e, hipGetLastError());
+  e->cur = e->stream;
+  if ((rc = trsm_cols(e, V, ldv, owned, 0, nt, 4, 6))) return rc;
+  hipLaunchKernelGGL(urows_v_kernel, dim3(owned * 2), dim3(256), 0, e->stream, V, ldv, e->dv, e->N, alpha_rows);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  ev_collect(e);
+  return GMB_OK;
+}
+
+// Where the multi-GPU driver assembles U (upper triangle of the factor buffer, leading dimension ld)
+// and alpha (Np doubles) before gmb_nlml_shard_u.
+int gmb_grad_buffers(gmb_engine* e, void** alpha) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (e->cap_pts_alpha < e->Np) {
+    if ((rc = alloc(e, &e->dalpha, e->Np))) return rc;
+    e->cap_pts_alpha = e->Np;
+  }
+  if (alpha) *alpha = e->dalpha;
+  return GMB_OK;
+}
+
+int gmb_nlml_shard_u(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc) {
+  int rc = require_ready(e, true);
+  if (rc) return rc;
+  if (!acc || nacc < (int32_t)GACC_DOUBLES || nshards < 1 || shard < 0 || shard >= nshards)
+    return fail(e, GMB_EINVAL, "bad gradient shard arguments");
+  std::vector<double> h;
+  if ((rc = grad_accumulate(e, shard, nshards, h, true))) return rc;
   std::memcpy(acc, h.data(), GACC_DOUBLES * sizeof(double));
   return GMB_OK;
 }

@@ -245,6 +245,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
     if (c0 + tx < cols && r0 + j < rows) dst[(c0 + tx) + (int64_t)(r0 + j) * ldd] = tile[tx][j];
 }
 
+// Multi-GPU inverse: a rank's block rows of the identity (block t of V is global block row
+// first + t*stride), the right-hand side of V <- V L^-T that yields its rows of U = L^-T ...
+__global__ void identity_rows_kernel(double* V, int64_t ldv, int first, int stride) {
+  const int t = blockIdx.x, i = threadIdx.x;
+  const int64_t col = ((int64_t)first + (int64_t)t * stride) * TILE + i;
+  V[(int64_t)t * TILE + i + col * ldv] = 1.0;
+}
+// ... and its share of alpha = U v: 64 rows x 4 k-phases per workgroup, fixed summation order
+__global__ __launch_bounds__(256) void urows_v_kernel(const double* __restrict__ V, int64_t ldv,
+                                                      const double* __restrict__ v, int64_t n,
+                                                      double* __restrict__ alpha_rows) {
+  __shared__ double part[4][64];
+  const int r = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 64 + r;
+  double s = 0.0;
+  for (int64_t k = ph; k < n; k += 4) s = fma(V[row + k * ldv], v[k], s);
+  part[ph][r] = s;
+  __syncthreads();
+  if (ph == 0) alpha_rows[row] = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+}
+
 // Batched transposes (one level of the inverse tree): blockIdx.z selects the descriptor.
 struct TransposeJob {
   const double* src;

@@ -258,6 +258,9 @@ class DistributedEngine:
         self.stream = torch.cuda.Stream(self.device)
         self.eng = Engine(device_index, stream=self.stream.cuda_stream)
         self.ops = None
+        # True: L^-T is computed by rows across the ranks (scales with the group size);
+        # False: every rank inverts the factor itself and only Sigma^-1 is sharded
+        self.partition_inverse = True
 
     def set_data(self, X, y):
         self.eng.set_data(X, y)
@@ -286,11 +289,46 @@ class DistributedEngine:
             return self.eng.nlml()
         torch = self.torch
         with torch.cuda.stream(self.stream):
-            acc = self.eng.nlml_shard(self.comm.rank, self.comm.world)
+            if self.partition_inverse and self.comm.world > 1:
+                acc = self._grad_partitioned()
+            else:
+                acc = self.eng.nlml_shard(self.comm.rank, self.comm.world)
             t = torch.as_tensor(acc, device=self.device)
             self.comm.all_reduce(t, "sum")
             acc = t.cpu().numpy()
         return self.eng.nlml_from_acc(acc)
+
+    def _grad_partitioned(self):
+        """L^-T by rows: rank r solves for ITS block rows of U (``gmb_inv_rows``, N^3/G flops, no
+        communication), one all-gather delivers all of U and alpha to every rank (8 N^2 bytes in total),
+        then each rank forms its block rows of Sigma^-1 = U U^T and reduces over them."""
+        torch = self.torch
+        eng, G, r = self.eng, self.comm.world, self.comm.rank
+        b = eng.factor_buffers()
+        Np, ld = b["Np"], b["ld"]
+        nt = Np // BLK
+        maxown = (nt + G - 1) // G
+        ldv = maxown * BLK
+        V = torch.empty(Np * ldv, dtype=torch.float64, device=self.device)      # V[m + c*ldv]
+        a_loc = torch.zeros(ldv, dtype=torch.float64, device=self.device)
+        self.stream.synchronize()
+        eng.inv_rows(r, G, V.data_ptr(), ldv, a_loc.data_ptr())
+        recvV = torch.empty(G * Np * ldv, dtype=torch.float64, device=self.device)
+        recva = torch.empty(G * ldv, dtype=torch.float64, device=self.device)
+        self.comm.all_gather(recvV, V)
+        self.comm.all_gather(recva, a_loc)
+        # scatter the gathered block rows into the upper triangle of the factor buffer (U[i][k] at
+        # i + k*ld) and into alpha; the factor is consumed by the gradient anyway
+        A = torch.as_tensor(_RawDeviceArray(b["A"], Np * ld), device=self.device).view(Np, ld)
+        alpha = torch.as_tensor(_RawDeviceArray(eng.grad_alpha_ptr(), Np), device=self.device)
+        for q in range(G):
+            Vq = recvV[q * Np * ldv:(q + 1) * Np * ldv].view(Np, ldv)
+            for t in range((nt - q + G - 1) // G if q < nt else 0):
+                g0 = (q + t * G) * BLK
+                A[:, g0:g0 + BLK].copy_(Vq[:, t * BLK:(t + 1) * BLK])
+                alpha[g0:g0 + BLK].copy_(recva[q * ldv + t * BLK:q * ldv + (t + 1) * BLK])
+        self.stream.synchronize()
+        return eng.nlml_shard_u(r, G)
 
     def predict(self, Xs, with_noise=True):
         """Every rank passes the same ``Xs``; rank r predicts ``np.array_split`` slice r and the

@@ -174,6 +174,9 @@ _SIGNATURES = {
     "gmb_copy_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _DBL_P]),
     "gmb_copy_v": (C.c_int, [C.c_void_p, _DBL_P]),
     "gmb_blk_potrf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmb_inv_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gmb_grad_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gmb_nlml_shard_u": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]),
     "gmb_grad_acc_size": (C.c_int32, []),
     "gmb_nlml_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]),
     "gmb_nlml_from_acc": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double),
@@ -401,6 +404,23 @@ class Engine:
         n = int(self._lib.gmb_grad_acc_size())
         acc = np.zeros(n, dtype=np.float64)
         self._check(self._lib.gmb_nlml_shard(self._h, shard, nshards, _dptr(acc), n), "gmb_nlml_shard")
+        return acc
+
+    def inv_rows(self, first: int, stride: int, v_ptr: int, ldv: int, alpha_ptr: int):
+        """This rank's block rows of U = L^-T into the device buffer ``v_ptr`` and its rows of alpha."""
+        self._check(self._lib.gmb_inv_rows(self._h, first, stride, C.c_void_p(v_ptr), ldv, C.c_void_p(alpha_ptr)),
+                    "gmb_inv_rows")
+
+    def grad_alpha_ptr(self) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.gmb_grad_buffers(self._h, C.byref(p)), "gmb_grad_buffers")
+        return int(p.value)
+
+    def nlml_shard_u(self, shard: int, nshards: int) -> np.ndarray:
+        """As :meth:`nlml_shard`, with U and alpha already assembled in the engine's buffers."""
+        n = int(self._lib.gmb_grad_acc_size())
+        acc = np.zeros(n, dtype=np.float64)
+        self._check(self._lib.gmb_nlml_shard_u(self._h, shard, nshards, _dptr(acc), n), "gmb_nlml_shard_u")
         return acc
 
     def nlml_from_acc(self, acc):

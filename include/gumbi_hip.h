@@ -169,6 +169,15 @@ int gmb_ls_limits(int32_t device, const double* X, int64_t N, int32_t n_cols, in
  * the raw accumulators (gmb_grad_acc_size() doubles, host).  They are plain sums over tiles: the
  * driver all-reduces them and every rank finishes with gmb_nlml_from_acc (chain rule to the packed
  * parameters, same layout as gmb_nlml's grad).  gmb_nlml(e, &v, grad) == shard 0 of 1 + from_acc. */
+/* Fully partitioned variant: gmb_inv_rows gives a rank ITS block rows first, first+stride, ... of
+ * U = L^-T (V: device, (owned*128) x Np column-major with leading dimension ldv; the predict solve
+ * applied to rows of the identity, N^3/G flops) and its rows of alpha = U v (device, owned*128
+ * doubles); the driver all-gathers both into the upper triangle of every rank's factor buffer
+ * (gmb_factor_buffers) and into the alpha vector (gmb_grad_buffers), then gmb_nlml_shard_u does
+ * the rank's share of Sigma^-1 and of the reductions without inverting anything itself. */
+int gmb_inv_rows(gmb_engine* e, int32_t first, int32_t stride, double* V, int64_t ldv, double* alpha_rows);
+int gmb_grad_buffers(gmb_engine* e, void** alpha);
+int gmb_nlml_shard_u(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc);
 int32_t gmb_grad_acc_size(void);
 int gmb_nlml_shard(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc);
 int gmb_nlml_from_acc(gmb_engine* e, const double* acc, int32_t nacc, double* nlml, double* grad);

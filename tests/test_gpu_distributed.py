@@ -45,6 +45,11 @@ def _worker(rank, world, port, N, d, M, out):
         val, g = eng.nlml(grad=True)
         val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
         err_g = max(abs(val - val_r) / abs(val_r), np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r))))
+        # the replicated-inverse variant (only Sigma^-1 sharded) must agree with the partitioned one
+        eng.partition_inverse = False
+        eng.factorize()
+        val2, g2 = eng.nlml(grad=True)
+        err_g = max(err_g, np.max(np.abs(g2 - g)) / max(1.0, np.max(np.abs(g))) * 1e2)  # 1e-10 relative
         out.put((rank, err_L, err_v, err_nl, err_mu, err_var, err_g, g.tobytes()))
         eng.close()
     finally:
