@@ -528,7 +528,8 @@ class Regressor(ABC):
         train_ds = DataSet(train_df, **ds_specs)
         test_ds = DataSet(test_df, **ds_specs)
 
-        train_obj = self.__class__(train_ds, outputs=self.outputs, seed=seed)
+        dev_kw = {"device": self.device} if hasattr(self, "device") else {}  # stay on this instance's GPU
+        train_obj = self.__class__(train_ds, outputs=self.outputs, seed=seed, **dev_kw)
         train_obj.specify_model(**_restricted(train_df))
         train_obj.filter_dims = self.filter_dims
         train_obj.build_model(**self.model_specs)
@@ -543,11 +544,40 @@ class Regressor(ABC):
 
         train_nlpd, train_err = _score(train_obj, train_obj)
         if len(test_df.index.unique()) > 0:
-            test_obj = self.__class__(test_ds, outputs=self.outputs, seed=seed)
+            test_obj = self.__class__(test_ds, outputs=self.outputs, seed=seed, **dev_kw)
             test_obj.specify_model(**_restricted(test_df))
             test_obj.filter_dims = self.filter_dims
             test_nlpd, test_err = _score(test_obj, train_obj)
         else:
             test_nlpd, test_err = np.nan, np.nan
+        engine = getattr(train_obj, "engine", None)
+        if engine is not None:
+            engine.close()  # the split's factor buffers go back to the device
         return {"train": {"data": train_ds, "NLPDs": train_nlpd, "errors": train_err},
                 "test": {"data": test_ds, "NLPDs": test_nlpd, "errors": test_err}}
+
+    def cross_validate_replicas(self, seeds, **kwargs):
+        """Independent :meth:`cross_validate` splits, one per seed, as replica-parallel jobs: with an
+        initialised ``torch.distributed`` process group (one process per GPU) the seeds are dealt
+        round-robin over the ranks -- no data-path communication, each fit runs on the rank's own GPU --
+        and every rank receives the complete list of results in seed order.  Without a process group
+        the splits simply run one after the other.  (the folds of a
+        cross-validation are independent GPs.)"""
+        seeds = list(seeds)
+        rank, world, dist = 0, 1, None
+        try:
+            import torch.distributed as dist_mod
+
+            if dist_mod.is_available() and dist_mod.is_initialized():
+                dist, rank, world = dist_mod, dist_mod.get_rank(), dist_mod.get_world_size()
+        except ImportError:
+            pass
+        mine = {i: self.cross_validate(seed=seeds[i], **kwargs) for i in range(rank, len(seeds), world)}
+        if dist is None:
+            return [mine[i] for i in range(len(seeds))]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        merged = {}
+        for part in gathered:
+            merged.update(part)
+        return [merged[i] for i in range(len(seeds))]

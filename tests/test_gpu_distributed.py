@@ -139,3 +139,60 @@ def test_distributed_map_fit_matches_single_gpu_fit(gpu):
     for rank, err_th, err_mu, err_var, n_d, n_s, _ in results:
         assert err_th < 1e-5 and err_mu < 1e-6 and err_var < 1e-6
     assert results[0][-1] == results[1][-1]
+
+
+def _cv_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pandas as pd
+
+        import gumbi_amd as gmb
+        from oracle import gp_oracle as O
+
+        X, y, _ = O.synthetic_table(300, 2, seed=4)
+        df = pd.DataFrame(X, columns=["a", "b"])
+        df["y"] = y
+        gp = gmb.GP(gmb.DataSet(df, outputs=["y"]), outputs=["y"])
+        gp.specify_model(continuous_dims=["a", "b"])
+        gp.build_model()
+        res = gp.cross_validate_replicas([11, 12, 13], pct_train=0.7)
+        out.put((rank, [float(r["test"]["NLPDs"].mean()) for r in res], [len(r["train"]["data"].wide) for r in res]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cross_validation_replicas_over_ranks(gpu):
+    """Three independent splits dealt over two ranks: both ranks end up with all three results, equal
+    to what one process computes alone."""
+    import pandas as pd
+    import torch.multiprocessing as mp
+
+    import gumbi_amd as gmb
+    from oracle import gp_oracle as O
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cv_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1:] == results[1][1:]
+    X, y, _ = O.synthetic_table(300, 2, seed=4)
+    df = pd.DataFrame(X, columns=["a", "b"])
+    df["y"] = y
+    gp = gmb.GP(gmb.DataSet(df, outputs=["y"]), outputs=["y"])
+    gp.specify_model(continuous_dims=["a", "b"])
+    gp.build_model()
+    alone = gp.cross_validate_replicas([11, 12, 13], pct_train=0.7)
+    # (MAP optima agree to the optimiser's tolerance, not bitwise: the trace reductions use atomics)
+    assert np.allclose([float(r["test"]["NLPDs"].mean()) for r in alone], results[0][1], rtol=1e-4)
+    assert [len(r["train"]["data"].wide) for r in alone] == results[0][2] == [210, 210, 210]
