@@ -250,6 +250,32 @@ def test_predict_edge_cases(gpu):
     assert rel(mu, O.predict(spec, theta2, X, y, X[:50], dist_mode="direct")[0]) < 1e-10
 
 
+def test_colliding_inputs_and_tiny_noise(gpu):
+    """Exactly repeated rows make K rank-deficient: only sigma^2 + jitter keeps Sigma positive definite.
+    The factor, NLML, gradient and predictions must still follow the oracle (the jitter is part of
+    the model, pymc/GP.py:580 -> 1e-6 on the diagonal), with the tolerance scaled by the conditioning."""
+    X, y, ls = O.synthetic_table(260, 2, seed=13)
+    X[130:] = X[:130]                      # every point appears twice
+    y[130:] = y[:130] + 0.01
+    spec = O.make_spec(2, range(2))
+    theta = O.pack_theta(spec, ls, 1.0, 1e-2)   # sigma^2 = 1e-4: cond(Sigma) ~ 2.6e6
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    val, g = eng.nlml(grad=True)
+    val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+    assert np.isclose(val, val_r, rtol=1e-9)
+    assert np.max(np.abs(g - g_r)) < 1e-6 * max(1.0, np.max(np.abs(g_r)))
+    eng.factorize()
+    Xs = np.random.default_rng(0).standard_normal((300, 2))
+    mu, var = eng.predict(Xs)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+    assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-8
+    # sigma -> 0: jitter alone (1e-6) on a doubled data set -- still factorises, like the reference does
+    eng.set_theta(O.pack_theta(spec, ls, 1.0, 1e-9))
+    eng.factorize()
+    assert np.isfinite(eng.nlml())
+
+
 def test_not_positive_definite_raises_linalgerror(gpu):
     X, y, ls = O.synthetic_table(150, 2, seed=9)
     X[77, 0] = np.nan
