@@ -792,6 +792,35 @@ int chol_lookahead_full(gmb_engine* e) {
   return GMB_OK;
 }
 
+// Plain right-looking panels on ONE stream, no look-ahead (scheme 3): since the chain and the bulk
+// update serialise in practice, one merged update per panel has the better tile quantisation.
+int chol_panels_serial(gmb_engine* e) {
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  const int w = e->panel_blocks;
+  int rc;
+  e->cur = e->stream;
+  for (int c0 = 0; c0 < nct; c0 += w) {
+    const int c1 = std::min(c0 + w, nct);
+    if ((rc = chol_cols(e, c0, c1, nrt))) return rc;
+    if (c1 >= nct) break;
+    GemmArgs g{};
+    g.C = e->dA + (int64_t)c1 * TILE + (int64_t)c1 * TILE * e->ld;
+    g.ldc = e->ld;
+    g.A = e->dA + (int64_t)c1 * TILE + (int64_t)c0 * TILE * e->ld;
+    g.lda = e->ld;
+    g.B = g.A;
+    g.ldb = e->ld;
+    g.mt = nct - c1;
+    g.nt = nrt - c1;
+    g.k = (c1 - c0) * TILE;
+    g.alpha = -1.0;
+    g.beta = 1.0;
+    g.tri = 1;
+    if ((rc = launch_gemm(e, g, 0))) return rc;
+  }
+  return GMB_OK;
+}
+
 // Full-height chain on the MAIN stream, U2 on the CU-masked stream (scheme 2).
 int chol_lookahead_masked(gmb_engine* e) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
@@ -1505,7 +1534,7 @@ void gmb_destroy(gmb_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->dchain, e->dsync, e->dsignal, e->dplan_gemm, e->dplan_tr, e->dsched, e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
+  void* ptrs[] = {e->dchain_stamps, e->dchain, e->dsync, e->dsignal, e->dplan_gemm, e->dplan_tr, e->dsched, e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv,  e->dV,    e->dXs,  e->txs,    e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
   for (void* p : ptrs)
@@ -1657,7 +1686,7 @@ int gmb_factorize(gmb_engine* e) {
   // 2. Cholesky
   PhaseTimer tc(e);
   if (e->lookahead && e->Np / TILE > e->panel_blocks) {
-    if ((rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : (e->chol_scheme == 2 ? chol_lookahead_masked(e) : chol_lookahead(e))))) return rc;
+    if ((rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : (e->chol_scheme == 2 ? chol_lookahead_masked(e) : (e->chol_scheme == 3 ? chol_panels_serial(e) : chol_lookahead(e)))))) return rc;
   } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) {
     return rc;
   }
