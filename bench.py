@@ -313,6 +313,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    mean_host = mean_dev.cpu().numpy()
+    var_host = var_dev.cpu().numpy()
+    finite = bool(np.all(np.isfinite(mean_host)) and np.all(var_host > 0))
+    # the headline engine's streams go away before the distributed section creates its own: more
+    # than four live HIP streams per process slow every kernel down on this stack
+    eng.close()
+    gp.engine = None
+
     dist_info = None
     if os.environ.get("GUMBI_BENCH_NO_DIST") != "1" and args.config == "c2":
         try:
@@ -321,9 +329,6 @@ def main():
             dist_info = {"error": f"{type(err).__name__}: {err}"[:300]}
 
     flops_total = sum(step_flops(cfg["N"], M, n) for n in n_evals) * world
-    mean_host = mean_dev.cpu().numpy()
-    var_host = var_dev.cpu().numpy()
-    finite = bool(np.all(np.isfinite(mean_host)) and np.all(var_host > 0))
 
     if rank == 0:
         gemm_tf = tm["total_gemm_flops"] / max(tm["total_gemm_ms"], 1e-9) / 1e9

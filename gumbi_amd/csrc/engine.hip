@@ -144,6 +144,8 @@ struct gmb_engine {
   const double* chain_A = nullptr;
   int chain_w = 0;
   long long* dchain_stamps = nullptr;
+  unsigned int column_seq = 0;   // fused leaf+strip column kernel: flag value of the next launch
+  bool fused_column = false;  // measured: 55 us per column against 37 + 11 + gap = 53 us as two launches
   int chain_dbg_panel = -1;
   std::vector<ChainOp> chain_host;  // host copy of the op lists (debug prints)
 
@@ -639,6 +641,27 @@ int chol_leaf(gmb_engine* e, int c, int rend) {
   a.info = e->dinfo;
   a.row0 = (int64_t)c * TILE;
   a.dbg = nullptr;
+  const int64_t rows_below = (int64_t)(rend - c - 1) * TILE;
+  if (e->fused_column && !e->rec && !e->naive_leaf && e->dsync && rows_below > 0) {
+    // leaf + strip as one launch (chol_column_kernel)
+    ColumnArgs ca;
+    ca.leaf = a;
+    ca.trsm.B = e->dA + (int64_t)(c + 1) * TILE + (int64_t)c * TILE * e->ld;
+    ca.trsm.ldb = e->ld;
+    ca.trsm.nrows = rows_below;
+    ca.trsm.L = a.A;
+    ca.trsm.ldl = e->ld;
+    ca.trsm.dinv16 = a.dinv16;
+    ca.trsm.nvalid = a.nvalid;
+    ca.flag = &e->dsync->colflag;
+    ca.seq = ++e->column_seq;
+    ca.abort_flag = &e->dsync->abort;
+    ev_begin(e, 1, 0.0);
+    hipLaunchKernelGGL(chol_column_kernel, dim3((unsigned)(1 + (rows_below / 16 + 7) / 8)), dim3(512), 0, e->cur, ca);
+    ev_end(e);
+    HIP_TRY(e, hipGetLastError());
+    return GMB_OK;
+  }
   int rc = launch_leaf(e, a);
   if (rc) return rc;
   // panel rows below the diagonal block:  P <- P inv(L_cc)^T   (in place, 16 rows per wavefront)
@@ -1500,6 +1523,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
       const int wgs = prop.multiProcessorCount - e->reserve_cus;
       e->persist_wgs = (e->reserve_cus > 0 && wgs >= 64) ? (wgs / 8) * 8 : 0;
     }
+    const char* fc = getenv("GMB_FUSED_COLUMN");  // tuning: 1 = leaf and strip as one launch (chol_column_kernel)
+    e->fused_column = fc && fc[0] == '1';
     const char* ck = getenv("GMB_CHAIN_KERNEL");
     e->chain_kernel = ck && ck[0] == '1';
     const char* cc = getenv("GMB_CHAIN_CUS");
@@ -1700,7 +1725,7 @@ int gmb_factorize(gmb_engine* e) {
   HIP_TRY(e, hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
   ChainSync hsync{};
-  if (e->chain_kernel && e->dsync)
+  if ((e->chain_kernel || e->fused_column) && e->dsync)
     HIP_TRY(e, hipMemcpyAsync(&hsync, e->dsync, sizeof(ChainSync), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   if (e->chain_dbg_panel >= 0 && e->dchain_stamps) {
@@ -1719,7 +1744,7 @@ int gmb_factorize(gmb_engine* e) {
   if (hsync.abort) {
     (void)hipMemset(e->dsync, 0, sizeof(ChainSync));
     ev_collect(e);
-    return fail(e, GMB_EHIP, "panel chain kernel: grid barrier watchdog fired (workgroups not co-resident?)");
+    return fail(e, GMB_EHIP, "fused Cholesky kernel: watchdog fired while waiting for another workgroup");
   }
   tm.kbuild_ms = tk.ms();
   tm.chol_ms = tc.ms();

@@ -46,6 +46,8 @@ struct ChainSync {
   unsigned int xgen[8];    // per XCD: generation, flipped by the XCD's leader once its L2 is coherent again
   unsigned int xwgs[8];    // per XCD: chain workgroups resident there
   unsigned int reg[8];     // registration scratch of the first barrier
+  unsigned int colflag;    // chol_column_kernel: sequence number of the last finished leaf
+  unsigned int pad[3];
 };
 
 __device__ __forceinline__ unsigned int chain_xcc_id() {
@@ -186,6 +188,48 @@ __global__ __launch_bounds__(512, 2) void panel_chain_kernel(const ChainOp* __re
     if (!chain_barrier(sync, xcd)) return;
     if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[2 * i + 2] = wall_clock64();  // barrier passed
   }
+}
+
+// ---- one block column of the Cholesky as ONE launch ---------------------------------------------
+// Workgroup 0 factors the diagonal block; the other workgroups (128 rows each, one 16-row slab per
+// wavefront) load their panel rows at once, wait for a flag and then run the strip solve.  Saves
+// the launch gap between leaf and strip and hides the strip's panel loads behind the leaf.
+// Cache coherence: the flag is an agent-scope atomic; the leaf workgroup writes its XCD's L2 back
+// before it raises it.  The waiting wavefronts need no invalidate of their own: every cache was
+// invalidated when this kernel was dispatched and nothing on their side touches the diagonal block
+// or its sub-block inverses before the flag (the panel rows are different cache lines).
+struct ColumnArgs {
+  LeafArgs leaf;
+  TrsmArgs trsm;
+  unsigned int* flag;
+  unsigned int seq;
+  unsigned int* abort_flag;
+};
+
+__global__ __launch_bounds__(512) void chol_column_kernel(ColumnArgs g) {
+  if (blockIdx.x == 0) {
+    potrf_leaf_body<8>(g.leaf);  // ends with a workgroup barrier: every wave's stores are acknowledged
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(g.flag, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  __builtin_amdgcn_s_setprio(3);
+  const int64_t r0 = (((int64_t)blockIdx.x - 1) * 8 + (threadIdx.x >> 6)) * 16;
+  if (r0 >= g.trsm.nrows) return;
+  strip_d4 X[8];
+  trsm_strip_load(g.trsm, r0, X);
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(g.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.seq) {
+    __builtin_amdgcn_s_sleep(24);  // ~0.7 us: ~1300 wavefronts poll one address, keep them off the fabric
+    if (wall_clock64() - t0 > 200000000LL) {  // 2 s: the leaf never came -- give up instead of hanging
+      __hip_atomic_store(g.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  trsm_strip_solve_store(g.trsm, r0, X);
 }
 
 }  // namespace gmb

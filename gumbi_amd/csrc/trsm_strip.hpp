@@ -34,17 +34,25 @@ struct TrsmArgs {
                          // the buffer holds there -- the y row of the factor buffer -- is ignored)
 };
 
-// one 16-row slab (rows r0 .. r0+15) by the calling wavefront
-__device__ __forceinline__ void trsm_strip_slab(const TrsmArgs& g, const int64_t r0) {
-  typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double strip_d4 __attribute__((ext_vector_type(4)));
+
+// The slab's eight 16 x 16 tiles in accumulator layout (independent of the diagonal block: a fused
+// kernel issues these loads before it waits for the leaf)
+__device__ __forceinline__ void trsm_strip_load(const TrsmArgs& g, const int64_t r0, strip_d4 (&X)[8]) {
   const int lane = threadIdx.x & 63;
   const int r16 = lane & 15, kq = lane >> 4;
-  double* Bp = g.B + r0 + r16;
-  d4 X[8];
+  const double* Bp = g.B + r0 + r16;
 #pragma unroll
   for (int s = 0; s < 8; ++s)
 #pragma unroll
     for (int q = 0; q < 4; ++q) X[s][q] = Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb];
+}
+
+__device__ __forceinline__ void trsm_strip_solve_store(const TrsmArgs& g, const int64_t r0, strip_d4 (&X)[8]) {
+  typedef strip_d4 d4;
+  const int lane = threadIdx.x & 63;
+  const int r16 = lane & 15, kq = lane >> 4;
+  double* Bp = g.B + r0 + r16;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const bool live = 16 * s + r16 < g.nvalid;
@@ -70,6 +78,13 @@ __device__ __forceinline__ void trsm_strip_slab(const TrsmArgs& g, const int64_t
   for (int s = 0; s < 8; ++s)
 #pragma unroll
     for (int q = 0; q < 4; ++q) Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb] = X[s][q];
+}
+
+// one 16-row slab (rows r0 .. r0+15) by the calling wavefront
+__device__ __forceinline__ void trsm_strip_slab(const TrsmArgs& g, const int64_t r0) {
+  strip_d4 X[8];
+  trsm_strip_load(g, r0, X);
+  trsm_strip_solve_store(g, r0, X);
 }
 
 __global__ __launch_bounds__(256) void trsm_strip_kernel(TrsmArgs g) {
