@@ -145,6 +145,7 @@ struct gmb_engine {
   int chain_w = 0;
   long long* dchain_stamps = nullptr;
   unsigned int column_seq = 0;   // fused leaf+strip column kernel: flag value of the next launch
+  bool strip_lds = false;     // GMB_STRIP_LDS=1: strip solves stage the diagonal block in LDS (measured 2% slower)
   bool fused_column = false;  // measured: 55 us per column against 37 + 11 + gap = 53 us as two launches
   int chain_dbg_panel = -1;
   std::vector<ChainOp> chain_host;  // host copy of the op lists (debug prints)
@@ -444,7 +445,10 @@ int launch_trsm_strip(gmb_engine* e, double* B, int64_t ldb, int64_t nrows, cons
     return GMB_OK;
   }
   ev_begin(e, ev_kind, (double)nrows * TILE * TILE);
-  hipLaunchKernelGGL(trsm_strip_kernel, dim3((unsigned)((nrows / 16 + 3) / 4)), dim3(256), 0, e->cur, t);
+  if (e->strip_lds)
+    hipLaunchKernelGGL(trsm_strip_lds_kernel, dim3((unsigned)((nrows / 16 + 3) / 4)), dim3(256), 0, e->cur, t);
+  else
+    hipLaunchKernelGGL(trsm_strip_kernel, dim3((unsigned)((nrows / 16 + 3) / 4)), dim3(256), 0, e->cur, t);
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -1523,6 +1527,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
       const int wgs = prop.multiProcessorCount - e->reserve_cus;
       e->persist_wgs = (e->reserve_cus > 0 && wgs >= 64) ? (wgs / 8) * 8 : 0;
     }
+    const char* sl = getenv("GMB_STRIP_LDS");
+    e->strip_lds = sl && sl[0] == '1';
     const char* fc = getenv("GMB_FUSED_COLUMN");  // tuning: 1 = leaf and strip as one launch (chol_column_kernel)
     e->fused_column = fc && fc[0] == '1';
     const char* ck = getenv("GMB_CHAIN_KERNEL");
