@@ -18,8 +18,11 @@ Model (non-additive, reference docstring :61-71 and code :711-729, :560-569)::
 Priors (:407, :409, :451-452, :460-461, :560): ls ~ InverseGamma(alpha, beta) from the pairwise
 distance rule; eta ~ Gamma(2,1); sigma ~ Exponential(1); c ~ N(0,10); tau ~ HalfNormal(10);
 W ~ N(0,3) with seeded initial value; kappa ~ Gamma(1.5,1).  ``find_MAP`` minimises, like
-``pm.find_MAP``, ``-(log-lik + log-priors + log-Jacobians)`` over the log of the positive
-parameters with L-BFGS-B (scipy -- the optimiser PyMC itself calls).
+``pm.find_MAP`` of PyMC >= 4, ``-(log-lik + log-priors)`` over the log of the positive parameters
+with L-BFGS-B (scipy -- the optimiser PyMC itself calls).  The log-Jacobians of the log transforms
+are NOT part of that objective (``model.compile_logp(jacobian=False)`` in pymc/tuning/starting.py;
+confirmed against the predictions printed in the reference's Multioutput_Regression notebook, see
+``HipGP.map_includes_jacobian``).
 """
 
 from __future__ import annotations
@@ -284,8 +287,13 @@ class HipGP(Regressor):
                 mask[sl] = True
         return mask
 
+    #: PyMC >= 4's ``find_MAP`` compiles ``model.logp(jacobian=False)`` (pymc/tuning/starting.py): the
+    #: log-Jacobians of the log transforms are NOT in the objective.  True restates PyMC3.
+    map_includes_jacobian = False
+
     def _objective(self, u, pos):
-        """-(log-lik + log-prior + log|d theta/du|) and its gradient w.r.t. the unconstrained u."""
+        """-(log-lik + log-prior [+ log|d theta/du|, see ``map_includes_jacobian``]) and its gradient
+        w.r.t. the unconstrained u (u = log theta for the positive parameters)."""
         theta = np.where(pos, np.exp(np.clip(u, -700, 700)), u)
         eng = self.engine
         try:
@@ -295,9 +303,10 @@ class HipGP(Regressor):
         except (np.linalg.LinAlgError, ValueError):
             return 1e100, np.zeros_like(u)
         lp, g_lp = self._log_prior(theta)
-        f = nlml - lp - np.sum(u[pos])
+        J = 1.0 if self.map_includes_jacobian else 0.0
+        f = nlml - lp - J * np.sum(u[pos])
         g = g_nlml - g_lp
-        g = np.where(pos, g * theta - 1.0, g)
+        g = np.where(pos, g * theta - J, g)
         if not np.isfinite(f):
             return 1e100, np.zeros_like(u)
         self.nlml_trace.append(float(nlml))

@@ -14,12 +14,20 @@ un-vendored third-party dependency **pymc** (``requirements.txt:6`` ``pymc>=5.3.
 container and cannot be.  This file therefore restates PyMC >= 5's *published* algorithm
 (``pymc.gp.cov``, ``pymc.gp.Marginal``) in numpy, anchored on Gumbi's call sites.
 
-PARITY STATUS: **parity unpinned** against PyMC itself -- the reference's own tests assert no
-posterior value for this path (``tests/test_regression.py:146-191`` are smoke tests) and PyMC
-cannot be run here.  The restatement is pinned instead by (i) an independent implementation,
-scikit-learn's ``GaussianProcessRegressor(optimizer=None)``, on every golden case
-(``tests/golden/make_gp_goldens.py``; agreement <= 1e-10), and (ii) finite-difference checks
-of the analytic NLML gradient (``tests/test_oracle.py``).
+PARITY STATUS: pinned against PyMC's own output at the precision the reference publishes, not
+at 1e-8.  The reference's tests assert no posterior value for this path
+(``tests/test_regression.py:146-191`` are smoke tests) and PyMC cannot be run here, but the
+reference's notebook ``docs/source/notebooks/examples/Multioutput_Regression.ipynb`` -- run by its
+author on PyMC 5 (its first cell prints a pytensor warning) on the package's own example data set
+-- prints the predictive means and variances of a MAP fit of the full composite model (RBF +
+linear kernel x output coregion x heteroskedastic output noise).  ``tests/test_oracle_notebook.py``
+replays those calls with this oracle as the numeric engine and reproduces the printed means to
+1e-4 .. 1e-3 in the interior of the grid (<= 6e-3 at its extrapolating ends) and the variances to
+<= 5 %; the same replay discriminates the two readings of ``pm.find_MAP``'s objective (see
+``log_prior_and_jacobian``).  Everything finer than that precision is pinned by (i) an independent
+implementation, scikit-learn's ``GaussianProcessRegressor(optimizer=None)``, on every golden case
+(``tests/golden/make_gp_goldens.py``; agreement <= 1e-10), and (ii) finite-difference checks of
+the analytic NLML gradient (``tests/test_oracle.py``).
 
 Formulas (PyMC >= 5)
 --------------------
@@ -489,7 +497,7 @@ def parse_ls_limits(X, ARD, lower=None, upper=None):
 
 
 # ----------------------------------------------------------------------------------------
-# MAP objective pieces: log-priors + log-Jacobians in the unconstrained space
+# MAP objective pieces: log-priors (+ optionally the log-Jacobians of the log transforms)
 # (priors at pymc/GP.py:407,409,451-452,460-461,560; PyMC optimises log-transformed
 # positive variables, so each contributes log|d theta/d u| = u = log theta)
 # ----------------------------------------------------------------------------------------
@@ -519,18 +527,28 @@ def logp_halfnormal(x, sd):
     return 0.5 * np.log(2.0 / np.pi) - np.log(sd) - 0.5 * (x / sd) ** 2
 
 
-def log_prior_and_jacobian(spec, theta, ls_alpha, ls_beta):
-    """Sum of log-prior densities and log-Jacobians of the log transforms, as PyMC's
-    ``model.logp`` (jacobian=True) adds to the likelihood in ``find_MAP``."""
+def log_prior_and_jacobian(spec, theta, ls_alpha, ls_beta, jacobian=False):
+    """Sum of the log-prior densities that ``pm.find_MAP`` adds to the likelihood.
+
+    PyMC >= 4 (the reference requires pymc >= 5.3.1) builds the MAP objective with
+    ``model.compile_logp(jacobian=False)`` (``pymc/tuning/starting.py: find_MAP``): the optimiser
+    works on the log-transformed variables but the log-Jacobians of the transforms are NOT part of
+    the objective, i.e. the optimum is the mode of the density over the natural parameters.
+    ``jacobian=True`` restates the PyMC3 behaviour (mode of the density over the transformed ones).
+    Evidence beyond the source reading: the reference's Multioutput_Regression notebook (run by its
+    author on PyMC 5 -- its first cell shows a pytensor warning) prints predictive means / variances
+    that the ``jacobian=False`` objective reproduces to 1e-4 / 4 %, the other one to 5e-3 / 36 %
+    (``tests/test_gpu_frontend.py``, ``tools/gpu_notebook_check2.py``)."""
     p = unpack_theta(spec, theta)
     a = np.asarray(ls_alpha, float)
     b = np.asarray(ls_beta, float)
-    tot = np.sum(logp_inverse_gamma(p["ls"], a, b) + np.log(p["ls"]))
-    tot += logp_gamma(p["eta"], 2.0, 1.0) + np.log(p["eta"])
-    tot += logp_exponential(p["sigma"], 1.0) + np.log(p["sigma"])
+    J = 1.0 if jacobian else 0.0
+    tot = np.sum(logp_inverse_gamma(p["ls"], a, b) + J * np.log(p["ls"]))
+    tot += logp_gamma(p["eta"], 2.0, 1.0) + J * np.log(p["eta"])
+    tot += logp_exponential(p["sigma"], 1.0) + J * np.log(p["sigma"])
     if spec["idx_lin"]:
         tot += np.sum(logp_normal(p["c"], 0.0, 10.0))
-        tot += logp_halfnormal(p["tau"], 10.0) + np.log(p["tau"])
+        tot += logp_halfnormal(p["tau"], 10.0) + J * np.log(p["tau"])
     pairs = list(p["coreg"])
     if spec["out_col"] >= 0:
         pairs.append((p["W_out"], p["kappa_out"]))
@@ -538,7 +556,7 @@ def log_prior_and_jacobian(spec, theta, ls_alpha, ls_beta):
             pairs.append((p["W_noise"], p["kappa_noise"]))
     for W, kap in pairs:
         tot += np.sum(logp_normal(W, 0.0, 3.0))
-        tot += np.sum(logp_gamma(kap, 1.5, 1.0) + np.log(kap))
+        tot += np.sum(logp_gamma(kap, 1.5, 1.0) + J * np.log(kap))
     return float(tot)
 
 

@@ -47,3 +47,20 @@ for trial in range(8):
     gp.engine.set_theta(th); gp.engine.factorize(); gp._theta_fitted = th; gp.MAP = gp._theta_to_dict(th)
     p = gp.predict_points(point)
     print(f"trial {trial}: obj {res.fun:.6f}  point mu {float(np.asarray(p.μ).ravel()[0]):.6f} s2 {float(np.asarray(p.σ2).ravel()[0]):.6f}  ls {np.round(th[:3],4)} eta {th[3]:.4f} sigma {th[4]:.4f}")
+
+# hypothesis: pm.find_MAP (PyMC >= 4) optimises logp WITHOUT the transforms' Jacobians
+def obj_nojac(u, pos):
+    f, g = gp._objective(u, pos)
+    f = f + np.sum(u[pos])          # remove the  -sum(u)  Jacobian term
+    g = g.copy(); g[pos] += 1.0
+    return f, g
+u0 = th0.copy(); u0[pos] = np.log(th0[pos])
+res = minimize(obj_nojac, u0, args=(pos,), jac=True, method="L-BFGS-B", options={"maxfun": 500})
+th = np.where(pos, np.exp(res.x), res.x)
+gp.engine.set_theta(th); gp.engine.factorize(); gp._theta_fitted = th; gp.MAP = gp._theta_to_dict(th)
+p = gp.predict_points(point)
+print("NO-JACOBIAN MAP: point", float(np.asarray(p.μ).ravel()[0]), float(np.asarray(p.σ2).ravel()[0]), " notebook: 0.7526282 0.00204789")
+gp.prepare_grid(at=gp.parray(lg10_Z=8, X=0.5)); gp.predict_grid()
+print("grid mu", np.round(np.asarray(gp.predictions.μ).ravel()[:10], 8))
+print("grid s2", np.round(np.asarray(gp.predictions.σ2).ravel()[:10], 8))
+print({k: np.round(v, 5) for k, v in gp.MAP.items() if not k.endswith("_log__")})
