@@ -714,7 +714,8 @@ int order_after(gmb_engine* e, hipStream_t from, hipStream_t to) {
   return GMB_OK;
 }
 
-int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip);
+int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip,
+              int lfirst = -1, int lstride = 0);
 
 // ---- fused panel chain --------------------------------------------------------------------------
 // Op lists of every panel but the first (which runs on the idle chip through ordinary launches),
@@ -971,13 +972,17 @@ int chol_lookahead(gmb_engine* e) {
 }
 
 // ---- predict recursion: V <- W L^-T over column blocks [c0, c1) ------------------------------
-int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip) {
+// lfirst / lstride (optional): row tile t of V stands for block row lfirst + t*lstride of a matrix
+// whose rows are zero left of their own diagonal block (rows of the identity being solved into
+// rows of L^-T): the update products then skip the structurally zero part of their contraction.
+int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip,
+              int lfirst, int lstride) {
   if (c1 - c0 == 1)
     return launch_trsm_strip(e, V + (int64_t)c0 * TILE * ldz, ldz, (int64_t)ntm * TILE,
                              e->dA + (int64_t)c0 * TILE * (e->ld + 1), e->ld, e->dDinv16 + (int64_t)c0 * 8 * 256,
                              (int)std::min<int64_t>(TILE, e->N - (int64_t)c0 * TILE), kind_strip);
   const int mid = c0 + (c1 - c0 + 1) / 2;
-  int rc = trsm_cols(e, V, ldz, ntm, c0, mid, kind_gemm, kind_strip);
+  int rc = trsm_cols(e, V, ldz, ntm, c0, mid, kind_gemm, kind_strip, lfirst, lstride);
   if (rc) return rc;
   GemmArgs g{};
   g.C = V + (int64_t)mid * TILE * ldz;
@@ -991,9 +996,14 @@ int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, in
   g.k = (mid - c0) * TILE;
   g.alpha = -1.0;
   g.beta = 1.0;
+  if (lstride > 0) {
+    g.klo_n = 1;
+    g.krow_stride = lstride;
+    g.krow_off = (lfirst - c0) * TILE;
+  }
   rc = launch_gemm(e, g, kind_gemm);
   if (rc) return rc;
-  return trsm_cols(e, V, ldz, ntm, mid, c1, kind_gemm, kind_strip);
+  return trsm_cols(e, V, ldz, ntm, mid, c1, kind_gemm, kind_strip, lfirst, lstride);
 }
 
 // ---- NLML gradient ---------------------------------------------------------------------------
@@ -1820,7 +1830,7 @@ int gmb_inv_rows(gmb_engine* e, int32_t first, int32_t stride, double* V, int64_
   hipLaunchKernelGGL(identity_rows_kernel, dim3(owned), dim3(TILE), 0, e->stream, V, ldv, first, stride);
   HIP_TRY(e, hipGetLastError());
   e->cur = e->stream;
-  if ((rc = trsm_cols(e, V, ldv, owned, 0, nt, 4, 6))) return rc;
+  if ((rc = trsm_cols(e, V, ldv, owned, 0, nt, 4, 6, first, stride))) return rc;
   hipLaunchKernelGGL(urows_v_kernel, dim3(owned * 2), dim3(256), 0, e->stream, V, ldv, e->dv, e->N, alpha_rows);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipStreamSynchronize(e->stream));

@@ -63,6 +63,10 @@ struct GemmArgs {
   // passes its first block row's offset)
   int32_t klo_m, klo_n, khi_n;
   int32_t krow_off;
+  // logical block stride of the n range for R(tn) when it differs from the stride in memory (0 =
+  // the same): a rank's packed rows of U = L^-T are contiguous in its buffer but stand for every
+  // G-th block row of the matrix, and their structural zeros end at that LOGICAL row
+  int32_t krow_stride;
   // XCD-balanced schedule (filled by gemm_schedule): the computed tiles, enumerated row-major
   // (tm outer, tn inner), are cut into 8 contiguous runs of equal WORK; block b serves run b % 8.
   int32_t xstart[9];
@@ -186,10 +190,11 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
   const int wm = wave / WGN, wn = wave % WGN;
   const int r16 = lane & 15, kq = lane >> 4;
 
-  const int krow = (int)gemm_noff(tn, BN, g.nblk_stride) + g.krow_off;
+  const int krow = (int)gemm_noff(tn, BN, g.krow_stride > 0 ? g.krow_stride : g.nblk_stride) + g.krow_off;
   int k_lo = g.klo_m * tm * BM + g.klo_n * krow;
   int k_hi = g.k;
   if (g.khi_n) k_hi = min(k_hi, krow + BN);
+  if (k_lo < 0) k_lo = 0;
   if (k_lo > k_hi) k_lo = k_hi;
 
   const int a_row = tid / LA, a_col = 2 * (tid % LA);
@@ -339,8 +344,9 @@ inline int gemm_schedule(GemmArgs& g, int bm, int bn, double* flops) {
     return f > g.nt ? g.nt : f;
   };
   auto kunits = [&](int tm, int tn) {
-    const int krow = (int)gemm_noff(tn, bn, g.nblk_stride < 1 ? 1 : g.nblk_stride) + g.krow_off;
-    const int lo = (g.klo_m * tm * bm + g.klo_n * krow) / KT;
+    const int kstride = g.krow_stride > 0 ? g.krow_stride : (g.nblk_stride < 1 ? 1 : g.nblk_stride);
+    const int krow = (int)gemm_noff(tn, bn, kstride) + g.krow_off;
+    const int lo = std::max(0, g.klo_m * tm * bm + g.klo_n * krow) / KT;
     int hi = KU;
     if (g.khi_n && (krow + bn) / KT < hi) hi = (krow + bn) / KT;
     return hi > lo ? hi - lo : 0;
