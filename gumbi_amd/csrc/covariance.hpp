@@ -52,22 +52,55 @@ struct CovParams {
   const double* noise_mult;   // diag(B_noise) per output level (device), used if noise_tab >= 0
 };
 
+// exp(x) for x <= 0 -- all a stationary covariance ever exponentiates.  Cody-Waite reduction
+// x = k ln2 + r (|r| <= ln2 / 2), degree-13 Taylor polynomial (truncation 4e-18), v_ldexp_f64.
+// Within 1-2 ulp of libm's exp; about two thirds of its instructions (no overflow / NaN paths).
+__device__ __forceinline__ double exp_nonpos(double x) {
+  if (x <= -745.0) return 0.0;  // underflow (and -inf); NaN falls through and stays NaN
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821614599e-10;        // 1/13!
+  p = fma(p, r, 2.0876756987868098979e-09);    // 1/12!
+  p = fma(p, r, 2.5052108385441718775e-08);    // 1/11!
+  p = fma(p, r, 2.7557319223985890653e-07);    // 1/10!
+  p = fma(p, r, 2.7557319223985892511e-06);    // 1/9!
+  p = fma(p, r, 2.4801587301587301566e-05);    // 1/8!
+  p = fma(p, r, 1.9841269841269841253e-04);    // 1/7!
+  p = fma(p, r, 1.3888888888888889419e-03);    // 1/6!
+  p = fma(p, r, 8.3333333333333332177e-03);    // 1/5!
+  p = fma(p, r, 4.1666666666666664354e-02);    // 1/4!
+  p = fma(p, r, 1.6666666666666665741e-01);    // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)k);
+}
+
+// Measured: no faster than libm's exp inside the covariance kernels (they were bound by branches
+// and XCD imbalance, not by the exponential), so libm stays the default; -DGMB_FAST_EXP selects it.
+#ifdef GMB_FAST_EXP
+#define GMB_EXP(x) exp_nonpos(x)
+#else
+#define GMB_EXP(x) exp(x)
+#endif
+
 template <int KIND>
 __device__ __forceinline__ double stationary(double r2) {
   if constexpr (KIND == 0) {
-    return exp(-0.5 * r2);
+    return GMB_EXP(-0.5 * r2);
   } else {
     const double r = sqrt(r2 + 1e-12);
     if constexpr (KIND == 1) {
       const double s5 = 2.23606797749978969641;
-      return (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp(-s5 * r);
+      return (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * GMB_EXP(-s5 * r);
     } else if constexpr (KIND == 2) {
       const double s3 = 1.73205080756887729353;
-      return (1.0 + s3 * r) * exp(-s3 * r);
+      return (1.0 + s3 * r) * GMB_EXP(-s3 * r);
     } else if constexpr (KIND == 3) {
-      return exp(-r);
+      return GMB_EXP(-r);
     } else {
-      return exp(-0.5 * r);
+      return GMB_EXP(-0.5 * r);
     }
   }
 }
@@ -76,19 +109,19 @@ __device__ __forceinline__ double stationary(double r2) {
 template <int KIND>
 __device__ __forceinline__ double stationary_dr2(double r2) {
   if constexpr (KIND == 0) {
-    return -0.5 * exp(-0.5 * r2);
+    return -0.5 * GMB_EXP(-0.5 * r2);
   } else {
     const double r = sqrt(r2 + 1e-12);
     if constexpr (KIND == 1) {
       const double s5 = 2.23606797749978969641;
-      return -(5.0 / 6.0) * (1.0 + s5 * r) * exp(-s5 * r);
+      return -(5.0 / 6.0) * (1.0 + s5 * r) * GMB_EXP(-s5 * r);
     } else if constexpr (KIND == 2) {
       const double s3 = 1.73205080756887729353;
-      return -1.5 * exp(-s3 * r);
+      return -1.5 * GMB_EXP(-s3 * r);
     } else if constexpr (KIND == 3) {
-      return -exp(-r) / (2.0 * r);
+      return -GMB_EXP(-r) / (2.0 * r);
     } else {
-      return -0.25 * exp(-0.5 * r) / r;
+      return -0.25 * GMB_EXP(-0.5 * r) / r;
     }
   }
 }
@@ -151,6 +184,7 @@ struct CovTileArgs {
   int32_t mode;    // CovMode
   int32_t lower_only;   // COV_TRAIN: skip tiles strictly above the diagonal
   const double* y;      // COV_TRAIN: observations, written into row n (the "y row")
+  int32_t tri_grid;     // the grid enumerates only the tiles on / below the diagonal (i0 == j0 == 0)
 };
 
 template <int KIND, int NC>
@@ -162,9 +196,23 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
   __shared__ int32_t ci[MAX_TABS][TILE];
 
   const int nwg = a.ti * a.tj;
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  const int tjx = wg / a.ti;
-  const int tix = wg - tjx * a.ti;
+  // Triangular build: the tile columns carry very different amounts of work (column j has ti - j
+  // tiles below the diagonal), so contiguous per-XCD runs would leave the last XCDs idle; dealing
+  // consecutive tiles round-robin over the XCDs (the hardware's own order) balances them.
+  int tjx, tix;
+  if (a.tri_grid) {  // block b -> b-th tile of the lower triangle, column by column
+    int rem = blockIdx.x;
+    tjx = 0;
+    while (rem >= a.ti - tjx) {
+      rem -= a.ti - tjx;
+      ++tjx;
+    }
+    tix = tjx + rem;
+  } else {
+    const int wg = (a.mode == COV_TRAIN && a.lower_only) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
+    tjx = wg / a.ti;
+    tix = wg - tjx * a.ti;
+  }
   const int64_t gi0 = a.i0 + (int64_t)tix * TILE;
   const int64_t gj0 = a.j0 + (int64_t)tjx * TILE;
   if (a.mode == COV_TRAIN && a.lower_only && gi0 + TILE - 1 < gj0) return;
@@ -203,6 +251,26 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
     ndiag = p.sigma2;
     if (p.noise_tab >= 0) ndiag *= p.noise_mult[ci[p.noise_tab][il]];
     ndiag += p.jitter;
+  }
+
+  // Fast path (almost every tile of a large matrix): stationary term only, every row and column
+  // real, and -- for the training matrix -- the tile strictly below the diagonal: no per-entry
+  // conditionals at all (the general loop below carries ~90 branches for the boundary cases).
+  const bool full = gi0 + TILE <= a.rows.n && gj0 + TILE <= a.cols.n;
+  const bool below = a.mode != COV_TRAIN || gj0 + TILE <= gi0;
+  if (full && below && p.n_lin == 0 && p.n_tab == 0) {
+    const double* xjp = &xj[0][jh * (TILE / 2)];
+#pragma unroll 8
+    for (int jj = 0; jj < TILE / 2; ++jj) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const double d = xi[k] - xjp[k * TILE + jj];
+        r2 = fma(d, d, r2);
+      }
+      outp[(int64_t)jj * a.ldo] = p.eta2 * stationary<KIND>(r2);
+    }
+    return;
   }
 
   for (int jj = 0; jj < TILE / 2; ++jj) {

@@ -475,7 +475,12 @@ int launch_leaf(gmb_engine* e, const LeafArgs& a) {
 
 template <int KIND>
 int launch_cov_nc(gmb_engine* e, const CovTileArgs& a, int nc) {
-  const dim3 grid(a.ti * a.tj), block(256);
+  long long nb = (long long)a.ti * a.tj;
+  if (a.tri_grid) {
+    nb = 0;
+    for (int j = 0; j < a.tj; ++j) nb += std::max(0, a.ti - j);
+  }
+  const dim3 grid((unsigned)nb), block(256);
   switch (nc) {
     case 1: hipLaunchKernelGGL((cov_tile_kernel<KIND, 1>), grid, block, 0, e->stream, a); break;
     case 2: hipLaunchKernelGGL((cov_tile_kernel<KIND, 2>), grid, block, 0, e->stream, a); break;
@@ -1724,6 +1729,7 @@ int gmb_factorize(gmb_engine* e) {
     a.tj = (int)(e->Np / TILE);
     a.mode = COV_TRAIN;
     a.lower_only = 1;
+    a.tri_grid = 1;
     a.y = e->dy;
     if ((rc = launch_cov(e, a))) return rc;
   }
