@@ -198,6 +198,7 @@ def distributed_section(world, local_rank, dist):
         torch.cuda.synchronize()
 
     eng.factorize()  # warm-up (allocations, code objects, RCCL channels)
+    eng.nlml(grad=True)  # ... including the gradient's N^2 workspace
     sync()
     t0 = time.perf_counter()
     eng.factorize()
