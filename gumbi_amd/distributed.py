@@ -261,6 +261,7 @@ class DistributedEngine:
         # True: L^-T is computed by rows across the ranks (scales with the group size);
         # False: every rank inverts the factor itself and only Sigma^-1 is sharded
         self.partition_inverse = True
+        self.force_partition = False  # tests: take the partitioned path even with a single rank
 
     def set_data(self, X, y):
         self.eng.set_data(X, y)
@@ -289,7 +290,7 @@ class DistributedEngine:
             return self.eng.nlml()
         torch = self.torch
         with torch.cuda.stream(self.stream):
-            if self.partition_inverse and self.comm.world > 1:
+            if self.partition_inverse and (self.comm.world > 1 or self.force_partition):
                 acc = self._grad_partitioned()
             else:
                 acc = self.eng.nlml_shard(self.comm.rank, self.comm.world)

@@ -196,3 +196,56 @@ def test_cross_validation_replicas_over_ranks(gpu):
     # (MAP optima agree to the optimiser's tolerance, not bitwise: the trace reductions use atomics)
     assert np.allclose([float(r["test"]["NLPDs"].mean()) for r in alone], results[0][1], rtol=1e-4)
     assert [len(r["train"]["data"].wide) for r in alone] == results[0][2] == [210, 210, 210]
+
+
+def _rccl_worker(out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from gumbi_amd.distributed import DistributedEngine
+        from gumbi_amd.engine import KernelSpec
+        from oracle import gp_oracle as O
+
+        N, d = 900, 3
+        X, y, ls = O.synthetic_table(N, d, seed=8)
+        spec = O.make_spec(d, range(d))
+        theta = O.pack_theta(spec, ls, 1.0, 0.25)
+        eng = DistributedEngine(0)
+        eng.force_partition = True
+        eng.set_data(X, y)
+        eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d))))
+        eng.set_theta(theta)
+        eng.factorize()
+        val, g = eng.nlml(grad=True)
+        val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+        eng.factorize()
+        Xs = np.random.default_rng(3).standard_normal((200, d))
+        mu, var = eng.predict(Xs)
+        mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+        out.put((dist.get_backend(), abs(val - val_r) / abs(val_r), float(np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r)))),
+                 float(np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))), float(np.max(np.abs(var - var_r)))))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_driver_on_the_rccl_backend_with_one_rank(gpu):
+    """The same driver on the nccl (= RCCL) backend: device-tensor broadcast / all-gather / all-reduce on
+    the engine's side stream, no host staging.  One rank is all a one-GPU box allows (RCCL refuses two
+    ranks on one device); the collectives are trivial but every call the 8-GPU run makes is made."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(out,))
+    p.start()
+    backend, e_val, e_g, e_mu, e_var = out.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert backend == "nccl"
+    assert e_val < 1e-10 and e_g < 1e-8 and e_mu < 1e-8 and e_var < 1e-9
