@@ -97,7 +97,30 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
   double g_eta = 0.0, g_tau = 0.0;
 
   const double* zp = a.Z + gi + (gj0 + jh * (TILE / 2)) * a.ldz;
-  for (int jj = 0; jj < TILE / 2; ++jj) {
+  // Fast path (almost every tile): stationary term only, tile strictly below the diagonal, every
+  // row and column real -- each entry stands for (i,j) and (j,i), no per-entry conditionals.
+  const bool fast = p.n_lin == 0 && p.n_tab == 0 && tix > tjx && gi0 + TILE <= a.pts.n && gj0 + TILE <= a.pts.n;
+  if (fast) {
+    const int jb = jh * (TILE / 2);
+#pragma unroll 4
+    for (int jj = 0; jj < TILE / 2; ++jj) {
+      const double m = zp[(int64_t)jj * a.ldz] - ai * aj[jb + jj];  // 2 * M_ij
+      double d2[NC];
+      double r2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const double d = xi[k] - xj[k][jb + jj];
+        d2[k] = d * d;
+        r2 += d2[k];
+      }
+      const double ks = stationary<KIND>(r2);
+      const double mdk = m * (p.eta2 * stationary_dr2<KIND>(r2));
+#pragma unroll
+      for (int k = 0; k < NC; ++k) g_ls[k] = fma(mdk, -2.0 * d2[k] * a.inv_ls[k], g_ls[k]);
+      g_eta = fma(m, 2.0 * a.eta * ks, g_eta);
+    }
+  }
+  for (int jj = fast ? TILE / 2 : 0; jj < TILE / 2; ++jj) {
     const int j = jh * (TILE / 2) + jj;
     const int64_t gj = gj0 + j;
     if (!row_real || gj >= a.pts.n || gj > gi) continue;
