@@ -1991,6 +1991,17 @@ int gmb_copy_v(const gmb_engine* ce, double* out) {
   return GMB_OK;
 }
 
+int gmb_copy_alpha(const gmb_engine* ce, double* out) {
+  gmb_engine* e = const_cast<gmb_engine*>(ce);
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  if (!out) return fail(e, GMB_EINVAL, "null output");
+  if (!e->factor_consumed || !e->dalpha)
+    return fail(e, GMB_EINVAL, "alpha exists only after a gradient evaluation (gmb_nlml with grad)");
+  HIP_TRY(e, hipMemcpy(out, e->dalpha, e->N * sizeof(double), hipMemcpyDeviceToHost));
+  return GMB_OK;
+}
+
 int gmb_ls_limits(int32_t device, const double* X, int64_t N, int32_t n_cols, int64_t ldx, int32_t ard,
                   double* lower, double* upper) {
   if (!X || !lower || !upper || N < 1 || n_cols < 1 || n_cols > GMB_MAX_DIMS || ldx < n_cols)

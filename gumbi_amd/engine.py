@@ -174,6 +174,7 @@ _SIGNATURES = {
     "gmb_copy_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _DBL_P]),
     "gmb_copy_v": (C.c_int, [C.c_void_p, _DBL_P]),
     "gmb_blk_potrf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmb_copy_alpha": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "gmb_inv_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gmb_grad_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "gmb_nlml_shard_u": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]),
@@ -395,6 +396,12 @@ class Engine:
     def copy_v(self):
         out = np.empty(self.N, dtype=np.float64)
         self._check(self._lib.gmb_copy_v(self._h, _dptr(out)), "gmb_copy_v")
+        return out
+
+    def copy_alpha(self):
+        """alpha = Sigma^-1 y (available after ``nlml(grad=True)``)."""
+        out = np.empty(self.N, dtype=np.float64)
+        self._check(self._lib.gmb_copy_alpha(self._h, _dptr(out)), "gmb_copy_alpha")
         return out
 
     # -- sharded gradient (multi-GPU driver) ---------------------------------------------------------------

@@ -34,6 +34,7 @@ import numpy as np
 
 from ..aggregation import DataSet
 from ..engine import KERNEL_KINDS, Engine, KernelSpec
+from . import icm
 from ..utils.gp_utils import get_ls_prior
 from ..utils.misc import assert_in
 from .base import Regressor
@@ -65,7 +66,7 @@ class HipGP(Regressor):
     """Gaussian-process regression on an MI355X.  Drop-in for ``gumbi.GP`` on the
     ``fit() / prepare_grid() / predict_grid()`` path; see the module docstring."""
 
-    def __init__(self, dataset: DataSet, outputs=None, seed=2021, device=0, distributed=None):
+    def __init__(self, dataset: DataSet, outputs=None, seed=2021, device=0, distributed=None, kronecker="auto"):
         """``distributed``: ``True`` (default process group) or a ``torch.distributed`` group -- ONE GP
         spread over the group's GPUs (:class:`gumbi_amd.distributed.DistributedEngine`: block-cyclic
         Cholesky, sharded gradient and prediction).  Every rank constructs the same GP on the same data
@@ -73,6 +74,10 @@ class HipGP(Regressor):
         super().__init__(dataset, outputs, seed)
         self.device = device
         self.distributed = distributed
+        #: "auto": multi-output tables that repeat the same inputs for every output are evaluated in
+        #: Kronecker form (:mod:`gumbi_amd.regression.icm`: P systems of size N instead of one of size
+        #: PN); False: always the stacked system, as the reference builds it
+        self.kronecker = kronecker
         self.model = None
         self.gp_dict = None
         self.MAP = None
@@ -217,6 +222,8 @@ class HipGP(Regressor):
             from ..distributed import DistributedEngine
 
             self.engine = DistributedEngine(self.device, None if self.distributed is True else self.distributed)
+        elif self.kronecker and spec.out_col >= 0 and icm.aligned_outputs(X, spec):
+            self.engine = icm.IcmEngine(device=self.device)
         else:
             self.engine = Engine(device=self.device)
         self.engine.set_data(X, y)

@@ -197,6 +197,9 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma);
 int gmb_copy_factor(const gmb_engine* e, int64_t r0, int64_t nr, int64_t c0, int64_t nc,
                     double* out);
 int gmb_copy_v(const gmb_engine* e, double* out); /* v = L^-1 y, length N, host */
+/* alpha = Sigma^-1 y (length N, host); exists after gmb_nlml with a gradient.  Used by the
+ * Kronecker (ICM) multi-output path, whose outer chain rule needs it (gumbi_amd/regression/icm.py). */
+int gmb_copy_alpha(const gmb_engine* e, double* out);
 
 /* -- block-level operations for the multi-GPU driver (device pointers, column-major) ----------
  * These expose the same kernels the single-GPU path uses so that a 1-D block-cyclic row

@@ -213,3 +213,56 @@ def test_reference_multioutput_notebook_is_reproduced(gpu):
     assert np.max(np.abs(mu - nb_mu) / np.abs(nb_mu)) < 8e-3
     assert np.max(np.abs(mu[1:4] - nb_mu[1:4]) / np.abs(nb_mu[1:4])) < 1e-3
     assert np.max(np.abs(s2 - nb_s2) / nb_s2) < 0.06
+
+
+def _multioutput_gp(kronecker):
+    import gumbi_amd as gmb
+
+    df = pd.read_pickle(GOLD / "example_dataset.pkl")
+    df = df[(df.Name == "binary-pollen") & (df.Color == "cyan") & (df.Metric == "mean")]
+    ds = gmb.DataSet(df, outputs=["a", "b", "c", "d", "e", "f"], log_vars=["Y", "b", "c", "d", "f"],
+                     logit_vars=["X", "e"])
+    gp = gmb.GP(ds, outputs=["a", "b", "c", "d", "e"], kronecker=kronecker)
+    gp.specify_model(continuous_dims="lg10_Z", linear_dims="lg10_Z")
+    gp.build_model()
+    return gp
+
+
+@pytest.mark.parametrize("hetero", [True, False])
+def test_kronecker_path_equals_the_stacked_system(gpu, hetero):
+    """IcmEngine (P systems of size N) against the stacked PN x PN engine at the same hyper-parameters:
+    NLML, every gradient entry and the predictions (mean, variance with and without noise)."""
+    from gumbi_amd.regression.icm import IcmEngine
+
+    gk, gs = _multioutput_gp("auto"), _multioutput_gp(False)
+    if not hetero:
+        for gp in (gk, gs):
+            gp.build_model(heteroskedastic_outputs=False)
+    assert isinstance(gk.engine, IcmEngine) and not isinstance(gs.engine, IcmEngine)
+    rng = np.random.default_rng(5)
+    pos = gk._positive_mask()
+    for trial in range(3):
+        theta = gk._initial_theta()
+        theta = np.where(pos, theta * np.exp(rng.normal(0, 0.4, theta.size)), theta + rng.normal(0, 0.3, theta.size))
+        vals = []
+        for gp in (gk, gs):
+            gp.engine.set_theta(theta)
+            gp.engine.factorize()
+            vals.append(gp.engine.nlml(grad=True))
+        (vk, gk_), (vs, gs_) = vals
+        assert np.isclose(vk, vs, rtol=1e-10, atol=1e-9)
+        assert np.max(np.abs(gk_ - gs_)) < 1e-7 * max(1.0, np.max(np.abs(gs_)))
+        X, _ = gs.get_shaped_data("mean")
+        pts = X[rng.choice(len(X), 25, replace=False)].copy()
+        pts[:, 0] += rng.normal(0, 0.3, len(pts))
+        for with_noise in (True, False):
+            preds = []
+            for gp in (gk, gs):
+                gp.engine.set_theta(theta)
+                gp.engine.factorize()
+                preds.append(gp.engine.predict(pts, with_noise=with_noise))
+            (mk, vk2), (ms, vs2) = preds
+            assert np.max(np.abs(mk - ms)) < 1e-8 * max(1.0, np.max(np.abs(ms)))
+            assert np.max(np.abs(vk2 - vs2)) < 1e-8 * max(1.0, np.max(np.abs(vs2)))
+    gk.engine.close()
+    gs.engine.close()
