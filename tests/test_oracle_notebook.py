@@ -55,21 +55,28 @@ class OracleEngine:
         return O.predict(self.spec, self.theta, self.X, self.y, np.asarray(Xs, float), with_noise=with_noise,
                          dist_mode="direct")
 
+    def copy_alpha(self):
+        from scipy.linalg import solve_triangular
+
+        L, v = O.factorize(self.spec, self.theta, self.X, self.y, dist_mode="direct")
+        return solve_triangular(L, v, lower=True, trans="T")
+
     def close(self):
         pass
 
 
-def _fit_and_predict(monkeypatch, jacobian):
+def _fit_and_predict(monkeypatch, jacobian, kronecker=False):
     import gumbi_amd as gmb
-    from gumbi_amd.regression import hip_gp
+    from gumbi_amd.regression import hip_gp, icm
 
     monkeypatch.setattr(hip_gp, "Engine", OracleEngine)
+    monkeypatch.setattr(icm, "Engine", OracleEngine)
     df = pd.read_pickle(GOLD / "example_dataset.pkl")
     df = df[(df.Name == "binary-pollen") & (df.Color == "cyan") & (df.Metric == "mean")]
     ds = gmb.DataSet(df, outputs=["a", "b", "c", "d", "e", "f"], log_vars=["Y", "b", "c", "d", "f"],
                      logit_vars=["X", "e"])
     fit_params = ["a", "b", "c", "d", "e"]
-    gp = gmb.GP(ds, outputs=fit_params)
+    gp = gmb.GP(ds, outputs=fit_params, kronecker=kronecker)
     gp.map_includes_jacobian = jacobian
     gp.fit(continuous_dims="lg10_Z", linear_dims="lg10_Z")
     assert len(gp.model.y) == 70
@@ -86,6 +93,16 @@ def test_oracle_reproduces_the_pymc5_notebook(monkeypatch):
     assert np.max(np.abs(mu - NB_MU) / np.abs(NB_MU)) < 8e-3
     assert np.max(np.abs(mu[1:4] - NB_MU[1:4]) / np.abs(NB_MU[1:4])) < 1e-3   # interior of the grid: 1e-4 .. 1e-3
     assert np.max(np.abs(s2 - NB_S2) / NB_S2) < 0.06
+
+
+def test_kronecker_algebra_on_the_oracle_gives_the_same_fit(monkeypatch):
+    """The host-side Kronecker algebra of gumbi_amd/regression/icm.py (P systems of size N), driven by the
+    oracle instead of the HIP engine: same MAP fit and predictions as the stacked system above."""
+    mu_s, s2_s = _fit_and_predict(monkeypatch, jacobian=False, kronecker=False)
+    mu_k, s2_k = _fit_and_predict(monkeypatch, jacobian=False, kronecker="auto")
+    assert np.max(np.abs(mu_k - mu_s) / np.abs(mu_s)) < 1e-5
+    assert np.max(np.abs(s2_k - s2_s) / s2_s) < 1e-4
+    assert np.max(np.abs(mu_k[1:4] - NB_MU[1:4]) / np.abs(NB_MU[1:4])) < 1e-3
 
 
 def test_the_jacobian_reading_of_find_map_does_not(monkeypatch):
