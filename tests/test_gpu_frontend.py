@@ -266,3 +266,46 @@ def test_kronecker_path_equals_the_stacked_system(gpu, hetero):
             assert np.max(np.abs(vk2 - vs2)) < 1e-8 * max(1.0, np.max(np.abs(vs2)))
     gk.engine.close()
     gs.engine.close()
+
+
+def test_kronecker_path_with_categorical_and_linear_dims(gpu):
+    """Aligned two-output table with an additional coregionalised categorical input and a linear dim:
+    those stay inside K, so the Kronecker form still applies and must match the stacked system."""
+    import gumbi_amd as gmb
+    from gumbi_amd.regression.icm import IcmEngine
+
+    def make(kron):
+        es = pd.read_pickle(GOLD / "test_dataset.pkl")
+        stdzr = gmb.Standardizer(**{k: dict(v) for k, v in example_stdzr.items()}, log_vars=["d", "f", "b", "c", "Y"],
+                                 logit_vars=["e", "X"])
+        ds = gmb.DataSet.from_tidy(es, names_column="Parameter", stdzr=stdzr)
+        gp = gmb.GP(ds, outputs=["d", "c"], kronecker=kron)
+        gp.specify_model(outputs=["d", "c"], continuous_dims=["X", "Y"], linear_dims=["Y"], categorical_dims="Code")
+        gp.build_model()
+        return gp
+
+    gk, gs = make("auto"), make(False)
+    if not isinstance(gk.engine, IcmEngine):
+        pytest.skip("fixture is not aligned across outputs")
+    rng = np.random.default_rng(11)
+    pos = gk._positive_mask()
+    theta = gk._initial_theta()
+    theta = np.where(pos, theta * np.exp(rng.normal(0, 0.3, theta.size)), theta + rng.normal(0, 0.3, theta.size))
+    res = []
+    for gp in (gk, gs):
+        gp.engine.set_theta(theta)
+        gp.engine.factorize()
+        res.append(gp.engine.nlml(grad=True))
+    (vk, g1), (vs, g2) = res
+    assert np.isclose(vk, vs, rtol=1e-10, atol=1e-9)
+    assert np.max(np.abs(g1 - g2)) < 1e-7 * max(1.0, np.max(np.abs(g2)))
+    X, _ = gs.get_shaped_data("mean")
+    pts = X[rng.choice(len(X), 20, replace=False)].copy()
+    pts[:, 0] += rng.normal(0, 0.2, len(pts))
+    out = []
+    for gp in (gk, gs):
+        gp.engine.set_theta(theta)
+        gp.engine.factorize()
+        out.append(gp.engine.predict(pts))
+    assert np.max(np.abs(out[0][0] - out[1][0])) < 1e-8 * max(1.0, np.max(np.abs(out[1][0])))
+    assert np.max(np.abs(out[0][1] - out[1][1])) < 1e-8 * max(1.0, np.max(np.abs(out[1][1])))
