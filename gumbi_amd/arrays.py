@@ -306,6 +306,18 @@ class UncertainArray(np.ndarray):
         """Negative log posterior density of ``target``."""
         return -np.log(self.dist.pdf(target))
 
+    def vEI(self, target, best_yet, k=1):
+        """Expected improvement towards a TARGET value (Uhrenholt & Jensen 2019, "Efficient Bayesian
+        optimization for target vector estimation"): ``E[max(0, best_yet - |target - y|^2)]`` for
+        ``y ~ N(mu, sigma^2 I_k)``.  ``|target - y|^2 / sigma^2`` is noncentral chi-square with k degrees
+        of freedom and noncentrality ``|target - mu|^2 / sigma^2``, which gives the closed form below;
+        ``best_yet`` is the smallest SQUARED distance observed so far (reference ``arrays.py:672-697``)."""
+        from scipy.stats import ncx2
+
+        nc = (target - self.μ) ** 2 / self.σ2
+        x = best_yet / self.σ2
+        return best_yet * ncx2.cdf(x, k, nc) - self.σ2 * (k * ncx2.cdf(x, k + 2, nc) + nc * ncx2.cdf(x, k + 4, nc))
+
     @staticmethod
     def stack(uarray_list, axis=0):
         names = {ua.name for ua in uarray_list}

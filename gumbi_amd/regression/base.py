@@ -452,6 +452,33 @@ class Regressor(ABC):
         return cond_grid.squeeze(), cond.squeeze()
 
     # -- evaluation ----------------------------------------------------------------------------------------------
+    def propose(self, target, acquisition="EI"):
+        """Next point to measure when steering ONE output towards ``target`` (reference :816-838): the
+        maximiser, over the points of the last prediction, of the target-value expected improvement
+        (``"EI"``, :meth:`UncertainArray.vEI` on the standardized scale) or of the posterior density at
+        the target (``"PD"``).  The reference's version cannot run (it takes ``.z`` of a plain float,
+        ``base.py:830-831``) and hands vEI a distance where the acquisition expects a squared distance;
+        this one follows the published definition."""
+        if self.predictions is None:
+            raise ValueError("No predictions to make proposal from!")
+        assert_in("acquisition", acquisition, ["EI", "PD"])
+        output = self.predictions.name
+        df = self.get_filtered_data(standardized=False)
+        df = df[df[self.out_col] == output]
+        vcol = self.data.values_column if self.data.values_column in df.columns else "Value"
+        observed = self.parray(**{output: df[vcol].to_numpy()}, stdzd=False)
+        goal = self.parray(**{output: target}, stdzd=False)
+        tz = float(np.asarray(goal.z.values()).ravel()[0])
+        best_yet = float(np.min((np.asarray(observed.z.values()).ravel() - tz) ** 2))
+        pz = self.predictions.z
+        if acquisition == "EI":
+            self.proposal_surface = np.asarray(pz.vEI(tz, best_yet))
+        else:
+            self.proposal_surface = -np.asarray(pz.nlpd(tz))
+        self.proposal_idx = int(np.argmax(self.proposal_surface))
+        self.proposal = self.predictions_X.ravel()[self.proposal_idx]
+        return self.proposal
+
     def cross_validate(self, unit=None, *, n_train=None, pct_train=None, train_only=None, warm_start=True,
                        seed=None, errors="natural", **MAP_kws):
         """Fit on a random subset, score on the rest (reference :844-1105).  Returns

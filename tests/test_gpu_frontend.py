@@ -309,3 +309,24 @@ def test_kronecker_path_with_categorical_and_linear_dims(gpu):
         out.append(gp.engine.predict(pts))
     assert np.max(np.abs(out[0][0] - out[1][0])) < 1e-8 * max(1.0, np.max(np.abs(out[1][0])))
     assert np.max(np.abs(out[0][1] - out[1][1])) < 1e-8 * max(1.0, np.max(np.abs(out[1][1])))
+
+
+def test_propose_picks_a_point_of_the_prediction_grid(gpu):
+    """``propose`` (reference base.py:816-838): target-value expected improvement / posterior density over
+    the last predictions."""
+    gp = example_gp()
+    gp.fit(continuous_dims=["X", "Y"])
+    gp.prepare_grid(resolution=9)
+    gp.predict_grid()
+    mu = np.asarray(gp.predictions.μ)
+    target = float(mu.ravel()[17])  # a value the surface attains
+    for acq in ("EI", "PD"):
+        prop = gp.propose(target, acquisition=acq)
+        assert gp.proposal_surface.shape == gp.predictions.shape
+        assert 0 <= gp.proposal_idx < mu.size
+        assert np.asarray(prop) == np.asarray(gp.predictions_X.ravel()[gp.proposal_idx])
+        assert np.all(np.isfinite(gp.proposal_surface))
+    # posterior density: the chosen point predicts (close to) the target
+    assert abs(mu.ravel()[gp.proposal_idx] - target) <= 0.5 * (mu.max() - mu.min())
+    with pytest.raises(ValueError):
+        example_gp().propose(1.0)
