@@ -87,6 +87,7 @@ def make_spec(
     n_out=0,
     hetero_noise=True,
     jitter=JITTER,
+    additive=False,
 ):
     """Plain-dict kernel spec (same field names as ``gumbi_amd.engine.KernelSpec``).
 
@@ -106,10 +107,22 @@ def make_spec(
         n_out=int(n_out),
         hetero_noise=bool(hetero_noise),
         jitter=float(jitter),
+        additive=bool(additive),
     )
 
 
+def _term_block_size(spec):
+    """Parameters of ONE continuous(+linear) kernel: ls | eta | [c, tau]."""
+    n = (len(spec["idx_cont"]) if spec["ard"] else 1) + 1
+    if spec["idx_lin"]:
+        n += len(spec["idx_lin"]) + 1
+    return n
+
+
 def theta_size(spec):
+    if spec.get("additive"):
+        base = dict(spec, additive=False)
+        return theta_size(base) + len(spec["coreg"]) * _term_block_size(spec)
     n = (len(spec["idx_cont"]) if spec["ard"] else 1) + 2
     if spec["idx_lin"]:
         n += len(spec["idx_lin"]) + 1
@@ -126,6 +139,9 @@ def unpack_theta(spec, theta):
     """Split the flat natural-scale vector into named pieces (see module docstring)."""
     theta = np.asarray(theta, dtype=np.float64)
     assert theta.shape == (theta_size(spec),), (theta.shape, theta_size(spec))
+    if spec.get("additive"):  # global term, tables and noise; the per-dim kernels follow (additive_terms)
+        base = dict(spec, additive=False)
+        return unpack_theta(base, theta[: theta_size(base)])
     p = {}
     k = 0
     n_ls = len(spec["idx_cont"]) if spec["ard"] else 1
@@ -230,8 +246,48 @@ def _coreg_factor(spec, p, X, Xs):
     return F
 
 
+def additive_terms(spec, theta):
+    """Additive model (``specify_model(additive=True)``, ``pymc/GP.py:732-754``): a "global" GP with the
+    continuous (+linear) kernel, plus one GP per categorical dim with its OWN continuous (+linear)
+    kernel times that dim's Coregion, every term times the output Coregion; ``gp_total`` is their sum,
+    i.e. the covariances add.  theta = [theta of the non-additive spec | per categorical dim:
+    ls | eta | (c, tau)].  Returns ``[(sub_spec, sub_theta, index_map)]``: each term as a non-additive
+    model of this module; ``index_map[i]`` is the position of sub_theta[i] in theta (-1: noise
+    parameters, which belong to no term)."""
+    theta = np.asarray(theta, float)
+    base = dict(spec, additive=False)
+    nb = theta_size(base)
+    n_ls = len(spec["idx_cont"]) if spec["ard"] else 1
+    nk = _term_block_size(spec)
+    n_core = n_ls + 2 + ((len(spec["idx_lin"]) + 1) if spec["idx_lin"] else 0)  # ls|eta|sigma|c,tau
+    core0 = list(range(n_core))
+    coreg_pos, k = [], n_core
+    for _, L in spec["coreg"]:
+        coreg_pos.append(list(range(k, k + 3 * L)))
+        k += 3 * L
+    tail = list(range(k, nb))  # W_out, kappa_out [, W_noise, kappa_noise]
+    n_out_par = 3 * spec["n_out"] if spec["out_col"] >= 0 else 0
+    tail_map = tail[:n_out_par] + [-1] * (len(tail) - n_out_par)
+    terms = []
+    sub0 = dict(base, coreg=[])
+    idx0 = core0 + tail
+    m0 = core0[:n_ls + 1] + [-1] + core0[n_ls + 2:] + tail_map
+    terms.append((sub0, theta[idx0], m0))
+    for j, cd in enumerate(spec["coreg"]):
+        off = nb + j * nk
+        blk = list(range(off, off + nk))
+        core = blk[:n_ls + 1] + [n_ls + 1] + blk[n_ls + 1:]  # splice sigma's slot in
+        sub = dict(base, coreg=[cd])
+        idx = core + coreg_pos[j] + tail
+        mp = blk[:n_ls + 1] + [-1] + blk[n_ls + 1:] + coreg_pos[j] + tail_map
+        terms.append((sub, theta[idx], mp))
+    return terms
+
+
 def cov_full(spec, theta, X, Xs=None, dist_mode="gemm"):
     """K(X, X') for the total covariance Gumbi declares (no noise, no jitter)."""
+    if spec.get("additive"):
+        return sum(cov_full(sp, th, X, Xs, dist_mode) for sp, th, _ in additive_terms(spec, theta))
     p = unpack_theta(spec, theta)
     X = np.asarray(X, float)
     Xs_ = None if Xs is None else np.asarray(Xs, float)
@@ -251,6 +307,8 @@ def cov_full(spec, theta, X, Xs=None, dist_mode="gemm"):
 
 def cov_diag(spec, theta, Xs):
     """diag K(X*, X*): stationary diag is exactly 1 (PyMC ``Stationary.diag``)."""
+    if spec.get("additive"):
+        return sum(cov_diag(sp, th, Xs) for sp, th, _ in additive_terms(spec, theta))
     p = unpack_theta(spec, theta)
     Xs = np.asarray(Xs, float)
     d = np.full(Xs.shape[0], p["eta"] ** 2)
@@ -347,15 +405,11 @@ def _stationary_dr2(kind, r2):
     raise ValueError(kind)
 
 
-def nlml_and_grad(spec, theta, X, y, dist_mode="direct"):
-    """NLML and d NLML / d theta (natural scale), ``dNLML = 1/2 tr((Sigma^-1 - a a^T) dSigma)``.
-
-    PyMC obtains the same derivative by reverse-mode autodiff through its Cholesky op
-    (``pm.find_MAP``, call site ``pymc/GP.py:811``); it is restated analytically here.
-    """
+def _kernel_grad_given_M(spec, theta, X, M, dist_mode="direct"):
+    """sum_ij M_ij dK_ij/dtheta for every KERNEL parameter of a non-additive spec (entries of sigma
+    and of the noise table stay 0), ``M = dNLML/dSigma``."""
     p = unpack_theta(spec, theta)
     X = np.asarray(X, float)
-    y = np.asarray(y, float)
     N = X.shape[0]
     ic = spec["idx_cont"]
     Xc = X[:, ic]
@@ -369,17 +423,6 @@ def nlml_and_grad(spec, theta, X, y, dist_mode="direct"):
         base = base + p["tau"] * lin
     F = _coreg_factor(spec, p, X, None)
     K = base if F is None else base * F
-    nd = noise_diag(spec, theta, X)
-    S = K.copy()
-    S[np.diag_indices_from(S)] += nd + spec["jitter"]
-    L = cholesky_lower(S)
-    v = solve_lower(L, y)
-    val = 0.5 * N * np.log(2.0 * np.pi) + np.sum(np.log(np.diag(L))) + 0.5 * float(v @ v)
-    Linv = solve_lower(L, np.eye(N))
-    Sinv = Linv.T @ Linv
-    alpha = Linv.T @ v
-    M = 0.5 * (Sinv - np.outer(alpha, alpha))  # dNLML/dSigma_ij
-
     g = np.zeros_like(np.asarray(theta, float))
     k = 0
     Fm = 1.0 if F is None else F
@@ -397,8 +440,7 @@ def nlml_and_grad(spec, theta, X, y, dist_mode="direct"):
         k += 1
     g[k] = np.sum(MF * 2.0 * p["eta"] * kst)  # eta
     k += 1
-    i_sigma = k
-    k += 1
+    k += 1  # sigma: not a kernel parameter
     if spec["idx_lin"]:
         nl = len(spec["idx_lin"])
         for j in range(nl):
@@ -441,10 +483,48 @@ def nlml_and_grad(spec, theta, X, y, dist_mode="direct"):
         g[k : k + 2 * Lc] = gW
         g[k + 2 * Lc : k + 3 * Lc] = gk
         k += 3 * Lc
+    return g
+
+
+def nlml_and_grad(spec, theta, X, y, dist_mode="direct"):
+    """NLML and d NLML / d theta (natural scale), ``dNLML = 1/2 tr((Sigma^-1 - a a^T) dSigma)``.
+
+    PyMC obtains the same derivative by reverse-mode autodiff through its Cholesky op
+    (``pm.find_MAP``, call site ``pymc/GP.py:811``); it is restated analytically here.
+    """
+    theta = np.asarray(theta, float)
+    p = unpack_theta(spec, theta)
+    X = np.asarray(X, float)
+    y = np.asarray(y, float)
+    N = X.shape[0]
+    S = sigma_matrix(spec, theta, X, dist_mode=dist_mode)
+    L = cholesky_lower(S)
+    v = solve_lower(L, y)
+    val = 0.5 * N * np.log(2.0 * np.pi) + np.sum(np.log(np.diag(L))) + 0.5 * float(v @ v)
+    Linv = solve_lower(L, np.eye(N))
+    Sinv = Linv.T @ Linv
+    alpha = Linv.T @ v
+    M = 0.5 * (Sinv - np.outer(alpha, alpha))  # dNLML/dSigma_ij
+
+    g = np.zeros_like(theta)
+    if spec.get("additive"):
+        for sub, th, mp in additive_terms(spec, theta):
+            gt = _kernel_grad_given_M(sub, th, X, M, dist_mode)
+            for i, dst in enumerate(mp):
+                if dst >= 0:
+                    g[dst] += gt[i]
+        base = dict(spec, additive=False)
+        k = theta_size(base)
+    else:
+        g += _kernel_grad_given_M(spec, theta, X, M, dist_mode)
+        k = theta.size
+    n_ls = len(spec["idx_cont"]) if spec["ard"] else 1
+    i_sigma = n_ls + 1
     # noise
     Md = np.diag(M)
     if spec["out_col"] >= 0 and spec["hetero_noise"]:
         P = spec["n_out"]
+        k -= 3 * P
         Wn, kn = p["W_noise"], p["kappa_noise"]
         Bn = coregion_B(Wn, kn)
         pi = X[:, spec["out_col"]].astype(np.int32)
@@ -454,10 +534,8 @@ def nlml_and_grad(spec, theta, X, y, dist_mode="direct"):
         # only the diagonal of B_noise enters: d diag(B)_a = 2 W_a . dW_a + dkappa_a
         g[k : k + 2 * P] = (2.0 * Gd[:, None] * Wn).ravel()
         g[k + 2 * P : k + 3 * P] = Gd
-        k += 3 * P
     else:
         g[i_sigma] = np.sum(Md) * 2.0 * p["sigma"]
-    assert k == g.size
     return val, g
 
 
