@@ -185,6 +185,9 @@ struct CovTileArgs {
   int32_t lower_only;   // COV_TRAIN: skip tiles strictly above the diagonal
   const double* y;      // COV_TRAIN: observations, written into row n (the "y row")
   int32_t tri_grid;     // the grid enumerates only the tiles on / below the diagonal (i0 == j0 == 0)
+  // Additive models (sum of kernels): passes after the first ADD their term to the real entries and
+  // leave padding, y row and the noise diagonal (written by the first pass) alone.
+  int32_t accumulate;
 };
 
 template <int KIND, int NC>
@@ -268,7 +271,9 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
         const double d = xi[k] - xjp[k * TILE + jj];
         r2 = fma(d, d, r2);
       }
-      outp[(int64_t)jj * a.ldo] = p.eta2 * stationary<KIND>(r2);
+      const double v = p.eta2 * stationary<KIND>(r2);
+      double* o = outp + (int64_t)jj * a.ldo;
+      *o = a.accumulate ? *o + v : v;
     }
     return;
   }
@@ -291,7 +296,9 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
     for (int t = 0; t < p.n_tab; ++t)
       v *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
     const bool col_real = gj < a.cols.n;
-    if (a.mode == COV_TRAIN) {
+    if (a.accumulate) {
+      if (row_real && col_real && (a.mode != COV_TRAIN || gi >= gj)) outp[(int64_t)jj * a.ldo] += v;
+    } else if (a.mode == COV_TRAIN) {
       if (!col_real) {
         v = (gi == gj) ? 1.0 : 0.0;  // identity padding keeps the padded factor trivial
       } else if (!row_real) {
@@ -314,6 +321,7 @@ struct KssArgs {
   PointSet pts;
   int32_t with_noise;
   double* kss;
+  int32_t accumulate;  // additive models: later terms add to kss
 };
 
 __global__ void kss_kernel(KssArgs a) {
@@ -338,7 +346,11 @@ __global__ void kss_kernel(KssArgs a) {
     if (p.noise_tab >= 0) nz *= p.noise_mult[a.pts.cat[(int64_t)p.noise_tab * a.pts.npad + m]];
     v += nz;
   }
-  a.kss[m] = (m < a.pts.n) ? v : 0.0;
+  if (a.accumulate) {
+    if (m < a.pts.n) a.kss[m] += v;
+  } else {
+    a.kss[m] = (m < a.pts.n) ? v : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

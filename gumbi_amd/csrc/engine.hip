@@ -78,6 +78,15 @@ struct gmb_engine {
   double* dnoise = nullptr;
   CovParams cp{};
   PrepArgs prep_proto{};
+  // Additive models: term 0 (the global kernel) is (prep_proto, cp); term 1 + j is the kernel of
+  // coregion dim j.  Covariances are built and differentiated term by term (accumulating passes).
+  struct Term {
+    PrepArgs pa;
+    CovParams cp;
+    double eta;
+    int n_tab_acc;  // tables whose partials this term's gradient pass produces
+  };
+  std::vector<Term> terms;
   std::vector<double> htabs;  // host copies (gradient chain rule)
   std::vector<double> hnoise;
 
@@ -602,6 +611,9 @@ int apply_theta(gmb_engine* e) {
     cp.noise_tab = s.n_coreg;  // the output table's category index
     k += 3 * P;
   }
+  // additive model: per coregion dim one more [ls | eta | (c, tau)] block (validated here, used below)
+  const int k_add = k;
+  if (s.additive) k += s.n_coreg * (n_ls + 1 + (s.n_lin > 0 ? s.n_lin + 1 : 0));
   if (k != (int)e->theta.size()) return fail(e, GMB_EINVAL, "internal: theta packing mismatch");
   if (!e->dtabs) {
     int rc = alloc(e, &e->dtabs, (int64_t)MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS);
@@ -618,12 +630,60 @@ int apply_theta(gmb_engine* e) {
   HIP_TRY(e, hipStreamSynchronize(e->stream));  // host vectors may be rewritten by the caller
   cp.tabs = e->dtabs;
   cp.noise_mult = e->dnoise;
+  // ---- terms ----
+  e->terms.clear();
+  if (!s.additive) {
+    e->terms.push_back(gmb_engine::Term{pa, cp, eta, ntab});
+    return GMB_OK;
+  }
+  const PrepArgs pa_all = pa;
+  const CovParams cp_all = cp;
+  auto select_tables = [&](gmb_engine::Term& t, int dim) {  // dim < 0: output table only
+    int n = 0;
+    auto take = [&](int src) {
+      t.cp.tab_levels[n] = cp_all.tab_levels[src];
+      t.cp.tab_off[n] = cp_all.tab_off[src];
+      t.pa.tab_col[n] = pa_all.tab_col[src];
+      t.pa.tab_levels[n] = pa_all.tab_levels[src];
+      ++n;
+    };
+    if (dim >= 0) take(dim);
+    if (s.out_col >= 0) take(s.n_coreg);
+    t.cp.n_tab = t.pa.n_tab = t.n_tab_acc = n;
+    t.cp.noise_tab = (dim < 0 && s.out_col >= 0 && s.hetero_noise) ? n - 1 : -1;
+  };
+  gmb_engine::Term t0{pa_all, cp_all, eta, 0};
+  select_tables(t0, -1);
+  e->terms.push_back(t0);
+  int ka = k_add;
+  for (int j = 0; j < s.n_coreg; ++j) {
+    gmb_engine::Term t{pa_all, cp_all, 0.0, 0};
+    for (int i = 0; i < s.n_cont; ++i) {
+      const double ls = th[ka + (s.ard ? i : 0)];
+      if (!(ls > 0.0)) return fail(e, GMB_EINVAL, "lengthscale %d of additive term %d = %g must be positive", i, j, ls);
+      t.pa.inv_ls[i] = 1.0 / ls;
+    }
+    ka += n_ls;
+    t.eta = th[ka++];
+    t.cp.eta2 = t.eta * t.eta;
+    if (s.n_lin > 0) {
+      for (int i = 0; i < s.n_lin; ++i) t.pa.c_lin[i] = th[ka + i];
+      t.cp.tau = th[ka + s.n_lin];
+      ka += s.n_lin + 1;
+    }
+    t.cp.sigma2 = 0.0;  // the noise is written by the first pass only
+    t.cp.jitter = 0.0;
+    select_tables(t, j);
+    e->terms.push_back(t);
+  }
+  pa = e->terms[0].pa;  // the engine-wide defaults are the global term
+  cp = e->terms[0].cp;
   return GMB_OK;
 }
 
 int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int64_t npad, double* xs,
-                double* xl, int32_t* cat) {
-  PrepArgs a = e->prep_proto;
+                double* xl, int32_t* cat, const PrepArgs* proto = nullptr) {
+  PrepArgs a = proto ? *proto : e->prep_proto;
   a.X = dXraw;
   a.n = n;
   a.ldx = ldx;
@@ -1261,7 +1321,8 @@ int launch_grad_nc(gmb_engine* e, const GradArgs& a, int nblocks) {
   return GMB_OK;
 }
 
-constexpr int GACC_DOUBLES = 64 + MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS + 64;
+constexpr int GACC_REGION = 64 + MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS + 64;  // accumulators of one term
+constexpr int GACC_DOUBLES = (1 + GMB_MAX_COREG) * GACC_REGION;  // additive models: one region per term
 
 // Device part of the gradient: inverse, alpha, Sigma^-1 and the trace reductions over the block
 // rows shard, shard + nshards, ... of the lower triangle; `h` receives the raw accumulators (they
@@ -1339,44 +1400,52 @@ int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& 
     g.beta = 0.0;
     if ((rc = launch_gemm(e, g, 4))) return rc;
   }
-  // 4. fused trace reductions
+  // 4. fused trace reductions, one pass per covariance term (additive models have several); term
+  //    t accumulates into region t of dgpart: [ls.. | eta | tau | c.. ] at 0, its tables from 64
   HIP_TRY(e, hipMemsetAsync(e->dgpart, 0, GACC_DOUBLES * sizeof(double), e->stream));
-  GradArgs a{};
-  a.p = e->cp;
-  a.pts = train_set(e);
-  a.Z = e->dW;
-  a.ldz = e->Np;
-  a.alpha = e->dalpha;
-  a.tiles = nt;
-  a.ard = s.ard;
-  a.nc_real = s.n_cont;
-  for (int k = 0; k < 16; ++k) a.inv_ls[k] = k < s.n_cont ? e->prep_proto.inv_ls[k] : 0.0;
   const int n_ls = s.ard ? s.n_cont : 1;
-  a.eta = e->theta[n_ls];
-  a.acc = e->dgpart;
-  a.row_first = shard;
-  a.row_stride = nshards;
-  const int ntab = spec_ntab(s);
-  int off = 64;
-  for (int t = 0; t < ntab; ++t) {
-    a.tab_acc_off[t] = off;
-    off += e->cp.tab_levels[t] * e->cp.tab_levels[t];
-  }
-  const int diag_off = off;  // [sigma, noise table...]
   int nblocks = 0;
   for (int i = shard; i < nt; i += nshards) nblocks += i + 1;
-  if (nblocks > 0) switch (e->cp.kind) {
-    case GMB_EXPQUAD: rc = launch_grad_nc<0>(e, a, nblocks); break;
-    case GMB_MATERN52: rc = launch_grad_nc<1>(e, a, nblocks); break;
-    case GMB_MATERN32: rc = launch_grad_nc<2>(e, a, nblocks); break;
-    case GMB_MATERN12: rc = launch_grad_nc<3>(e, a, nblocks); break;
-    default: rc = launch_grad_nc<4>(e, a, nblocks); break;
+  for (size_t t = 0; t < e->terms.size(); ++t) {
+    const gmb_engine::Term& tr = e->terms[t];
+    if (t > 0 && (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &tr.pa))) return rc;
+    GradArgs a{};
+    a.p = tr.cp;
+    a.pts = train_set(e);
+    a.Z = e->dW;
+    a.ldz = e->Np;
+    a.alpha = e->dalpha;
+    a.tiles = nt;
+    a.ard = s.ard;
+    a.nc_real = s.n_cont;
+    for (int k = 0; k < 16; ++k) a.inv_ls[k] = k < s.n_cont ? tr.pa.inv_ls[k] : 0.0;
+    a.eta = tr.eta;
+    a.acc = e->dgpart + (int64_t)t * GACC_REGION;
+    a.row_first = shard;
+    a.row_stride = nshards;
+    int off = 64;
+    for (int j = 0; j < tr.cp.n_tab; ++j) {
+      a.tab_acc_off[j] = off;
+      off += tr.cp.tab_levels[j] * tr.cp.tab_levels[j];
+    }
+    if (nblocks > 0) switch (tr.cp.kind) {
+      case GMB_EXPQUAD: rc = launch_grad_nc<0>(e, a, nblocks); break;
+      case GMB_MATERN52: rc = launch_grad_nc<1>(e, a, nblocks); break;
+      case GMB_MATERN32: rc = launch_grad_nc<2>(e, a, nblocks); break;
+      case GMB_MATERN12: rc = launch_grad_nc<3>(e, a, nblocks); break;
+      default: rc = launch_grad_nc<4>(e, a, nblocks); break;
+    }
+    if (rc) return rc;
+    if (t == 0) {  // diagonal terms (sigma, noise table) with the global term's categories in place
+      const double sigma = e->theta[n_ls + 1];
+      hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, e->dW, e->Np, e->dalpha,
+                         train_set(e), tr.cp, sigma, e->dgpart + off, shard, nshards);
+      HIP_TRY(e, hipGetLastError());
+    }
   }
-  if (rc) return rc;
-  const double sigma = e->theta[n_ls + 1];
-  hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, e->dW, e->Np, e->dalpha,
-                     train_set(e), e->cp, sigma, e->dgpart + diag_off, shard, nshards);
-  HIP_TRY(e, hipGetLastError());
+  if (e->terms.size() > 1 &&
+      (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
+    return rc;
   tg.stop();
   h.assign(GACC_DOUBLES, 0.0);
   HIP_TRY(e, hipMemcpyAsync(h.data(), e->dgpart, GACC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
@@ -1391,47 +1460,82 @@ int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& 
 int grad_chain_rule(gmb_engine* e, const std::vector<double>& h, double* grad) {
   const gmb_kernel_spec& s = e->spec;
   const int n_ls = s.ard ? s.n_cont : 1;
-  const int ntab = spec_ntab(s);
-  int tab_acc_off[MAX_TABS] = {0};
-  int off = 64;
-  for (int t = 0; t < ntab; ++t) {
-    tab_acc_off[t] = off;
-    off += e->cp.tab_levels[t] * e->cp.tab_levels[t];
-  }
-  const int diag_off = off;
   const double* th = e->theta.data();
-  int k = 0;
-  for (int i = 0; i < n_ls; ++i) grad[k++] = h[i];
-  grad[k++] = h[n_ls];              // eta
-  grad[k++] = h[diag_off];          // sigma
-  if (s.n_lin > 0) {
-    for (int i = 0; i < s.n_lin; ++i) grad[k++] = h[n_ls + 2 + i];
-    grad[k++] = h[n_ls + 1];        // tau
-  }
-  for (int t = 0; t < ntab; ++t) {
-    const int L = e->cp.tab_levels[t];
-    const double* G = h.data() + tab_acc_off[t];
-    const double* W = th + k;
+  auto region = [&](size_t t) { return h.data() + t * GACC_REGION; };
+  auto table_slot = [&](size_t t, int j) {  // j-th table of term t inside its region
+    int off = 64;
+    for (int q = 0; q < j; ++q) off += e->terms[t].cp.tab_levels[q] * e->terms[t].cp.tab_levels[q];
+    return region(t) + off;
+  };
+  auto kernel_block = [&](size_t t, double* g) {  // [ls | eta] and, after a gap the caller fills, [c | tau]
+    const double* r = region(t);
+    int k = 0;
+    for (int i = 0; i < n_ls; ++i) g[k++] = r[i];
+    g[k++] = r[n_ls];
+    return k;
+  };
+  auto table_grad = [&](const std::vector<double>& G, int L, const double* W, double* g) {
     for (int x = 0; x < L; ++x)
       for (int q = 0; q < 2; ++q) {
         double acc = 0.0;
         for (int b = 0; b < L; ++b) acc += (G[x * L + b] + G[b * L + x]) * W[2 * b + q];
-        grad[k + 2 * x + q] = acc;
+        g[2 * x + q] = acc;
       }
-    for (int x = 0; x < L; ++x) grad[k + 2 * L + x] = G[x * L + x];
+    for (int x = 0; x < L; ++x) g[2 * L + x] = G[x * L + x];
+  };
+  // global term: ls | eta | sigma | c | tau
+  int k = kernel_block(0, grad);
+  const int i_sigma = k++;
+  if (s.n_lin > 0) {
+    for (int i = 0; i < s.n_lin; ++i) grad[k++] = region(0)[n_ls + 2 + i];
+    grad[k++] = region(0)[n_ls + 1];  // tau
+  }
+  // coregion tables of the categorical dims, then the output table
+  const int ntab = spec_ntab(s);
+  for (int j = 0; j < ntab; ++j) {
+    const bool is_out = (j == s.n_coreg);
+    const int L = is_out ? s.n_out : s.coreg_levels[j];
+    std::vector<double> G((size_t)L * L, 0.0);
+    if (!s.additive) {
+      const double* src = table_slot(0, j);
+      for (int i = 0; i < L * L; ++i) G[i] = src[i];
+    } else if (!is_out) {
+      const double* src = table_slot(1 + j, 0);  // the dim's own term carries its table first
+      for (int i = 0; i < L * L; ++i) G[i] = src[i];
+    } else {
+      for (size_t t = 0; t < e->terms.size(); ++t) {  // every term is multiplied by the output table
+        const double* src = table_slot(t, e->terms[t].cp.n_tab - 1);
+        for (int i = 0; i < L * L; ++i) G[i] += src[i];
+      }
+    }
+    table_grad(G, L, th + k, grad + k);
     k += 3 * L;
   }
+  // noise: region 0 keeps [sigma, noise table ...] after the global term's tables
+  int diag_off = 64;
+  for (int j = 0; j < e->terms[0].cp.n_tab; ++j) diag_off += e->terms[0].cp.tab_levels[j] * e->terms[0].cp.tab_levels[j];
+  const double* hd = region(0) + diag_off;
+  grad[i_sigma] = hd[0];
   if (s.out_col >= 0 && s.hetero_noise) {
     const int P = s.n_out;
     const double* W = th + k;
     for (int x = 0; x < P; ++x) {
-      const double gd = h[diag_off + 1 + x];
+      const double gd = hd[1 + x];
       grad[k + 2 * x] = 2.0 * gd * W[2 * x];
       grad[k + 2 * x + 1] = 2.0 * gd * W[2 * x + 1];
       grad[k + 2 * P + x] = gd;
     }
     k += 3 * P;
   }
+  // additive terms: ls | eta | c | tau per coregion dim
+  if (s.additive)
+    for (int j = 0; j < s.n_coreg; ++j) {
+      k += kernel_block(1 + j, grad + k);
+      if (s.n_lin > 0) {
+        for (int i = 0; i < s.n_lin; ++i) grad[k++] = region(1 + j)[n_ls + 2 + i];
+        grad[k++] = region(1 + j)[n_ls + 1];
+      }
+    }
   if (k != (int)e->theta.size()) return fail(e, GMB_EINVAL, "internal: gradient packing mismatch");
   return GMB_OK;
 }
@@ -1608,6 +1712,10 @@ int gmb_theta_size(const gmb_kernel_spec* s) {
     n += 3 * s->n_out;
     if (s->hetero_noise) n += 3 * s->n_out;
   }
+  if (s->additive) {
+    const int blk = (s->ard ? s->n_cont : 1) + 1 + (s->n_lin > 0 ? s->n_lin + 1 : 0);
+    n += s->n_coreg * blk;
+  }
   return n;
 }
 
@@ -1732,6 +1840,16 @@ int gmb_factorize(gmb_engine* e) {
     a.tri_grid = 1;
     a.y = e->dy;
     if ((rc = launch_cov(e, a))) return rc;
+    // additive models: the other terms add their covariance to the real entries, one pass each
+    for (size_t t = 1; t < e->terms.size(); ++t) {
+      if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[t].pa))) return rc;
+      a.p = e->terms[t].cp;
+      a.accumulate = 1;
+      if ((rc = launch_cov(e, a))) return rc;
+    }
+    if (e->terms.size() > 1 &&
+        (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
+      return rc;
   }
   tk.stop();
   // 2. Cholesky
@@ -1943,14 +2061,37 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
       a.mode = COV_CROSS;
       if ((rc = launch_cov(e, a))) return rc;
     }
+    KssArgs k{};
+    k.p = e->cp;
+    k.pts = test;
+    k.with_noise = with_noise;
+    k.kss = e->dkss;
+    hipLaunchKernelGGL(kss_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, e->stream, k);
+    for (size_t t = 1; t < e->terms.size(); ++t) {  // additive models: one accumulating pass per further term
+      const gmb_engine::Term& tr = e->terms[t];
+      if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &tr.pa))) return rc;
+      if ((rc = prep_points(e, e->dXs, mc, e->D, mpad, e->txs, e->txl, e->tcat, &tr.pa))) return rc;
+      CovTileArgs a{};
+      a.p = tr.cp;
+      a.rows = test;
+      a.cols = train_set(e);
+      a.out = e->dV;
+      a.ldo = mpad;
+      a.ti = (int)(mpad / TILE);
+      a.tj = (int)(e->Np / TILE);
+      a.mode = COV_CROSS;
+      a.accumulate = 1;
+      if ((rc = launch_cov(e, a))) return rc;
+      k.p = tr.cp;
+      k.with_noise = 0;
+      k.accumulate = 1;
+      hipLaunchKernelGGL(kss_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, e->stream, k);
+    }
+    if (e->terms.size() > 1 &&
+        (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
+      return rc;
     if ((rc = trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, (int)(e->Np / TILE), 3, 6))) return rc;
     {
-      KssArgs k{};
-      k.p = e->cp;
-      k.pts = test;
-      k.with_noise = with_noise;
-      k.kss = e->dkss;
-      hipLaunchKernelGGL(kss_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, e->stream, k);
       double* pmu = e->dpart;
       double* ps = e->dpart + (int64_t)nchunk * mpad;
       hipLaunchKernelGGL(predict_partial_kernel, dim3((unsigned)(mpad / 256 + (mpad % 256 ? 1 : 0)), nchunk),
@@ -2283,7 +2424,15 @@ int gmb_blk_kbuild(gmb_engine* e, double* out, int64_t ldo, int64_t i0, int64_t 
   a.mode = COV_TRAIN;
   a.lower_only = 1;
   a.y = e->dy;
-  return launch_cov(e, a);
+  if ((rc = launch_cov(e, a))) return rc;
+  for (size_t t = 1; t < e->terms.size(); ++t) {  // additive models: accumulating passes
+    if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[t].pa))) return rc;
+    a.p = e->terms[t].cp;
+    a.accumulate = 1;
+    if ((rc = launch_cov(e, a))) return rc;
+  }
+  if (e->terms.size() > 1) return prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa);
+  return GMB_OK;
 }
 
 }  // extern "C"

@@ -44,6 +44,7 @@ class _Spec(C.Structure):
         ("out_col", C.c_int32),
         ("n_out", C.c_int32),
         ("hetero_noise", C.c_int32),
+        ("additive", C.c_int32),
         ("jitter", C.c_double),
     ]
 
@@ -91,6 +92,7 @@ class KernelSpec:
     n_out: int = 0
     hetero_noise: bool = True
     jitter: float = 1e-6
+    additive: bool = False  # a global kernel + one kernel per coregion dim (specify_model(additive=True))
 
     @property
     def kind_id(self) -> int:
@@ -104,7 +106,8 @@ class KernelSpec:
         return dict(D=int(self.D), kind=self.kind_id, ard=bool(self.ard),
                     idx_cont=[int(i) for i in self.idx_cont], idx_lin=[int(i) for i in self.idx_lin],
                     coreg=[(int(c), int(n)) for c, n in self.coreg], out_col=int(self.out_col),
-                    n_out=int(self.n_out), hetero_noise=bool(self.hetero_noise), jitter=float(self.jitter))
+                    n_out=int(self.n_out), hetero_noise=bool(self.hetero_noise), jitter=float(self.jitter),
+                    additive=bool(self.additive))
 
     def theta_size(self) -> int:
         n = (len(self.idx_cont) if self.ard else 1) + 2
@@ -113,6 +116,9 @@ class KernelSpec:
         n += sum(3 * L for _, L in self.coreg)
         if self.out_col >= 0:
             n += 3 * self.n_out * (2 if self.hetero_noise else 1)
+        if self.additive:  # one more [ls | eta | (c, tau)] block per coregion dim
+            blk = (len(self.idx_cont) if self.ard else 1) + 1 + ((len(self.idx_lin) + 1) if self.idx_lin else 0)
+            n += len(self.coreg) * blk
         return n
 
     def to_c(self) -> _Spec:
@@ -135,6 +141,7 @@ class KernelSpec:
             s.coreg_col[i], s.coreg_levels[i] = int(col), int(lev)
         s.out_col, s.n_out = int(self.out_col), int(self.n_out)
         s.hetero_noise = int(bool(self.hetero_noise))
+        s.additive = int(bool(self.additive))
         s.jitter = float(self.jitter)
         return s
 

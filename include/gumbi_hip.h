@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 1
+#define GMB_ABI_VERSION 2
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -77,6 +77,10 @@ typedef struct gmb_kernel_spec {
   int32_t out_col;                   /* output-coregion column or -1 (single output)           */
   int32_t n_out;                     /* number of outputs P                                    */
   int32_t hetero_noise;              /* heteroskedastic_outputs (pymc/GP.py:565)               */
+  int32_t additive;                  /* specify_model(additive=True) (pymc/GP.py:732-754): a global
+                                      * kernel plus one kernel per coregion dim, each times that dim's
+                                      * table (and the output table); theta gains, after the layout
+                                      * above, one block [ls | eta | (c, tau)] per coregion dim     */
   double jitter;                     /* 1e-6 to follow pm.gp.Marginal                          */
 } gmb_kernel_spec;
 

@@ -27,14 +27,14 @@ def test_header_symbols_are_all_exported(lib):
     assert declared == set(engine.exported_symbols()), declared ^ set(engine.exported_symbols())
     for name in declared:
         assert hasattr(lib, name), f"{name} missing from libgumbi_hip.so"
-    assert lib.gmb_abi_version() == 1
+    assert lib.gmb_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     from gumbi_amd import engine
 
-    # gmb_kernel_spec: 3 + 16 + 1 + 8 + 1 + 4 + 4 + 3 int32 (= 40) then one double
-    assert engine.C.sizeof(engine._Spec) == 40 * 4 + 8
+    # gmb_kernel_spec: 3 + 16 + 1 + 8 + 1 + 4 + 4 + 4 int32 (= 41), 4 bytes of padding, then one double
+    assert engine.C.sizeof(engine._Spec) == 41 * 4 + 4 + 8
     assert engine.C.sizeof(engine.Timings) == 21 * 8
     spec = engine.KernelSpec(D=6, idx_cont=[0, 1, 2], idx_lin=[1], coreg=[(3, 4)], out_col=5, n_out=2)
     cs = spec.to_c()
