@@ -151,8 +151,6 @@ class HipGP(Regressor):
             raise NotImplementedError("Heteroskedasticity over inputs is not yet implemented.")
         if sparse:
             raise NotImplementedError("The sparse (FITC) approximation is not part of the HIP backend.")
-        if self.additive:
-            raise NotImplementedError("Additive GPs are not yet part of the HIP backend.")
         periodic = [k + "+Periodic" for k in KERNEL_KINDS] + ["Periodic"]
         assert_in("Continuous kernel", continuous_kernel, list(KERNEL_KINDS) + periodic)
         if continuous_kernel in periodic:
@@ -184,7 +182,8 @@ class HipGP(Regressor):
         spec = KernelSpec(D=D_in, idx_cont=idx["s"], kind=continuous_kernel, ard=ARD, idx_lin=idx["l"],
                           coreg=coreg, out_col=idx["p"] if multi else -1,
                           n_out=len(self.categorical_levels[self.out_col]) if multi else 0,
-                          hetero_noise=bool(heteroskedastic_outputs), jitter=1e-6)
+                          hetero_noise=bool(heteroskedastic_outputs), jitter=1e-6,
+                          additive=bool(self.additive and coreg))
         ls_params = self._prepare_lengthscales(X, ARD=ARD, ls_bounds=ls_bounds, mass=mass)
 
         # parameter blocks in the packing order of include/gumbi_hip.h
@@ -213,6 +212,15 @@ class HipGP(Regressor):
             if spec.hetero_noise:
                 add("W_Output_noise", "real", (P, 2))
                 add("κ_Output_noise", "pos", (P,))
+        if spec.additive:
+            # one more continuous (+ linear) kernel per categorical dimension (reference :732-754),
+            # appended in the order of include/gumbi_hip.h
+            for d in [d for d in self.categorical_dims if d != self.out_col]:
+                add(f"ls_{d}", "pos", (n_ls,))
+                add(f"η_{d}", "pos", ())
+                if idx["l"]:
+                    add(f"c_{d}", "real", (len(idx["l"]),))
+                    add(f"τ_{d}", "pos", ())
         assert k == spec.theta_size()
 
         self.model = HipModel(spec, ls_params, blocks, X, y)
@@ -222,7 +230,7 @@ class HipGP(Regressor):
             from ..distributed import DistributedEngine
 
             self.engine = DistributedEngine(self.device, None if self.distributed is True else self.distributed)
-        elif self.kronecker and spec.out_col >= 0 and icm.aligned_outputs(X, spec):
+        elif self.kronecker and spec.out_col >= 0 and not spec.additive and icm.aligned_outputs(X, spec):
             self.engine = icm.IcmEngine(device=self.device)
         else:
             self.engine = Engine(device=self.device)
@@ -240,16 +248,16 @@ class HipGP(Regressor):
         m = self.model
         theta = np.zeros(m.spec.theta_size())
         for name, _kind, shape, sl in m.blocks:
-            if name == "ls_total":
+            if name.startswith("ls_"):
                 a, b = np.asarray(m.ls_params["alpha"]), np.asarray(m.ls_params["beta"])
                 theta[sl] = np.where(a > 1, b / np.maximum(a - 1, 1e-300), b / (a + 1))
-            elif name == "η_total":
+            elif name.startswith("η_"):
                 theta[sl] = 2.0
             elif name == "σ":
                 theta[sl] = 1.0
-            elif name == "c_total":
+            elif name.startswith("c_"):
                 theta[sl] = 0.0
-            elif name == "τ_total":
+            elif name.startswith("τ_"):
                 theta[sl] = 10.0
             elif name.startswith("W_"):
                 theta[sl] = np.random.default_rng(self.seed).standard_normal(size=shape).ravel()
@@ -263,20 +271,20 @@ class HipGP(Regressor):
         val, grad = 0.0, np.zeros_like(theta)
         for name, _kind, _shape, sl in m.blocks:
             x = theta[sl]
-            if name == "ls_total":
+            if name.startswith("ls_"):
                 a, b = np.asarray(m.ls_params["alpha"], float), np.asarray(m.ls_params["beta"], float)
                 val += np.sum(a * np.log(b) - np.array([lgamma(v) for v in a]) - (a + 1) * np.log(x) - b / x)
                 grad[sl] = -(a + 1) / x + b / x**2
-            elif name == "η_total":  # Gamma(2, 1)
+            elif name.startswith("η_"):  # Gamma(2, 1)
                 val += np.sum(np.log(x) - x)
                 grad[sl] = 1.0 / x - 1.0
             elif name == "σ":  # Exponential(1)
                 val += np.sum(-x)
                 grad[sl] = -1.0
-            elif name == "c_total":  # Normal(0, 10)
+            elif name.startswith("c_"):  # Normal(0, 10)
                 val += np.sum(-0.5 * np.log(2 * np.pi) - np.log(10.0) - 0.5 * (x / 10.0) ** 2)
                 grad[sl] = -x / 100.0
-            elif name == "τ_total":  # HalfNormal(10)
+            elif name.startswith("τ_"):  # HalfNormal(10)
                 val += np.sum(0.5 * np.log(2 / np.pi) - np.log(10.0) - 0.5 * (x / 10.0) ** 2)
                 grad[sl] = -x / 100.0
             elif name.startswith("W_"):  # Normal(0, 3)

@@ -635,6 +635,20 @@ def log_prior_and_jacobian(spec, theta, ls_alpha, ls_beta, jacobian=False):
     for W, kap in pairs:
         tot += np.sum(logp_normal(W, 0.0, 3.0))
         tot += np.sum(logp_gamma(kap, 1.5, 1.0) + J * np.log(kap))
+    if spec.get("additive"):
+        # the per-dimension kernels are built by the same factories (``pymc/GP.py:738-741``), so their
+        # ls / eta / c / tau carry the same priors as the global ones
+        n_ls = len(spec["idx_cont"]) if spec["ard"] else 1
+        theta = np.asarray(theta, float)
+        nb, nk = theta_size(dict(spec, additive=False)), _term_block_size(spec)
+        for j in range(len(spec["coreg"])):
+            blk = theta[nb + j * nk: nb + (j + 1) * nk]
+            ls, eta = blk[:n_ls], blk[n_ls]
+            tot += np.sum(logp_inverse_gamma(ls, a, b) + J * np.log(ls))
+            tot += logp_gamma(eta, 2.0, 1.0) + J * np.log(eta)
+            if spec["idx_lin"]:
+                tot += np.sum(logp_normal(blk[n_ls + 1:-1], 0.0, 10.0))
+                tot += logp_halfnormal(blk[-1], 10.0) + J * np.log(blk[-1])
     return float(tot)
 
 

@@ -103,6 +103,54 @@ def test_map_objective_matches_oracle_formula(gpu):
         assert abs(fd - g[i]) <= 1e-4 * max(1.0, abs(g[i])), (i, fd, g[i])
 
 
+@pytest.mark.parametrize("linear", [False, True])
+def test_additive_model_fit_and_objective(gpu, linear):
+    """``specify_model(additive=True)`` (reference ``pymc/GP.py:732-754``): block names follow the reference's
+    (``ls_<dim>``, ``η_<dim>`` ...), the MAP objective and its gradient match the oracle, the fitted model
+    predicts like the oracle at the same hyper-parameters."""
+    gp = example_gp()
+    gp.specify_model(outputs=["d", "c"], continuous_dims=["X", "Y"], linear_dims=["Y"] if linear else None,
+                     categorical_dims="Name", additive=True)
+    gp.build_model()
+    assert gp.model.spec.additive
+    names = [b[0] for b in gp.model.blocks]
+    assert "ls_Name" in names and "η_Name" in names and ("τ_Name" in names) == linear
+    X, y = gp.get_shaped_data("mean")
+    pos = gp._positive_mask()
+    theta = np.where(pos, np.abs(gp._initial_theta() * 0.9 + 0.05) + 0.05, gp._initial_theta() * 0.9 + 0.05)
+    u = theta.copy()
+    u[pos] = np.log(theta[pos])
+    f, g = gp._objective(u, pos)
+    spec = oracle_spec(gp)
+    nl, gn = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+    lp = O.log_prior_and_jacobian(spec, theta, gp.model.ls_params["alpha"], gp.model.ls_params["beta"])
+    assert np.isclose(f, nl - lp, rtol=1e-9)
+    h = 1e-6
+    for i in range(0, u.size, max(1, u.size // 10)):
+        up, um = u.copy(), u.copy()
+        up[i] += h
+        um[i] -= h
+        th_p, th_m = np.where(pos, np.exp(up), up), np.where(pos, np.exp(um), um)
+        fo = [O.nlml(spec, t, X, y, dist_mode="direct")
+              - O.log_prior_and_jacobian(spec, t, gp.model.ls_params["alpha"], gp.model.ls_params["beta"])
+              for t in (th_p, th_m)]
+        fd = (fo[0] - fo[1]) / (2 * h)
+        assert abs(fd - g[i]) <= 1e-4 * max(1.0, abs(g[i])), (i, fd, g[i])
+    gp.find_MAP(maxeval=40)
+    assert gp.nlml_trace[-1] < gp.nlml_trace[0]
+    assert "ls_Name_log__" in gp.MAP and gp.MAP["W_Name"].shape == (len(gp.categorical_levels["Name"]), 2)
+    gp.prepare_grid(resolution=5)
+    cat = {"Name": gp.categorical_levels["Name"][0]}
+    pred = gp.predict_grid(categorical_levels=cat)
+    pa, _, _ = gp._prepare_points_for_prediction(gp.append_categorical_points(gp.grid_points, cat),
+                                                 output=gp._parse_prediction_output(None))
+    mu, var = O.predict(spec, gp._theta_fitted, X, y, pa, with_noise=True)
+    mu_g, var_g = gp.predict(pa)
+    assert np.max(np.abs(mu_g - mu)) <= 1e-8 * max(np.max(np.abs(mu)), 1e-3)
+    assert np.max(np.abs(var_g - var)) <= 1e-8
+    assert pred.shape == gp.grid_parray.shape
+
+
 def test_unsupported_options_raise_like_reference(gpu):
     gp = example_gp().specify_model(continuous_dims=["X", "Y"])
     with pytest.raises(NotImplementedError):

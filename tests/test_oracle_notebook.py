@@ -111,3 +111,41 @@ def test_the_jacobian_reading_of_find_map_does_not(monkeypatch):
     restated behaviour (pymc/tuning/starting.py: ``model.compile_logp(jacobian=False)``)."""
     mu, s2 = _fit_and_predict(monkeypatch, jacobian=True)
     assert np.max(np.abs(s2 - NB_S2) / NB_S2) > 0.2
+
+
+def test_additive_front_end_blocks_and_prior_on_cpu(monkeypatch):
+    """Host logic of ``specify_model(additive=True)`` (reference ``pymc/GP.py:732-754``) with the oracle standing
+    in for the engine: parameter blocks (names and order of include/gumbi_hip.h), prior sum, MAP dictionary."""
+    import gumbi_amd as gmb
+    from gumbi_amd.regression import hip_gp
+
+    monkeypatch.setattr(hip_gp, "Engine", OracleEngine)
+    df = pd.read_pickle(GOLD / "example_dataset.pkl")
+    df = df[(df.Color == "cyan") & (df.Metric == "mean") & df.Name.isin(sorted(df.Name.unique())[:3])]
+    ds = gmb.DataSet(df, outputs=["a", "b", "c", "d", "e", "f"], log_vars=["Y", "b", "c", "d", "f"],
+                     logit_vars=["X", "e"])
+    gp = gmb.GP(ds, outputs=["d"], kronecker=False)
+    gp.specify_model(continuous_dims=["lg10_Z"], linear_dims=["lg10_Z"], categorical_dims="Name", additive=True)
+    gp.build_model()
+    spec = gp.model.spec
+    assert spec.additive and spec.theta_size() == O.theta_size(spec.as_dict())
+    names = [b[0] for b in gp.model.blocks]
+    assert names == ["ls_total", "η_total", "σ", "c_total", "τ_total", "W_Name", "κ_Name",
+                     "ls_Name", "η_Name", "c_Name", "τ_Name"]
+    theta = gp._initial_theta()
+    assert theta[gp.model.blocks[names.index("η_Name")][3]] == 2.0
+    lp, glp = gp._log_prior(theta)
+    a, b = gp.model.ls_params["alpha"], gp.model.ls_params["beta"]
+    assert np.isclose(lp, O.log_prior_and_jacobian(spec.as_dict(), theta, a, b), rtol=1e-12)
+    h = 1e-6
+    for i in range(theta.size):
+        tp, tm = theta.copy(), theta.copy()
+        tp[i] += h
+        tm[i] -= h
+        assert abs((gp._log_prior(tp)[0] - gp._log_prior(tm)[0]) / (2 * h) - glp[i]) <= 1e-5 * max(1, abs(glp[i]))
+    gp.find_MAP(maxeval=25)
+    assert gp.nlml_trace[-1] < gp.nlml_trace[0]
+    assert {"ls_Name", "ls_Name_log__", "η_Name", "τ_Name", "c_Name", "W_Name", "κ_Name"} <= set(gp.MAP)
+    X = gp.prepare_grid(resolution=7)
+    pred = gp.predict_grid(categorical_levels={"Name": gp.categorical_levels["Name"][1]})
+    assert pred.shape == gp.grid_parray.shape and np.all(np.isfinite(pred.μ)) and np.all(pred.σ2 > 0)
