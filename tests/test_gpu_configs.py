@@ -61,6 +61,40 @@ def icm_problem(n, d, seed=2021):
     return X, y, spec, theta
 
 
+def test_c2_full_size_direct_parity_and_dense_grid(gpu):
+    """C2 at its full size (N = 10k, d = 4, RBF-ARD) straight against the oracle (one LAPACK Cholesky of
+    the 10k x 10k covariance on the host, seconds): NLML, and mean / variance at points sampled from the
+    dense M = 20^4 = 160,000 grid over all four dims of SURVEY.md section 8d, which the engine predicts
+    in full (M-tiled: the N x M solve never exists as a whole)."""
+    import time
+
+    N, d = 10_000, 4
+    X, y, ls = O.synthetic_table(N, d)
+    spec = O.make_spec(d, range(d))
+    sigma = 0.2
+    theta = O.pack_theta(spec, ls, 1.0, sigma)
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    g = np.linspace(-2.4, 2.4, 20)
+    Xs = np.stack(np.meshgrid(g, g, g, g, indexing="ij"), axis=-1).reshape(-1, d)
+    assert Xs.shape == (160_000, 4)
+    eng.predict(Xs[:4096])
+    t0 = time.perf_counter()
+    mu, var = eng.predict(Xs, with_noise=True)
+    dt = time.perf_counter() - t0
+    assert np.all(np.isfinite(mu)) and np.all(var > sigma**2) and np.all(var <= 1.0 + sigma**2 + 1e-9)
+    # N^2 M = 1.6e13 flops; anything below 10 TF/s would mean the M-tiling fell off the MFMA path
+    assert float(N) ** 2 * len(Xs) / dt > 1.0e13, dt
+    sub = np.random.default_rng(5).choice(len(Xs), 48, replace=False)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs[sub], with_noise=True)
+    assert rel(mu[sub], mu_r) < 1e-8 and np.max(np.abs(var[sub] - var_r)) < 1e-9
+    # the same points in a different batch composition give the same numbers (tiling independence)
+    mu_s, var_s = eng.predict(Xs[sub], with_noise=True)
+    assert rel(mu_s, mu[sub]) < 1e-12 and np.max(np.abs(var_s - var[sub])) < 1e-12
+    assert np.isclose(eng.nlml(), O.nlml(spec, theta, X, y), rtol=1e-10)
+    eng.close()
+
+
 def test_c3_midsize_parity(gpu):
     N, d = 4000, 8
     X, y, ls = O.synthetic_table(N, d)
