@@ -237,6 +237,28 @@ def distributed_section(world, local_rank, dist):
     }
 
 
+def run_with_deadline(fn, seconds):
+    """fn() on a helper thread; (result, finished).  A collective that never completes (a peer
+    died, a link is down) must not take the headline line with it: the caller prints what it has
+    and leaves with os._exit."""
+    import threading
+
+    box = {}
+
+    def target():
+        try:
+            box["value"] = fn()
+        except Exception as err:  # never lose the headline line to the side measurement
+            box["value"] = {"error": f"{type(err).__name__}: {err}"[:300]}
+
+    th = threading.Thread(target=target, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": f"no result after {seconds:.0f} s (collective did not complete)"}, False
+    return box["value"], True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,12 +344,13 @@ def main():
     eng.close()
     gp.engine = None
 
-    dist_info = None
+    dist_info, healthy = None, True
     if os.environ.get("GUMBI_BENCH_NO_DIST") != "1" and args.config == "c2":
-        try:
-            dist_info = distributed_section(world, local_rank, dist)
-        except Exception as err:  # never lose the headline line to the side measurement
-            dist_info = {"error": f"{type(err).__name__}: {err}"[:300]}
+        def section():
+            torch.cuda.set_device(local_rank)  # the current device is per-thread state
+            return distributed_section(world, local_rank, dist)
+
+        dist_info, healthy = run_with_deadline(section, float(os.environ.get("GUMBI_BENCH_DIST_DEADLINE", "300")))
 
     flops_total = sum(step_flops(cfg["N"], M, n) for n in n_evals) * world
 
@@ -388,10 +411,19 @@ def main():
             out["distributed"] = dist_info
         if not args.no_cpu_baseline and world == 1 and os.environ.get("GUMBI_BENCH_NO_CPU") != "1":
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out, ensure_ascii=False))
+        print(json.dumps(out, ensure_ascii=False), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        def leave():
+            torch.cuda.set_device(local_rank)
+            dist.barrier()
+            dist.destroy_process_group()
+
+        if healthy:
+            _, healthy = run_with_deadline(leave, 180.0)
+        if not healthy:
+            sys.stderr.write(f"[bench rank {rank}] leaving without the final barrier\n")
+            sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":
