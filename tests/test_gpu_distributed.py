@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, N, d, M, out):
+def _worker(rank, world, port, N, d, M, out, model="matern"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch  # noqa: F401
@@ -22,13 +22,25 @@ def _worker(rank, world, port, N, d, M, out):
         from gumbi_amd.engine import KernelSpec
         from oracle import gp_oracle as O
 
-        X, y, ls = O.synthetic_table(N, d, seed=5)
-        spec = O.make_spec(d, range(d), kind="Matern52")
-        theta = O.pack_theta(spec, ls, 1.1, 0.3)
-        Xs = np.random.default_rng(1).standard_normal((M, d))
+        if model == "additive":
+            # additive two-output model with a linear and a categorical dim (reference pymc/GP.py:732-754):
+            # the K-build of the owned block rows and the sharded gradient run term by term
+            from test_oracle import additive_problem
+
+            spec, theta, X, y = additive_problem(n=N // 2)
+            Xs = X[::3].copy()
+            Xs[:, 0] += 0.21
+            kspec = KernelSpec(**{k: spec[k] for k in ("D", "idx_cont", "kind", "ard", "idx_lin", "coreg", "out_col",
+                                                        "n_out", "hetero_noise", "jitter", "additive")})
+        else:
+            X, y, ls = O.synthetic_table(N, d, seed=5)
+            spec = O.make_spec(d, range(d), kind="Matern52")
+            theta = O.pack_theta(spec, ls, 1.1, 0.3)
+            Xs = np.random.default_rng(1).standard_normal((M, d))
+            kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind="Matern52")
         eng = DistributedEngine(0)
         eng.set_data(X, y)
-        eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d)), kind="Matern52"))
+        eng.set_kernel(kspec)
         eng.set_theta(theta)
         eng.factorize()
         L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
@@ -62,14 +74,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,N", [(2, 700), (2, 512), (3, 1000)])
-def test_two_ranks_one_gpu_match_oracle(gpu, world, N):
+@pytest.mark.parametrize("world,N,model", [(2, 700, "matern"), (2, 512, "matern"), (3, 1000, "matern"),
+                                           (2, 600, "additive")])
+def test_two_ranks_one_gpu_match_oracle(gpu, world, N, model):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, 333, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, 333, out, model)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=300) for _ in range(world)]
