@@ -1,11 +1,13 @@
-"""A/B environment-variable settings (argv: VAR=val[,VAR2=val2] ...) on factorize / predict / gradient."""
+"""A/B environment-variable settings (argv: VAR=val[,VAR2=val2] ...) on factorize / predict / gradient;
+AB_SIZES=10000x4,30000x8 picks the (N, d) cases."""
 import os, subprocess, sys
 CODE = r'''
 import sys, time; sys.path.insert(0, '.')
 import numpy as np
 from gumbi_amd import engine
 from oracle import gp_oracle as O
-for N, d in ((10000, 4), (30000, 8)):
+import os
+for N, d in [tuple(int(v) for v in t.split('x')) for t in os.environ.get('AB_SIZES', '10000x4,30000x8').split(',')]:
     X, y, ls = O.synthetic_table(N, d); Xs = O.synthetic_grid(d)
     e = engine.Engine(0); e.set_data(X, y); e.set_kernel(engine.KernelSpec(D=d, idx_cont=list(range(d)))); e.set_theta(np.concatenate([ls, [1.0, 0.2]]))
     e.factorize(); e.predict(Xs); e.factorize(); e.nlml(grad=True)
