@@ -237,8 +237,14 @@ def _preload_hip_runtime():
         pass  # fall back to whatever libamdhip64.so.7 the loader finds
 
 
+#: GMB_ABI_VERSION of include/gumbi_hip.h this binding was written against (the layout of
+#: ``gmb_kernel_spec`` changed with version 2: ``additive``)
+ABI_VERSION = 2
+
+
 def load_library():
-    """Load libgumbi_hip.so (once) and attach the prototypes.  Raises if it is not built."""
+    """Load libgumbi_hip.so (once) and attach the prototypes.  Raises if it is not built or was
+    built from another version of the header."""
     global _LIB
     if _LIB is not None:
         return _LIB
@@ -253,6 +259,9 @@ def load_library():
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header / library mismatch
         fn.restype, fn.argtypes = restype, argtypes
+    if lib.gmb_abi_version() != ABI_VERSION:
+        raise GumbiHipError(f"{path} has ABI version {lib.gmb_abi_version()}, this binding needs {ABI_VERSION}: "
+                            f"rebuild it (`python -m gumbi_amd.build`)")
     _LIB = lib
     return lib
 

@@ -27,7 +27,6 @@ confirmed against the predictions printed in the reference's Multioutput_Regress
 
 from __future__ import annotations
 
-import warnings
 from math import lgamma
 
 import numpy as np

@@ -27,7 +27,9 @@ def test_header_symbols_are_all_exported(lib):
     assert declared == set(engine.exported_symbols()), declared ^ set(engine.exported_symbols())
     for name in declared:
         assert hasattr(lib, name), f"{name} missing from libgumbi_hip.so"
-    assert lib.gmb_abi_version() == 2
+    header = (ROOT / "include" / "gumbi_hip.h").read_text()
+    declared = int(re.search(r"#define\s+GMB_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.gmb_abi_version() == declared == engine.ABI_VERSION
 
 
 def test_struct_layouts_match_header():
