@@ -143,8 +143,31 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     const int hi = m > r16 ? m : r16, lo = m > r16 ? r16 : m;
     acc[r] = Sd[lo * pitch + hi];
   }
-  double Lcol[4], ax[4], rinv[4][4];
-  int badcol = -1;
+  double Lcol[4], ax[4];
+  // position masks of this lane: mx[] over the lower triangle (i, k <= i) of a 4 x 4 piece held at
+  // lanes (r16 = i, kq = k); keep[q] over the rows / columns that take part in step q
+  double mx[10], keep[4];
+  {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k <= i; ++k) mx[n++] = (r16 == i && kq == k) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int a = r16 - 4 * q;
+      keep[q] = (a < 0 || (a < 4 && kq > a)) ? 0.0 : 1.0;
+    }
+  }
+  unsigned badbits = 0;  // bit c: pivot c was not positive (one OR per pivot; the column is decoded at the end)
+  // X = L^-1 (16 x 16) by forward substitution on the identity, 4 rows per step, INTERLEAVED with the
+  // factor steps: step q of the substitution needs only X44_q and the solved panel of factor step q,
+  // and its two MFMAs run on the matrix pipe while the vector pipe works through the pivot chain of
+  // factor step q + 1 (as a separate loop after the factorisation it cost 1460 cycles of 8400).
+  d4 e;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[r] = (kq + 4 * r == r16) ? 1.0 : 0.0;
+  double Xrow[4];
   D16_STAMP(1);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -160,7 +183,7 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     double p = t00;
     {
       const bool bad = !(p > 0.0);
-      badcol = (bad && badcol < 0) ? j0 + 0 : badcol;
+      badbits |= bad ? (1u << (j0 + 0)) : 0u;
       p = bad ? 1.0 : p;
     }
     sqrt_rsqrt(p, l00, r0);
@@ -168,7 +191,7 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     p = fma(-l10, l10, t11);
     {
       const bool bad = !(p > 0.0);
-      badcol = (bad && badcol < 0) ? j0 + 1 : badcol;
+      badbits |= bad ? (1u << (j0 + 1)) : 0u;
       p = bad ? 1.0 : p;
     }
     sqrt_rsqrt(p, l11, r1);
@@ -176,7 +199,7 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     p = fma(-l21, l21, fma(-l20, l20, t22));
     {
       const bool bad = !(p > 0.0);
-      badcol = (bad && badcol < 0) ? j0 + 2 : badcol;
+      badbits |= bad ? (1u << (j0 + 2)) : 0u;
       p = bad ? 1.0 : p;
     }
     sqrt_rsqrt(p, l22, r2);
@@ -184,7 +207,7 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     p = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, t33)));
     {
       const bool bad = !(p > 0.0);
-      badcol = (bad && badcol < 0) ? j0 + 3 : badcol;
+      badbits |= bad ? (1u << (j0 + 3)) : 0u;
       p = bad ? 1.0 : p;
     }
     sqrt_rsqrt(p, l33, r3);
@@ -195,57 +218,48 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
     const double x20 = -fma(l21, x10, l20 * r0) * r2;
     const double x31 = -fma(l32, x21, l31 * r1) * r3;
     const double x30 = -fma(l32, x20, fma(l31, x10, l30 * r0)) * r3;
-    rinv[q][0] = r0; rinv[q][1] = r1; rinv[q][2] = r2; rinv[q][3] = r3;
-    // X44 as an MFMA A operand: lane (i = r16, k = kq) holds X44[r16][kq] for r16 < 4, else 0
-    {
-      const double row0 = kq == 0 ? r0 : 0.0;
-      const double row1 = kq == 0 ? x10 : (kq == 1 ? r1 : 0.0);
-      const double row2 = kq == 0 ? x20 : (kq == 1 ? x21 : (kq == 2 ? r2 : 0.0));
-      const double row3 = kq == 0 ? x30 : (kq == 1 ? x31 : (kq == 2 ? x32 : r3));
-      ax[q] = r16 == 0 ? row0 : (r16 == 1 ? row1 : (r16 == 2 ? row2 : (r16 == 3 ? row3 : 0.0)));
-    }
+    // X44 as an MFMA A operand: lane (i = r16, k = kq) holds X44[r16][kq] for r16 < 4, else 0 -- a sum of
+    // ten products with the lane's 0/1 position masks (one of them is 1 at most: exact, and branch-free;
+    // nested selects compiled to divergent branches that cost a third of the step)
+    ax[q] = fma(mx[9], r3, fma(mx[8], x32, fma(mx[7], x31, fma(mx[6], x30, mx[5] * r2)))) +
+            fma(mx[4], x21, fma(mx[3], x20, fma(mx[2], r1, fma(mx[1], x10, mx[0] * r0))));
     // solved panel in operand layout, P[i][k] = sum_k' D[i][j0+k'] X44[k][k'] (i = r16, k = kq), from ONE
     // MFMA: C[m][n] = sum_e X44[m][e] D[n][j0+e]; acc[q] already is the B operand (D is symmetric),
     // and C's register 0 (m = kq, n = r16) is P in the operand layout the rank-4 update needs.
     const d4 pt = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[q], acc[q], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-    double pn = pt[0];
-    const int a = r16 - j0;  // row inside the 4 x 4 piece, if 0 <= a < 4
-    if (a < 0) pn = 0.0;     // finished rows take no part in the update
-    if (a >= 0 && a < 4) {   // the piece's own rows: exactly L44 (no rounding noise above the diagonal)
-      const double row0v = kq == 0 ? l00 : 0.0;
-      const double row1v = kq == 0 ? l10 : (kq == 1 ? l11 : 0.0);
-      const double row2v = kq == 0 ? l20 : (kq == 1 ? l21 : (kq == 2 ? l22 : 0.0));
-      const double row3v = kq == 0 ? l30 : (kq == 1 ? l31 : (kq == 2 ? l32 : l33));
-      pn = a == 0 ? row0v : (a == 1 ? row1v : (a == 2 ? row2v : row3v));
-    }
+    // finished rows take no part in the update and the piece's own rows are L44, whose entries above
+    // the diagonal are exact zeros (keep[q] = 0 there, 1 elsewhere); L44 itself is the MFMA's
+    // T X44^T = L44 to rounding
+    const double pn = pt[0] * keep[q];
     Lcol[q] = pn;
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pn, pn, acc, 0, 0, 0);
+    {
+      // X[4q + kq][r16] = sum_k' X44_q[kq][k'] E[4q + k'][r16]: e[q] is the B operand as it stands
+      const d4 xt = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[q], e[q], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+      const double xq = xt[0];
+      Xrow[q] = xq;
+      if (q < 3) e = __builtin_amdgcn_mfma_f64_16x16x4f64(-pn, xq, e, 0, 0, 0);
+    }
     D16_STAMP(2 + q);
   }
-  if (badcol >= 0 && lane == 0 && c0 + badcol < nv) atomicCAS(info, 0, (int)(row0 + c0 + badcol + 1));
-
-  // X = L^-1 (16 x 16): forward substitution on the identity, 4 rows at a time
-  d4 e;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) e[r] = (kq + 4 * r == r16) ? 1.0 : 0.0;
-  double Xrow[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    // X[4q + kq][r16] = sum_k' X44_q[kq][k'] E[4q + k'][r16]: e[q] is the B operand as it stands
-    const d4 xt = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[q], e[q], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-    const double xq = xt[0];
-    Xrow[q] = xq;
-    if (q < 3) e = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lcol[q], xq, e, 0, 0, 0);
-    D16_STAMP(6 + q);
+  if (badbits) {
+    const int badcol = __builtin_ctz(badbits);
+    if (lane == 0 && c0 + badcol < nv) atomicCAS(info, 0, (int)(row0 + c0 + badcol + 1));
   }
+  D16_STAMP(6); D16_STAMP(7); D16_STAMP(8); D16_STAMP(9);
   // results: L_ss (lower) into the block, dense X_ss into dinv_s, 1/diag
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int col = 4 * q + kq;          // Lcol[q]: L[r16][col];  Xrow[q]: X[col][r16]
     if (r16 >= col) Sd[col * pitch + r16] = Lcol[q];
     dinv_s[r16 * SB + col] = Xrow[q];    // column-major X: X[a = col][j = r16] at j*16 + a
-    if (gdinv) gdinv[r16 * SB + col] = Xrow[q];
-    if (r16 == 0) rdiag[c0 + col] = kq == 0 ? rinv[q][0] : (kq == 1 ? rinv[q][1] : (kq == 2 ? rinv[q][2] : rinv[q][3]));
+    // 1 / L_cc is the diagonal of X: exactly the pivot's reciprocal (the substitution multiplies it
+    // by the identity's 1 and adds exact zeros)
+    if (r16 == col) rdiag[c0 + col] = Xrow[q];
+  }
+  if (gdinv) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gdinv[r16 * SB + 4 * q + kq] = Xrow[q];
   }
   D16_STAMP(10);
 }

@@ -21,7 +21,7 @@ for spec in sys.argv[1:]:
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     print("  m=%d n=%d k=%d: %.3f ms  %.1f TF/s  tiles128=%d" % (m, n, k, best*1e3, 2.0*m*n*k/best/1e12, (m//128)*(n//128)))
 '''
-for v in ("0", "1", "2", "3"):
+for v in os.environ.get("SWEEP_VARIANTS", "0,1,2,3").split(","):
     out = subprocess.run([sys.executable, "-c", CODE] + sys.argv[1:], env=dict(os.environ, GMB_GEMM_VARIANT=v), capture_output=True, text=True)
     print("variant", v)
     print(out.stdout.rstrip() if out.returncode == 0 else out.stderr[-600:])
