@@ -1,0 +1,57 @@
+"""Host-side pieces of bench.py that need no GPU: the flop count of a step, the synthetic tables
+(SURVEY.md section 8d recipe, shared with the oracle) and the deadline guard around the side
+measurement (a stuck collective must not take the headline JSON line with it)."""
+import importlib.util
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location("bench_module", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["bench_module"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_deadline_guard_returns_result_error_or_timeout():
+    bench = load_bench()
+    val, ok = bench.run_with_deadline(lambda: {"x": 1}, 5.0)
+    assert ok and val == {"x": 1}
+
+    def boom():
+        raise RuntimeError("peer died")
+
+    val, ok = bench.run_with_deadline(boom, 5.0)
+    assert ok and "RuntimeError: peer died" in val["error"]
+    t0 = time.perf_counter()
+    val, ok = bench.run_with_deadline(lambda: time.sleep(3.0), 0.2)
+    assert not ok and "no result after" in val["error"] and time.perf_counter() - t0 < 2.0
+
+
+def test_synthetic_tables_follow_the_survey_recipe():
+    bench = load_bench()
+    from oracle import gp_oracle as O
+
+    X, y, ls = bench.synthetic_table(500, 4)
+    Xo, yo, lso = O.synthetic_table(500, 4)
+    assert np.array_equal(X, Xo) and np.array_equal(y, yo) and np.array_equal(ls, lso)
+    assert abs(y.mean()) < 1e-12 and abs(y.std(ddof=1) - 1.0) < 1e-12
+    assert np.allclose(ls, np.geomspace(0.7, 2.0, 4))
+    G = bench.synthetic_grid(4, 100)
+    assert G.shape == (10_000, 4) and np.all(G[:, 2:] == 0.0) and G[:, 0].min() == -2.4 and G[:, 1].max() == 2.4
+    assert np.array_equal(G, O.synthetic_grid(4, 100))
+
+
+def test_step_flops_counts_cholesky_inverse_and_prediction():
+    bench = load_bench()
+    N, M, n_eval = 10_000, 10_000, 70
+    per_eval = N**3 / 3 + 2 * N**3 / 3                  # Cholesky + (L^-1 and Sigma^-1), SURVEY 8d
+    final = N**3 / 3 + float(N) ** 2 * M                # re-factorisation + N^2 M solve of the grid prediction
+    got = bench.step_flops(N, M, n_eval)
+    assert abs(got - (n_eval * per_eval + final)) / got < 0.02
