@@ -251,11 +251,14 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int col = 4 * q + kq;          // Lcol[q]: L[r16][col];  Xrow[q]: X[col][r16]
-    if (r16 >= col) Sd[col * pitch + r16] = Lcol[q];
+    // unconditional: Lcol is exactly zero above the diagonal (keep[]), and nothing reads the upper
+    // triangle of a diagonal sub-block in LDS anyway
+    Sd[col * pitch + r16] = Lcol[q];
     dinv_s[r16 * SB + col] = Xrow[q];    // column-major X: X[a = col][j = r16] at j*16 + a
     // 1 / L_cc is the diagonal of X: exactly the pivot's reciprocal (the substitution multiplies it
-    // by the identity's 1 and adds exact zeros)
-    if (r16 == col) rdiag[c0 + col] = Xrow[q];
+    // by the identity's 1 and adds exact zeros).  The lanes off the diagonal write to a spare slot
+    // instead of being branched around.
+    rdiag[r16 == col ? c0 + col : LB] = Xrow[q];
   }
   if (gdinv) {
 #pragma unroll
@@ -286,7 +289,7 @@ __device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
   constexpr int NTH = 64 * NW;
   __shared__ double S[PK_SIZE];        //  75,776 B
   __shared__ double dinv[SB * SB];     //   2,048 B  dense X_ss of the current sub-panel, column-major
-  __shared__ double rdiag[LB];         //   1,024 B  1 / L_cc  (= X_cc)
+  __shared__ double rdiag[LB + 1];     //   1,032 B  1 / L_cc  (= X_cc); [LB] is a write-only spare slot
   __shared__ double red[NW];
 
   const int tid = threadIdx.x;

@@ -70,12 +70,12 @@ def test_mfma_gemm_block_op_layouts(gpu):
     torch.cuda.synchronize()
     eng.blk_gemm_nt(tC.data_ptr(), n, tA.data_ptr(), m, tB.data_ptr(), n, m, n, k, -1.0, 1.0)
     torch.cuda.synchronize()
-    torch.cuda.synchronize()
     got = tC.cpu().numpy().T  # back to (n, m)
     want = C0 - B @ A.T
     assert rel(got, want) < 1e-13
     # beta = 0 overwrite + tri skipping (tiles with tn < tm untouched)
     tC2 = torch.full((m, n), 7.0, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the product on the engine's own
     eng.blk_gemm_nt(tC2.data_ptr(), n, tA.data_ptr(), m, tB.data_ptr(), n, m, n, k, 2.0, 0.0, 1, 0)
     torch.cuda.synchronize()
     got2 = tC2.cpu().numpy().T
