@@ -384,7 +384,16 @@ __device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
         factor_diag16_mfma(Sn, pn, dinv, gd ? gd + (s + 1) * SB * SB : nullptr, rdiag, c0 + SB, nv, g.info, g.row0);
       } else {
         const int ntile = n * (n + 1) / 2;
-        for (int t = wave; t < ntile; t += NW - 1) {  // t = 0 is the diagonal tile wave 0 owns
+        // Tiles 1 .. ntile-1 (t = 0 is the diagonal tile wave 0 owns) are dealt in rounds of 2 (NW - 2) + 1
+        // slots: two per wave, but only ONE for wave NW / 2 -- it shares its SIMD with wave 0, whose
+        // dependent chain takes half of that SIMD's issue slots, so it works at about half speed (with an
+        // equal share it reached the barrier ~1 us after everybody else in the first two steps).
+        constexpr int SLOTS = 2 * (NW - 2) + 1;
+        const int mate = NW / 2;
+        const int rank = wave < mate ? wave - 1 : wave - 2;  // 0 .. NW-3 among the full-speed waves
+        for (int i = 0;; ++i) {
+          const int t = (wave == mate) ? 1 + i * SLOTS + (SLOTS - 1) : 1 + (i >> 1) * SLOTS + rank + (i & 1) * (NW - 2);
+          if (t >= ntile) break;
           int tc = 0, rem = t;
           while (rem >= n - tc) {
             rem -= n - tc;
