@@ -304,32 +304,53 @@ __device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
   __builtin_amdgcn_s_setprio(3);
   LEAF_STAMP(0);
 
-  // ---- load: lower block triangle of real columns, identity elsewhere, zeros above the diagonal
-  {
-    // all 16-byte loads of a thread are issued before the first use (one latency, not 32)
-    constexpr int NL = 8192 / NTH;
+  // ---- load: lower block triangle of real columns, identity elsewhere, zeros above the diagonal.
+  //      Wave 0 fetches only the first 16 x 16 diagonal sub-block and factors it at once; the other
+  //      waves bring in the rest meanwhile (the first factorisation, 2.3 us, used to start after the
+  //      whole 64 KB burst had landed).
+  auto put_pair = [&](int r, int c, d2 v) {
+    if (c >= nv) v = d2{0.0, 0.0};
+    if (r < c) v[0] = 0.0;
+    if (r + 1 < c) v[1] = 0.0;
+    if (c >= nv && r == c) v[0] = 1.0;
+    if (c >= nv && r + 1 == c) v[1] = 1.0;
+    const int a = pk(r, c);
+    S[a] = v[0];
+    S[a + 1] = v[1];
+  };
+  if (wave == 0) {
+    d2 buf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = lane + 64 * i;  // 16 columns x 8 row pairs
+      const int c = p >> 3, r = (p & 7) * 2;
+      buf[i] = *reinterpret_cast<const d2*>(g.A + r + (int64_t)c * g.lda);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = lane + 64 * i;
+      put_pair((p & 7) * 2, p >> 3, buf[i]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    factor_diag16_mfma(&S[0], pk_pitch(0), dinv, gd, rdiag, 0, nv, g.info, g.row0, g.dbg ? g.dbg + 40 : nullptr);
+  } else {
+    // all 16-byte loads of a thread are issued before the first use (one latency, not 19)
+    constexpr int NO = NTH - 64;
+    constexpr int NL = (8192 + NO - 1) / NO;
     d2 buf[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int p = tid + NTH * i;            // pair index: column p / 64, rows 2 (p % 64), +1
+      const int p = tid - 64 + NO * i;        // pair index: column p / 64, rows 2 (p % 64), +1
       const int c = p >> 6, r = (p & 63) * 2;
-      if (r >= (c & ~15)) buf[i] = *reinterpret_cast<const d2*>(g.A + r + (int64_t)c * g.lda);
+      if (p < 8192 && r >= (c & ~15) && !(c < SB && r < SB))
+        buf[i] = *reinterpret_cast<const d2*>(g.A + r + (int64_t)c * g.lda);
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int p = tid + NTH * i;
+      const int p = tid - 64 + NO * i;
       const int c = p >> 6, r = (p & 63) * 2;
-      if (r >= (c & ~15)) {
-        d2 v = buf[i];
-        if (c >= nv) v = d2{0.0, 0.0};
-        if (r < c) v[0] = 0.0;
-        if (r + 1 < c) v[1] = 0.0;
-        if (c >= nv && r == c) v[0] = 1.0;
-        if (c >= nv && r + 1 == c) v[1] = 1.0;
-        const int a = pk(r, c);
-        S[a] = v[0];
-        S[a + 1] = v[1];
-      }
+      if (p < 8192 && r >= (c & ~15) && !(c < SB && r < SB)) put_pair(r, c, buf[i]);
     }
   }
   __syncthreads();
@@ -347,8 +368,7 @@ __device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
   };
 
   // ---- factorisation: right-looking over 16-column sub-panels with one-step look-ahead -------
-  if (wave == 0) factor_diag16_mfma(&S[0], pk_pitch(0), dinv, gd, rdiag, 0, nv, g.info, g.row0, g.dbg ? g.dbg + 40 : nullptr);
-  __syncthreads();
+  //      (sub-block 0 was factored by wave 0 during the load)
   for (int s = 0; s < LB / SB - 1; ++s) {
     const int c0 = s * SB;
     double* Sd = &S[pk_off(s)];      // block column s, first row c0
