@@ -420,11 +420,22 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
     variant = 7;
   }
   const dim3 grid(nlaunch);
+  const bool pfc = g.beta != 0.0 && g.k <= 1024 && !in_place;
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, g); break;
-    case 1: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2>), grid, dim3(256), 0, e->cur, g); break;
-    case 2: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 2, 2>), grid, dim3(256), 0, e->cur, g); break;
-    case 3: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2>), grid, dim3(256), 0, e->cur, g); break;
+    // small tiles with a short contraction and beta != 0: the C-prefetching instantiations (gemm_f64.hpp)
+    case 1:
+      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2, false, true>), grid, dim3(256), 0, e->cur, g);
+      else hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2>), grid, dim3(256), 0, e->cur, g);
+      break;
+    case 2:
+      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 2, 2, false, true>), grid, dim3(256), 0, e->cur, g);
+      else hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 2, 2>), grid, dim3(256), 0, e->cur, g);
+      break;
+    case 3:
+      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2, false, true>), grid, dim3(256), 0, e->cur, g);
+      else hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2>), grid, dim3(256), 0, e->cur, g);
+      break;
     case 4: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 2, 4>), grid, dim3(512), 0, e->cur, g); break;
     case 6: hipLaunchKernelGGL((gemm_f64_kernel<4, 2, 4, 4, 2, true>), grid, dim3(512), 0, e->cur, g); break;
     case 7: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2, true>), grid, dim3(256), 0, e->cur, g); break;
