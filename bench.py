@@ -137,10 +137,11 @@ def cpu_baseline(cfg, target_seconds=20.0):
 
     # grow the sample (cost ~ N^3, but BLAS efficiency also grows with N, so re-scale from each
     # measurement) until one evaluation takes >= 10 s or the full N is reached
+    target_seconds = float(os.environ.get("GUMBI_BENCH_CPU_SECONDS", target_seconds))  # tests shorten it
     Ns = min(cfg["N"], 1500)
     dt = run(Ns)
     for _ in range(3):
-        if dt >= 10.0 or Ns >= cfg["N"]:
+        if dt >= 0.5 * target_seconds or Ns >= cfg["N"]:
             break
         nxt = int(Ns * (target_seconds / max(dt, 1e-3)) ** (1.0 / 3.0))
         nxt = min(cfg["N"], max(Ns + 128, nxt // 128 * 128))
@@ -165,7 +166,7 @@ def cpu_baseline(cfg, target_seconds=20.0):
     }
 
 
-DIST_N, DIST_D = 40_960, 8
+DIST_N, DIST_D = int(os.environ.get("GUMBI_BENCH_DIST_N", "40960")), 8  # the env override is for the tests
 
 
 def distributed_section(world, local_rank, dist):

@@ -262,3 +262,62 @@ def test_driver_on_the_rccl_backend_with_one_rank(gpu):
     assert p.exitcode == 0
     assert backend == "nccl"
     assert e_val < 1e-10 and e_g < 1e-8 and e_mu < 1e-8 and e_var < 1e-9
+
+
+def test_bench_contract_with_two_ranks_on_one_gpu(gpu):
+    """bench.py as the driver launches it for N > 1 (``python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N ...``), with both ranks on the test box's one GPU over gloo: rank 0 prints exactly ONE
+    JSON line with the contract's keys, n_gpus = 2, the replica workload and the distributed section."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GUMBI_BENCH_SINGLE_DEVICE="1", GUMBI_BENCH_BACKEND="gloo", GUMBI_BENCH_DIST_N="2304",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--map-evals", "4"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["value"] > 0 and d["results_finite"] and "cpu_baseline" not in d
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    dist = d["distributed"]
+    assert "error" not in dist, dist
+    assert dist["results_finite"] and dist["grad_finite"] and "2 GPU(s)" in dist["workload"]
+
+
+def test_bench_contract_single_process(gpu):
+    """``python bench.py`` (N = 1): one JSON line with the contract's keys plus ``roofline``, ``cpu_baseline``
+    (here on a shortened sample) and the per-phase timings."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GUMBI_BENCH_DIST_N="2304", GUMBI_BENCH_CPU_SECONDS="2")
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "1", "--warmup", "0", "--map-evals", "4"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["unit"] == "GFLOP/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("synthetic N=10k d=4") and len(d["config"]["map_evals_per_step"]) == 1
+    assert 1 <= d["config"]["map_evals_per_step"][0] <= 8  # scipy checks maxfun between line searches
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 20.0 < r["achieved"] < r["peak"] and r["launches"] > 100
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "N=" in c["sample"]
+    assert d["phases"]["factorize_ms"] > 0 and d["phases"]["predict_ms"] > 0
+    assert d["distributed"]["results_finite"] and "1 GPU(s)" in d["distributed"]["workload"]
