@@ -378,3 +378,16 @@ def test_propose_picks_a_point_of_the_prediction_grid(gpu):
     assert abs(mu.ravel()[gp.proposal_idx] - target) <= 0.5 * (mu.max() - mu.min())
     with pytest.raises(ValueError):
         example_gp().propose(1.0)
+
+
+def test_driver_smoke_entry(gpu):
+    """``__graft_entry__.smoke()`` is what the driver runs on the GPU box before the bench: one small
+    fit + predict + gradient on cuda:0 checked against the oracle (it asserts inside)."""
+    import importlib
+    import sys
+
+    root = str(Path(__file__).resolve().parent.parent)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.smoke()
