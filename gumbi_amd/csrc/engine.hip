@@ -484,10 +484,16 @@ int launch_leaf(gmb_engine* e, const LeafArgs& a) {
     return GMB_OK;
   }
   ev_begin(e, 1, 0.0);
-  if (e->naive_leaf)
+  static const char* px = getenv("GMB_PROBE_XCD");  // software XCD partition probe: leaf on one XCD only
+  if (e->naive_leaf) {
     hipLaunchKernelGGL(potrf_leaf_naive_kernel, dim3(1), dim3(256), 0, e->cur, a);
-  else
+  } else if (px) {
+    LeafArgs b = a;
+    b.xcd_only = atoi(px) + 1;
+    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(8), dim3(512), 0, e->cur, b);
+  } else {
     hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(512), 0, e->cur, a);
+  }
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -713,7 +719,7 @@ PointSet train_set(const gmb_engine* e) { return PointSet{e->xs, e->xl, e->cat, 
 // `rend`: block row where the panel solve / updates stop (the whole matrix, or the end of a
 // diagonal square when the rows below are solved later in bulk)
 int chol_leaf(gmb_engine* e, int c, int rend) {
-  LeafArgs a;
+  LeafArgs a{};
   a.A = e->dA + (int64_t)c * TILE + (int64_t)c * TILE * e->ld;
   a.lda = e->ld;
   a.nvalid = (int)std::min<int64_t>(TILE, e->N - (int64_t)c * TILE);
@@ -2230,10 +2236,13 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
   const char* ez = getenv("GMB_PEAK_SCALE");
   const int per_cu = (eb && atoi(eb) > 0) ? atoi(eb) : 2;
   const double scale = ez ? atof(ez) : 1.0;
-  const int blocks = 256 * per_cu, iters = 2000;
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100, scale);  // warm-up
+  const char* ei = getenv("GMB_PEAK_ITERS");
+  const char* es = getenv("GMB_PEAK_SKIP_XCD");  // partition probe: leave one XCD to other kernels
+  const int skip_xcd = es ? atoi(es) : -1;
+  const int blocks = 256 * per_cu, iters = (ei && atoi(ei) > 0) ? atoi(ei) : 2000;
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100, scale, skip_xcd);  // warm-up
   (void)hipEventRecord(a, 0);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, scale);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, scale, skip_xcd);
   (void)hipEventRecord(b, 0);
   int rc = GMB_OK;
   if (hipEventSynchronize(b) != hipSuccess || hipGetLastError() != hipSuccess) rc = GMB_EHIP;
@@ -2257,7 +2266,7 @@ int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, doubl
                   double* logdet_accum, int32_t* info) {
   if (!e || !Akk || nvalid < 1 || nvalid > TILE || lda < TILE) return fail(e, GMB_EINVAL, "bad potrf block");
   HIP_TRY(e, hipSetDevice(e->device));
-  LeafArgs a;
+  LeafArgs a{};
   a.A = Akk;
   a.lda = lda;
   a.nvalid = nvalid;

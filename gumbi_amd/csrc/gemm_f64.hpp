@@ -326,7 +326,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_batched_kernel(c
 // MFMA-only microbenchmark: the GEMM's own register pattern (4 x 4 independent accumulators fed
 // by 4 + 4 operand registers) with no memory traffic -- the f64 matrix rate a kernel of this shape
 // can sustain, i.e. the practical ceiling the roofline is compared with.
-__global__ __launch_bounds__(256, 2) void mfma_f64_peak_kernel(double* sink, int iters, double scale) {
+// `skip_xcd` >= 0: workgroups that land on that XCD leave at once (the software XCD partition probe,
+// tools/gpu_xcd_partition_probe.py: MFMA-saturating background load on seven XCDs).
+__global__ __launch_bounds__(256, 2) void mfma_f64_peak_kernel(double* sink, int iters, double scale, int skip_xcd = -1) {
+  if (skip_xcd >= 0) {
+    unsigned int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if ((int)(x & 7u) == skip_xcd) return;
+  }
   d4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
