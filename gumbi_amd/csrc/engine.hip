@@ -187,6 +187,8 @@ struct gmb_engine {
   size_t sync_next = 0;
   bool lookahead = true;
   bool par_inverse = true;
+  bool aux_shared = false;  // aux[2] is the process-wide masked stream (not ours to destroy)
+  bool chain_shared = false;  // aux[1] is the process-wide stream masked to ONE XCD (the chain's)
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
 };
@@ -971,7 +973,18 @@ int chol_lookahead_masked(gmb_engine* e) {
     rc = (n1 < nct) ? update(n1, nct, true) : 0;          // U2, on the compute units its mask allows
     e->cur = mainS;
     if (rc) return rc;
-    if ((rc = chol_cols(e, n0, n1, nrt))) return rc;      // panel p+1, beside U2
+    if (e->chain_shared && n1 < nct) {
+      // panel p+1 on the stream that owns the XCD the bulk stream leaves free
+      hipStream_t chainS = e->aux[1];
+      if ((rc = order_after(e, mainS, chainS))) return rc;
+      e->cur = chainS;
+      rc = chol_cols(e, n0, n1, nrt);
+      e->cur = mainS;
+      if (rc) return rc;
+      if ((rc = order_after(e, chainS, mainS))) return rc;
+    } else if ((rc = chol_cols(e, n0, n1, nrt))) {        // panel p+1, beside U2
+      return rc;
+    }
   }
   e->cur = mainS;
   return order_after(e, bulkS, mainS);
@@ -1132,7 +1145,7 @@ int winv_level_batched(gmb_engine* e, const gmb_engine::InvLevelPlan& lp);
 int winv_levels(gmb_engine* e, int nt) {
   std::vector<std::vector<InvNode>> levels;
   collect_inv_nodes(0, nt, 0, levels);
-  hipStream_t streams[4] = {e->stream, e->aux[0], e->aux[1], e->aux[2]};
+  hipStream_t streams[4] = {e->stream, e->aux[0], e->chain_shared ? e->stream : e->aux[1], e->aux_shared ? e->aux[0] : e->aux[2]};
   int rc;
   for (int a = 1; a < 4; ++a)
     if ((rc = order_after(e, streams[0], streams[a]))) return rc;
@@ -1644,7 +1657,35 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   for (int a = 0; a < 3; ++a) {
     hipError_t st2;
     hipDeviceProp_t prop;
-    if (a == 2 && mask_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    static hipStream_t shared_masked_dev[64] = {};  // GMB_MASK_XCD: ONE masked stream per process and device, never destroyed
+    hipStream_t& shared_masked = shared_masked_dev[device & 63];
+    const char* mx = getenv("GMB_MASK_XCD");     // experiment: the bulk stream leaves this whole XCD free
+    if (a == 2 && mx && hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      if (!shared_masked) {
+        const int ncu = prop.multiProcessorCount, xcd = atoi(mx);
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 0; i < ncu; ++i)
+          if ((i & 7) != xcd) mask[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&shared_masked, (uint32_t)mask.size(), mask.data()) != hipSuccess) shared_masked = nullptr;
+      }
+      e->aux[a] = shared_masked;
+      e->aux_shared = true;
+      st2 = shared_masked ? hipSuccess : hipErrorUnknown;
+    } else if (a == 1 && mx && getenv("GMB_MASK_CHAIN") && hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      // ... and the chain stream the complement: only that XCD
+      static hipStream_t shared_chain_dev[64] = {};
+      hipStream_t& shared_chain = shared_chain_dev[device & 63];
+      if (!shared_chain) {
+        const int ncu = prop.multiProcessorCount, xcd = atoi(mx);
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 0; i < ncu; ++i)
+          if ((i & 7) == xcd) mask[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&shared_chain, (uint32_t)mask.size(), mask.data()) != hipSuccess) shared_chain = nullptr;
+      }
+      e->aux[a] = shared_chain;
+      e->chain_shared = true;
+      st2 = shared_chain ? hipSuccess : hipErrorUnknown;
+    } else if (a == 2 && mask_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess) {
       // mask bit i addresses XCD i % 8 (then shader engine, then CU): clearing the first mask_cus
       // bits takes mask_cus / 8 compute units from every XCD
       const int ncu = prop.multiProcessorCount;
@@ -1716,8 +1757,8 @@ void gmb_destroy(gmb_engine* e) {
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  for (auto s2 : e->aux)
-    if (s2) (void)hipStreamDestroy(s2);
+  for (int a = 0; a < 3; ++a)
+    if (e->aux[a] && !(a == 2 && e->aux_shared) && !(a == 1 && e->chain_shared)) (void)hipStreamDestroy(e->aux[a]);
   for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
