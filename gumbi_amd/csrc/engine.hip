@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/gumbi_hip.h"
@@ -44,6 +45,7 @@ struct EventPair {
   int kind;  // 0 chol gemm, 1 leaf, 2 trsm, 3 predict gemm, 4 grad gemm
   double flops;
   int mt, nt, k, flags;
+  bool masked = false;  // launched on the CU-masked bulk stream
 };
 
 }  // namespace
@@ -178,7 +180,8 @@ struct gmb_engine {
   // whole-compute-unit workgroups (compute units minus `reserve_cus`); their tile counters come
   // from a ring that is zeroed once per factorisation
   int reserve_cus = 0;  // off by default: no gain measured at N = 10k, a loss at N = 30k
-  int chol_scheme = 0;  // 0 = full-height panel chain on the aux stream, 1 = square chain + bulk row solve
+  int chol_scheme = -1;  // -1 = by size (masked bulk stream for small matrices, else 0); 0 = full-height panel chain on the aux stream, 1 = square chain + bulk row solve
+  int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
   int persist_wgs = 0;
   int reserve_slots = 0;  // tuning: half-CU slots a persistent 128x128 bulk grid leaves free (GMB_RESERVE_SLOTS)
   int32_t* dsched = nullptr;
@@ -187,7 +190,9 @@ struct gmb_engine {
   size_t sync_next = 0;
   bool lookahead = true;
   bool par_inverse = true;
+  std::vector<hipEvent_t> col_event;  // partitioned schedule: per block column, see wait_for_columns
   bool aux_shared = false;  // aux[2] is the process-wide masked stream (not ours to destroy)
+  int part_cus = 0;         // compute units the masked stream leaves free
   bool chain_shared = false;  // aux[1] is the process-wide stream masked to ONE XCD (the chain's)
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
@@ -271,6 +276,7 @@ void ev_begin(gmb_engine* e, int kind, double flops, int mt = 0, int nt = 0, int
   (void)hipEventCreate(&p.b);
   p.kind = kind;
   p.flops = flops;
+  p.masked = e->aux_shared && e->cur == e->aux[2];
   (void)hipEventRecord(p.a, e->cur);
   e->evs.push_back(p);
 }
@@ -284,6 +290,32 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
     const char* path = getenv("GMB_TRACE_FILE");  // per-launch log for tuning: kind mt nt k flags ms GF
     if (path && path[0]) trace = fopen(path, "a");
   }
+  // Wall time during which at least one GEMM launch of this call was in flight (union of the launch
+  // intervals on the device timeline): launches of the two streams of the look-ahead schedules
+  // overlap, so the SUM of their durations exceeds the time they cover.
+  if (!e->evs.empty()) {
+    std::vector<std::pair<float, float>> iv;
+    for (auto& p : e->evs)
+      if (p.kind == 0 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
+        float ta = 0.f, tb = 0.f;
+        if (hipEventElapsedTime(&ta, e->evs[0].a, p.a) == hipSuccess && hipEventElapsedTime(&tb, e->evs[0].a, p.b) == hipSuccess)
+          iv.emplace_back(ta, tb);
+      }
+    std::sort(iv.begin(), iv.end());
+    float cur_lo = 0.f, cur_hi = -1.f;
+    double uni = 0.0;
+    for (auto& x : iv) {
+      if (cur_hi < cur_lo || x.first > cur_hi) {
+        if (cur_hi >= cur_lo) uni += cur_hi - cur_lo;
+        cur_lo = x.first;
+        cur_hi = x.second;
+      } else if (x.second > cur_hi) {
+        cur_hi = x.second;
+      }
+    }
+    if (cur_hi >= cur_lo) uni += cur_hi - cur_lo;
+    e->tm.total_gemm_wall_ms += uni;
+  }
   for (auto& p : e->evs) {
     float t = 0.f;
     (void)hipEventElapsedTime(&t, p.a, p.b);
@@ -292,6 +324,10 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
       e->tm.total_gemm_ms += t;
       e->tm.total_gemm_flops += p.flops;
       e->tm.total_gemm_launches += 1;
+      if (p.masked) {
+        e->tm.masked_gemm_ms += t;
+        e->tm.masked_gemm_flops += p.flops;
+      }
     }
     switch (p.kind) {
       case 0:
@@ -758,11 +794,23 @@ int chol_leaf(gmb_engine* e, int c, int rend) {
                            (int64_t)(rend - c - 1) * TILE, a.A, e->ld, a.dinv16, a.nvalid, 5);
 }
 
+// Partitioned schedule (chol_partitioned): column c of the panel being factored may only be touched once
+// the previous panel's update of it has been issued on the bulk stream -- col_event[c] marks that point.
+int wait_for_columns(gmb_engine* e, int c_last) {
+  if (e->col_event.empty() || c_last >= (int)e->col_event.size() || !e->col_event[c_last]) return GMB_OK;
+  HIP_TRY(e, hipStreamWaitEvent(e->cur, e->col_event[c_last], 0));
+  return GMB_OK;
+}
+
 int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
-  if (c1 - c0 == 1) return chol_leaf(e, c0, rend);
+  if (c1 - c0 == 1) {
+    int rcw = wait_for_columns(e, c0);
+    return rcw ? rcw : chol_leaf(e, c0, rend);
+  }
   const int mid = c0 + (c1 - c0 + 1) / 2;
   int rc = chol_cols(e, c0, mid, rend);
   if (rc) return rc;
+  if ((rc = wait_for_columns(e, c1 - 1))) return rc;
   GemmArgs g{};
   g.C = e->dA + (int64_t)mid * TILE + (int64_t)mid * TILE * e->ld;
   g.ldc = e->ld;
@@ -990,6 +1038,82 @@ int chol_lookahead_masked(gmb_engine* e) {
   return order_after(e, bulkS, mainS);
 }
 
+
+// Partitioned schedule (GMB_CHOL_SCHEME=4 with GMB_MASK_XCD / GMB_MASK_CHAIN): the chain of panel p+1
+// runs on the stream that owns one XCD, every update of the trailing matrix on the stream that owns
+// the other seven, and the update of the NEXT panel's columns (U1) is issued in the pieces the panel
+// recursion consumes them in (1, 1, 2, 4 ... block columns), each followed by an event the chain
+// waits for just before it first touches those columns: only the first piece is on the critical path.
+//
+//   chain :  panel 0 (whole chip) | wait piece events ... panel 1 ...          | panel 2 ...
+//   bulk  :                       | U1(0) pieces | U2(0)   | wait panel 1 | U1(1) pieces | U2(1) ...
+int chol_partitioned(gmb_engine* e) {
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  const int w = e->panel_blocks;
+  hipStream_t mainS = e->stream, bulkS = e->aux[2], chainS = e->aux[1];
+  e->sync_next = 0;
+  e->sched_next = 0;
+  HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
+  int rc;
+  e->col_event.assign(nct, nullptr);
+  e->cur = mainS;
+  rc = chol_cols(e, 0, std::min(w, nct), nrt);  // panel 0 on the whole chip (no events yet)
+  if (rc) { e->col_event.clear(); return rc; }
+  if ((rc = order_after(e, mainS, bulkS))) { e->col_event.clear(); return rc; }
+  if ((rc = order_after(e, mainS, chainS))) { e->col_event.clear(); return rc; }
+  for (int c0 = 0; c0 < nct; c0 += w) {
+    const int c1 = std::min(c0 + w, nct);
+    const int n0 = c1, n1 = std::min(c1 + w, nct);
+    if (n0 >= nct) break;
+    auto update = [&](int col_lo, int col_hi) {
+      GemmArgs g{};
+      g.C = e->dA + (int64_t)col_lo * TILE + (int64_t)col_lo * TILE * e->ld;
+      g.ldc = e->ld;
+      g.A = e->dA + (int64_t)col_lo * TILE + (int64_t)c0 * TILE * e->ld;
+      g.lda = e->ld;
+      g.B = g.A;
+      g.ldb = e->ld;
+      g.mt = col_hi - col_lo;
+      g.nt = nrt - col_lo;
+      g.k = (c1 - c0) * TILE;
+      g.alpha = -1.0;
+      g.beta = 1.0;
+      g.tri = 1;
+      return launch_gemm(e, g, 0);
+    };
+    // bulk side: U1(p) in the pieces of the recursion over [n0, n1), then U2(p)
+    e->cur = bulkS;
+    int covered = n0;
+    std::function<int(int, int)> pieces = [&](int a, int b) -> int {
+      auto emit = [&](int lo, int hi) -> int {
+        int r = update(lo, hi);
+        if (r) return r;
+        hipEvent_t ev = next_sync_event(e);
+        if (hipEventRecord(ev, bulkS) != hipSuccess) return fail(e, GMB_EHIP, "event record");
+        for (int c = lo; c < hi; ++c) e->col_event[c] = ev;
+        covered = hi;
+        return GMB_OK;
+      };
+      if (b - a == 1) return a >= covered ? emit(a, b) : GMB_OK;
+      const int mid = a + (b - a + 1) / 2;
+      int r = pieces(a, mid);
+      if (r) return r;
+      if (b > covered && (r = emit(std::max(mid, covered), b))) return r;
+      return pieces(mid, b);
+    };
+    if ((rc = pieces(n0, n1))) break;
+    if (n1 < nct && (rc = update(n1, nct))) break;  // U2(p)
+    // chain side: panel p+1 (its kernels wait for the piece events), then the bulk side may go on
+    e->cur = chainS;
+    if ((rc = chol_cols(e, n0, n1, nrt))) break;
+    if ((rc = order_after(e, chainS, bulkS))) break;
+  }
+  e->cur = mainS;
+  e->col_event.clear();
+  if (rc) return rc;
+  if ((rc = order_after(e, chainS, mainS))) return rc;
+  return order_after(e, bulkS, mainS);
+}
 
 // ---- Cholesky with panel look-ahead -------------------------------------------------------------
 // Right-looking over panels of `panel_blocks` block columns [c0, c1).  Only the panel's diagonal
@@ -1659,18 +1783,35 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
     hipDeviceProp_t prop;
     static hipStream_t shared_masked_dev[64] = {};  // GMB_MASK_XCD: ONE masked stream per process and device, never destroyed
     hipStream_t& shared_masked = shared_masked_dev[device & 63];
-    const char* mx = getenv("GMB_MASK_XCD");     // experiment: the bulk stream leaves this whole XCD free
-    if (a == 2 && mx && hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    // aux[2] is the BULK stream of the masked look-ahead schedule (chol_lookahead_masked): a CU-masked
+    // stream that leaves `part` / 8 compute units of every XCD to the latency-bound chain on the main
+    // stream.  The mask applies symmetrically to all XCDs (bit i <-> XCD i % 8, compute unit i / 8 of
+    // it; a mask naming a single XCD is not honoured -- tools/probes/cumask_probe.hip).  ONE such
+    // stream per process and device, created on first use and never destroyed: masked streams that
+    // were created and destroyed with every engine made the timings depend on the queue history of
+    // the process.  GMB_PART_CUS=0 disables it (then aux[2] is an ordinary low-priority stream).
+    const char* mx = getenv("GMB_MASK_XCD");     // experiment: XCD form of the masks (not honoured by the runtime)
+    const char* pc = getenv("GMB_PART_CUS");
+    const int part = pc ? atoi(pc) : 32;
+    if (a == 2 && (mx || part > 0) && hipGetDeviceProperties(&prop, device) == hipSuccess) {
       if (!shared_masked) {
-        const int ncu = prop.multiProcessorCount, xcd = atoi(mx);
+        const int ncu = prop.multiProcessorCount, xcd = mx ? atoi(mx) : 0;
         std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
         for (int i = 0; i < ncu; ++i)
-          if ((i & 7) != xcd) mask[i / 32] |= 1u << (i % 32);
-        if (hipExtStreamCreateWithCUMask(&shared_masked, (uint32_t)mask.size(), mask.data()) != hipSuccess) shared_masked = nullptr;
+          if (part > 0 ? i >= part : (i & 7) != xcd) mask[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&shared_masked, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+          shared_masked = nullptr;
+          (void)hipGetLastError();
+        }
       }
-      e->aux[a] = shared_masked;
-      e->aux_shared = true;
-      st2 = shared_masked ? hipSuccess : hipErrorUnknown;
+      if (shared_masked) {
+        e->aux[a] = shared_masked;
+        e->aux_shared = true;
+        e->part_cus = part > 0 ? part : prop.multiProcessorCount / 8;
+        st2 = hipSuccess;
+      } else {  // no masked stream on this system: ordinary stream, unmasked schedules only
+        st2 = hipStreamCreateWithPriority(&e->aux[a], hipStreamNonBlocking, prio_lo);
+      }
     } else if (a == 1 && mx && getenv("GMB_MASK_CHAIN") && hipGetDeviceProperties(&prop, device) == hipSuccess) {
       // ... and the chain stream the complement: only that XCD
       static hipStream_t shared_chain_dev[64] = {};
@@ -1679,7 +1820,7 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
         const int ncu = prop.multiProcessorCount, xcd = atoi(mx);
         std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
         for (int i = 0; i < ncu; ++i)
-          if ((i & 7) == xcd) mask[i / 32] |= 1u << (i % 32);
+          if (part > 0 ? i < part : (i & 7) == xcd) mask[i / 32] |= 1u << (i % 32);
         if (hipExtStreamCreateWithCUMask(&shared_chain, (uint32_t)mask.size(), mask.data()) != hipSuccess) shared_chain = nullptr;
       }
       e->aux[a] = shared_chain;
@@ -1704,6 +1845,8 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   {
     const char* cs = getenv("GMB_CHOL_SCHEME");
     if (cs) e->chol_scheme = atoi(cs);
+    const char* mb = getenv("GMB_MASKED_MAX_BLOCKS");
+    if (mb) e->masked_max_blocks = atoi(mb);
     const char* rs = getenv("GMB_RESERVE_CUS");  // tuning: 0 = ordinary (chip-filling) bulk launches
     if (rs) e->reserve_cus = atoi(rs);
     const char* rsl = getenv("GMB_RESERVE_SLOTS");
@@ -1858,6 +2001,9 @@ int gmb_set_profiling(gmb_engine* e, int32_t on) {
   e->profiling = on != 0;
   if (on) {
     e->tm.total_gemm_ms = e->tm.total_gemm_flops = 0.0;
+    e->tm.masked_gemm_ms = e->tm.masked_gemm_flops = 0.0;
+    e->tm.total_gemm_wall_ms = 0.0;
+    e->tm.masked_cus = e->aux_shared ? e->wg_slots / 2 - e->part_cus : 0;
     e->tm.total_gemm_launches = 0;
     e->tm.total_kbuild_ms = e->tm.total_kbuild_bytes = 0.0;
     e->tm.total_kbuild_launches = 0;
@@ -1926,7 +2072,14 @@ int gmb_factorize(gmb_engine* e) {
     e->panel_blocks = std::max(8, ((nct / 16 + 4) / 8) * 8);
   }
   if (e->lookahead && e->Np / TILE > e->panel_blocks) {
-    if ((rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : (e->chol_scheme == 2 ? chol_lookahead_masked(e) : (e->chol_scheme == 3 ? chol_panels_serial(e) : chol_lookahead(e)))))) return rc;
+    // default (chol_scheme < 0): small matrices are chain-bound -- the masked bulk stream lets the chain run
+    // beside the trailing updates (N = 10k: 9.8 -> 9.0 ms); large ones lose more to the 12 % of compute
+    // units taken from the updates than the chain is worth (N = 30k: +5 %), they keep the full chip
+    if (e->chol_scheme < 0)
+      rc = (e->aux_shared && e->Np / TILE <= e->masked_max_blocks) ? chol_lookahead_masked(e) : chol_lookahead_full(e);
+    else
+    rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : (e->chol_scheme == 2 ? chol_lookahead_masked(e) : (e->chol_scheme == 3 ? chol_panels_serial(e) : ((e->chol_scheme == 4 && e->aux_shared && e->chain_shared) ? chol_partitioned(e) : chol_lookahead(e)))));
+    if (rc) return rc;
   } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) {
     return rc;
   }

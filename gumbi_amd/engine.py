@@ -72,6 +72,10 @@ class Timings(C.Structure):
         ("total_kbuild_ms", C.c_double),
         ("total_kbuild_bytes", C.c_double),
         ("total_kbuild_launches", C.c_int64),
+        ("masked_gemm_ms", C.c_double),
+        ("masked_gemm_flops", C.c_double),
+        ("masked_cus", C.c_int64),
+        ("total_gemm_wall_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -238,8 +242,8 @@ def _preload_hip_runtime():
 
 
 #: GMB_ABI_VERSION of include/gumbi_hip.h this binding was written against (the layout of
-#: ``gmb_kernel_spec`` changed with version 2: ``additive``)
-ABI_VERSION = 2
+#: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3)
+ABI_VERSION = 3
 
 
 def load_library():

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 2
+#define GMB_ABI_VERSION 3
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -107,6 +107,14 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
   double total_kbuild_ms;
   double total_kbuild_bytes;
   int64_t total_kbuild_launches;
+  /* the part of total_gemm_* that ran on the CU-masked bulk stream (trailing updates of the masked
+     look-ahead schedule: masked_cus of the device's compute units were available to them)        */
+  double masked_gemm_ms;
+  double masked_gemm_flops;
+  int64_t masked_cus;
+  /* wall time with at least one GEMM launch in flight (union of the launch intervals: launches of
+     the look-ahead schedules' two streams overlap, total_gemm_ms is the SUM of their durations)    */
+  double total_gemm_wall_ms;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
 
     # gmb_kernel_spec: 3 + 16 + 1 + 8 + 1 + 4 + 4 + 4 int32 (= 41), 4 bytes of padding, then one double
     assert engine.C.sizeof(engine._Spec) == 41 * 4 + 4 + 8
-    assert engine.C.sizeof(engine.Timings) == 21 * 8
+    assert engine.C.sizeof(engine.Timings) == 25 * 8
     spec = engine.KernelSpec(D=6, idx_cont=[0, 1, 2], idx_lin=[1], coreg=[(3, 4)], out_col=5, n_out=2)
     cs = spec.to_c()
     assert (cs.n_cont, cs.n_lin, cs.n_coreg, cs.out_col, cs.n_out, cs.hetero_noise) == (3, 1, 1, 5, 2, 1)
