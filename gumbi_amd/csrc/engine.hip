@@ -1050,7 +1050,7 @@ int chol_lookahead_masked(gmb_engine* e) {
 int chol_partitioned(gmb_engine* e) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
   const int w = e->panel_blocks;
-  hipStream_t mainS = e->stream, bulkS = e->aux[2], chainS = e->aux[1];
+  hipStream_t mainS = e->stream, bulkS = e->aux[2], chainS = e->chain_shared ? e->aux[1] : e->stream;
   e->sync_next = 0;
   e->sched_next = 0;
   HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
@@ -2078,7 +2078,7 @@ int gmb_factorize(gmb_engine* e) {
     if (e->chol_scheme < 0)
       rc = (e->aux_shared && e->Np / TILE <= e->masked_max_blocks) ? chol_lookahead_masked(e) : chol_lookahead_full(e);
     else
-    rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : (e->chol_scheme == 2 ? chol_lookahead_masked(e) : (e->chol_scheme == 3 ? chol_panels_serial(e) : ((e->chol_scheme == 4 && e->aux_shared && e->chain_shared) ? chol_partitioned(e) : chol_lookahead(e)))));
+    rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : (e->chol_scheme == 2 ? chol_lookahead_masked(e) : (e->chol_scheme == 3 ? chol_panels_serial(e) : ((e->chol_scheme == 4 && e->aux_shared) ? chol_partitioned(e) : chol_lookahead(e)))));
     if (rc) return rc;
   } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) {
     return rc;
