@@ -24,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "../../include/gumbi_hip.h"
@@ -32,7 +33,6 @@
 #include "gradient.hpp"
 #include "potrf_leaf.hpp"
 #include "trsm_strip.hpp"
-#include "panel_chain.hpp"
 
 using namespace gmb;
 
@@ -49,8 +49,6 @@ struct EventPair {
 };
 
 }  // namespace
-
-constexpr int SCHED_RING = 1024;  // persistent launches per factorisation (8 tile counters each)
 
 struct gmb_engine {
   int device = 0;
@@ -140,26 +138,6 @@ struct gmb_engine {
   const double* plan_A = nullptr;
   bool batch_inverse = true;
   bool lpt_order = true;
-  int bulk_variant = -1;  // tuning: tile shape of the bulk trailing updates that run beside the panel chain
-
-  // panel chain as one cooperative kernel (panel_chain.hpp): op lists per panel, built once per data set
-  std::vector<ChainOp>* rec = nullptr;  // recording mode of the launch helpers
-  ChainOp* dchain = nullptr;
-  std::vector<int> chain_off, chain_cnt;  // per panel index
-  ChainSync* dsync = nullptr;
-  unsigned int* dsignal = nullptr;        // stream-memory-op flag (hipMallocSignalMemory)
-  unsigned int chain_seq = 0;
-  int chain_cus = 64;
-  bool chain_kernel = false;
-  int64_t chain_N = -1, chain_ld = -1;
-  const double* chain_A = nullptr;
-  int chain_w = 0;
-  long long* dchain_stamps = nullptr;
-  unsigned int column_seq = 0;   // fused leaf+strip column kernel: flag value of the next launch
-  bool strip_lds = false;     // GMB_STRIP_LDS=1: strip solves stage the diagonal block in LDS (measured 2% slower)
-  bool fused_column = false;  // measured: 55 us per column against 37 + 11 + gap = 53 us as two launches
-  int chain_dbg_panel = -1;
-  std::vector<ChainOp> chain_host;  // host copy of the op lists (debug prints)
 
   // timing
   bool profiling = false;
@@ -176,24 +154,14 @@ struct gmb_engine {
   // level-parallel triangular inverse (independent merges dealt over stream + aux[0..2])
   hipStream_t cur = nullptr;
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-  // bulk updates that run beside the chain are launched as persistent grids of `persist_wgs`
-  // whole-compute-unit workgroups (compute units minus `reserve_cus`); their tile counters come
-  // from a ring that is zeroed once per factorisation
-  int reserve_cus = 0;  // off by default: no gain measured at N = 10k, a loss at N = 30k
-  int chol_scheme = -1;  // -1 = by size (masked bulk stream for small matrices, else 0); 0 = full-height panel chain on the aux stream, 1 = square chain + bulk row solve
+  int chol_scheme = -1;  // -1 = by size (masked bulk stream for small matrices, else 0); 0 = panel chain on the aux stream; 2 = masked bulk stream
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
-  int persist_wgs = 0;
-  int reserve_slots = 0;  // tuning: half-CU slots a persistent 128x128 bulk grid leaves free (GMB_RESERVE_SLOTS)
-  int32_t* dsched = nullptr;
-  int sched_next = 0;
   std::vector<hipEvent_t> sync_pool;
   size_t sync_next = 0;
   bool lookahead = true;
   bool par_inverse = true;
-  std::vector<hipEvent_t> col_event;  // partitioned schedule: per block column, see wait_for_columns
   bool aux_shared = false;  // aux[2] is the process-wide masked stream (not ours to destroy)
   int part_cus = 0;         // compute units the masked stream leaves free
-  bool chain_shared = false;  // aux[1] is the process-wide stream masked to ONE XCD (the chain's)
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
 };
@@ -369,7 +337,7 @@ long long gemm_nact128(const GemmArgs& g) {
   return nact;
 }
 
-int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persistent = false) {
+int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   if (g_in.mt <= 0 || g_in.nt <= 0 || g_in.k <= 0) return GMB_OK;
   GemmArgs g = g_in;
   // tiles the 128 x 128 tiling would compute
@@ -380,18 +348,8 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
     f = f > g.nt ? g.nt : f;
     nact += g.nt - f;
   }
-  if (e->rec) {  // op of the fused panel kernel: 128 x 128 tiles by 8 waves, XCD-run order
-    ChainOp op{};
-    op.type = CHAIN_GEMM;
-    g.order = 0;
-    g.sched = nullptr;
-    op.nblocks = gemm_schedule(g, TILE, TILE, nullptr);
-    op.gemm = g;
-    if (op.nblocks > 0) e->rec->push_back(op);
-    return GMB_OK;
-  }
   const bool in_place = (const double*)g.C == g.B;  // the block must own every column of its rows
-  // variant: 0 = 128x128 / 4 waves, 1 = 64x64, 2 = 128x64, 3 = 128x32, 4 = 128x128 / 8 waves, 5 = 128x256 / 8 waves
+  // variant: 0 = 128x128, 1 = 64x64, 2 = 128x64, 3 = 128x32 (all 4 waves, two workgroups per compute unit)
   int variant = e->gemm_variant;
   {
     // Tile shape by a small model: a launch of T tiles on S workgroup slots (two per compute
@@ -413,9 +371,7 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
       variant = 0;
       if (score(2) > score(variant)) variant = 2;
       if (score(3) > score(variant)) variant = 3;
-    } else if (e->force_variant) {
-      if (variant == 5 && (g.nt % 2 || g.nblk_stride != 1 || g.tri)) variant = 0;
-    } else {
+    } else if (!e->force_variant) {
       variant = 0;
       if (e->small_tiles) {
         if (score(2) > score(variant)) variant = 2;
@@ -423,61 +379,36 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind, bool persisten
       }
     }
   }
-  // 6 = 256 x 128 / 8 waves, 106 KB of LDS: ONE workgroup per compute unit by construction -- the
-  // persistent bulk update, whose grid of (compute units - reserve_cus) workgroups then leaves
-  // whole compute units to the concurrent chain (a leaf sharing its unit with GEMM waves ran 4x slower)
-  if (persistent && !in_place && e->bulk_variant >= 0) variant = e->bulk_variant;
-  const bool persist = persistent && e->persist_wgs > 0 && !in_place && g_in.mt % 2 == 0 &&
-                       e->sched_next < SCHED_RING;
-  if (persist) variant = 6;
-  // alternative: the ordinary 128 x 128 / two-per-CU kernel as a persistent grid that leaves
-  // `reserve_slots` workgroup slots free (the chain kernels then share compute units with it)
-  const bool persist_half = !persist && persistent && e->reserve_slots > 0 && !in_place && variant == 0 &&
-                            e->sched_next < SCHED_RING;
-  static const int BMs[7] = {128, 64, 128, 128, 128, 128, 256}, BNs[7] = {128, 64, 64, 32, 128, 256, 128};
+  static const int BMs[4] = {128, 64, 128, 128}, BNs[4] = {128, 64, 64, 32};
   const int bm = BMs[variant], bn = BNs[variant];
   g.mt = g_in.mt * TILE / bm;
   g.nt = g_in.nt * TILE / bn;
   // triangular operand: dispatch the longest contractions first (see GemmArgs::order)
   g.order = 0;
-  if (e->lpt_order && !persist && g.nblk_stride == 1 && g.tri_off >= 0 && !g.klo_m && (g.klo_n != 0) != (g.khi_n != 0))
+  if (e->lpt_order && g.nblk_stride == 1 && g.tri_off >= 0 && !g.klo_m && (g.klo_n != 0) != (g.khi_n != 0))
     g.order = g.klo_n ? 1 : 2;
   double flops = 0.0;
   const int nblocks = gemm_schedule(g, bm, bn, &flops);
   if (nblocks <= 0) return GMB_OK;
   ev_begin(e, ev_kind, flops, g_in.mt, g_in.nt, g.k,
            g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (variant << 8));
-  int nlaunch = nblocks;
-  g.sched = nullptr;
-  if (persist) {
-    g.sched = e->dsched + 8 * (e->sched_next++);
-    nlaunch = std::min(nblocks, e->persist_wgs);
-  } else if (persist_half && nblocks > (int)e->wg_slots - e->reserve_slots) {
-    g.sched = e->dsched + 8 * (e->sched_next++);
-    nlaunch = (((int)e->wg_slots - e->reserve_slots) / 8) * 8;
-    variant = 7;
-  }
-  const dim3 grid(nlaunch);
+  const dim3 grid(nblocks);
   const bool pfc = g.beta != 0.0 && g.k <= 1024 && !in_place;
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, g); break;
     // small tiles with a short contraction and beta != 0: the C-prefetching instantiations (gemm_f64.hpp)
     case 1:
-      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2, false, true>), grid, dim3(256), 0, e->cur, g);
+      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2, true>), grid, dim3(256), 0, e->cur, g);
       else hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2>), grid, dim3(256), 0, e->cur, g);
       break;
     case 2:
-      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 2, 2, false, true>), grid, dim3(256), 0, e->cur, g);
+      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 2, 2, true>), grid, dim3(256), 0, e->cur, g);
       else hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 2, 2>), grid, dim3(256), 0, e->cur, g);
       break;
-    case 3:
-      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2, false, true>), grid, dim3(256), 0, e->cur, g);
+    default:
+      if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2, true>), grid, dim3(256), 0, e->cur, g);
       else hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 1, 2>), grid, dim3(256), 0, e->cur, g);
       break;
-    case 4: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 2, 4>), grid, dim3(512), 0, e->cur, g); break;
-    case 6: hipLaunchKernelGGL((gemm_f64_kernel<4, 2, 4, 4, 2, true>), grid, dim3(512), 0, e->cur, g); break;
-    case 7: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2, true>), grid, dim3(256), 0, e->cur, g); break;
-    default: hipLaunchKernelGGL((gemm_f64_kernel<2, 4, 4, 4, 2>), grid, dim3(512), 0, e->cur, g); break;
   }
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
@@ -496,42 +427,19 @@ int launch_trsm_strip(gmb_engine* e, double* B, int64_t ldb, int64_t nrows, cons
   t.ldl = ldl;
   t.dinv16 = dinv16;
   t.nvalid = nvalid;
-  if (e->rec) {
-    ChainOp op{};
-    op.type = CHAIN_STRIP;
-    op.trsm = t;
-    e->rec->push_back(op);
-    return GMB_OK;
-  }
   ev_begin(e, ev_kind, (double)nrows * TILE * TILE);
-  if (e->strip_lds)
-    hipLaunchKernelGGL(trsm_strip_lds_kernel, dim3((unsigned)((nrows / 16 + 3) / 4)), dim3(256), 0, e->cur, t);
-  else
-    hipLaunchKernelGGL(trsm_strip_kernel, dim3((unsigned)((nrows / 16 + 3) / 4)), dim3(256), 0, e->cur, t);
+  hipLaunchKernelGGL(trsm_strip_kernel, dim3((unsigned)((nrows / 16 + 3) / 4)), dim3(256), 0, e->cur, t);
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
 }
 
 int launch_leaf(gmb_engine* e, const LeafArgs& a) {
-  if (e->rec) {
-    ChainOp op{};
-    op.type = CHAIN_LEAF;
-    op.leaf = a;
-    e->rec->push_back(op);
-    return GMB_OK;
-  }
   ev_begin(e, 1, 0.0);
-  static const char* px = getenv("GMB_PROBE_XCD");  // software XCD partition probe: leaf on one XCD only
-  if (e->naive_leaf) {
+  if (e->naive_leaf)
     hipLaunchKernelGGL(potrf_leaf_naive_kernel, dim3(1), dim3(256), 0, e->cur, a);
-  } else if (px) {
-    LeafArgs b = a;
-    b.xcd_only = atoi(px) + 1;
-    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(8), dim3(512), 0, e->cur, b);
-  } else {
+  else
     hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(512), 0, e->cur, a);
-  }
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -766,27 +674,6 @@ int chol_leaf(gmb_engine* e, int c, int rend) {
   a.info = e->dinfo;
   a.row0 = (int64_t)c * TILE;
   a.dbg = nullptr;
-  const int64_t rows_below = (int64_t)(rend - c - 1) * TILE;
-  if (e->fused_column && !e->rec && !e->naive_leaf && e->dsync && rows_below > 0) {
-    // leaf + strip as one launch (chol_column_kernel)
-    ColumnArgs ca;
-    ca.leaf = a;
-    ca.trsm.B = e->dA + (int64_t)(c + 1) * TILE + (int64_t)c * TILE * e->ld;
-    ca.trsm.ldb = e->ld;
-    ca.trsm.nrows = rows_below;
-    ca.trsm.L = a.A;
-    ca.trsm.ldl = e->ld;
-    ca.trsm.dinv16 = a.dinv16;
-    ca.trsm.nvalid = a.nvalid;
-    ca.flag = &e->dsync->colflag;
-    ca.seq = ++e->column_seq;
-    ca.abort_flag = &e->dsync->abort;
-    ev_begin(e, 1, 0.0);
-    hipLaunchKernelGGL(chol_column_kernel, dim3((unsigned)(1 + (rows_below / 16 + 7) / 8)), dim3(512), 0, e->cur, ca);
-    ev_end(e);
-    HIP_TRY(e, hipGetLastError());
-    return GMB_OK;
-  }
   int rc = launch_leaf(e, a);
   if (rc) return rc;
   // panel rows below the diagonal block:  P <- P inv(L_cc)^T   (in place, 16 rows per wavefront)
@@ -794,23 +681,11 @@ int chol_leaf(gmb_engine* e, int c, int rend) {
                            (int64_t)(rend - c - 1) * TILE, a.A, e->ld, a.dinv16, a.nvalid, 5);
 }
 
-// Partitioned schedule (chol_partitioned): column c of the panel being factored may only be touched once
-// the previous panel's update of it has been issued on the bulk stream -- col_event[c] marks that point.
-int wait_for_columns(gmb_engine* e, int c_last) {
-  if (e->col_event.empty() || c_last >= (int)e->col_event.size() || !e->col_event[c_last]) return GMB_OK;
-  HIP_TRY(e, hipStreamWaitEvent(e->cur, e->col_event[c_last], 0));
-  return GMB_OK;
-}
-
 int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
-  if (c1 - c0 == 1) {
-    int rcw = wait_for_columns(e, c0);
-    return rcw ? rcw : chol_leaf(e, c0, rend);
-  }
+  if (c1 - c0 == 1) return chol_leaf(e, c0, rend);
   const int mid = c0 + (c1 - c0 + 1) / 2;
   int rc = chol_cols(e, c0, mid, rend);
   if (rc) return rc;
-  if ((rc = wait_for_columns(e, c1 - 1))) return rc;
   GemmArgs g{};
   g.C = e->dA + (int64_t)mid * TILE + (int64_t)mid * TILE * e->ld;
   g.ldc = e->ld;
@@ -850,59 +725,6 @@ int order_after(gmb_engine* e, hipStream_t from, hipStream_t to) {
 int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip,
               int lfirst = -1, int lstride = 0);
 
-// ---- fused panel chain --------------------------------------------------------------------------
-// Op lists of every panel but the first (which runs on the idle chip through ordinary launches),
-// recorded by running the panel recursion with the launch helpers in recording mode.
-int build_chain_plan(gmb_engine* e) {
-  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
-  const int w = e->panel_blocks;
-  if (e->chain_N == e->N && e->chain_ld == e->ld && e->chain_A == e->dA && e->chain_w == w && e->dchain) return GMB_OK;
-  std::vector<ChainOp> ops;
-  e->chain_off.clear();
-  e->chain_cnt.clear();
-  int rc = GMB_OK;
-  e->rec = &ops;
-  for (int n0 = 0; n0 < nct && !rc; n0 += w) {
-    const int n1 = std::min(n0 + w, nct);
-    e->chain_off.push_back((int)ops.size());
-    if (n0 > 0) rc = chol_cols(e, n0, n1, nrt);
-    e->chain_cnt.push_back((int)ops.size() - e->chain_off.back());
-  }
-  e->rec = nullptr;
-  if (rc) return rc;
-  if (e->dchain) (void)hipFree(e->dchain);
-  e->dchain = nullptr;
-  e->chain_N = -1;
-  if (ops.empty()) return GMB_EINVAL;
-  HIP_TRY(e, hipMalloc((void**)&e->dchain, ops.size() * sizeof(ChainOp)));
-  HIP_TRY(e, hipMemcpy(e->dchain, ops.data(), ops.size() * sizeof(ChainOp), hipMemcpyHostToDevice));
-  e->chain_host = ops;
-  e->chain_N = e->N;
-  e->chain_ld = e->ld;
-  e->chain_A = e->dA;
-  e->chain_w = w;
-  return GMB_OK;
-}
-
-// Launch the chain of panel index `pi` on `chainS` and hold `bulkS` until its workgroups are resident.
-int launch_panel_chain(gmb_engine* e, int pi, hipStream_t chainS, hipStream_t bulkS) {
-  const unsigned int seq = ++e->chain_seq;
-  ev_begin(e, 1, 0.0);
-  long long* stamps = nullptr;
-  static const char* dbg_env = getenv("GMB_CHAIN_DBG");  // tuning: per-op time stamps of panel index N
-  if (dbg_env && atoi(dbg_env) == pi) {
-    if (!e->dchain_stamps) HIP_TRY(e, hipMalloc((void**)&e->dchain_stamps, 4096 * sizeof(long long)));
-    stamps = e->dchain_stamps;
-    e->chain_dbg_panel = pi;
-  }
-  hipLaunchKernelGGL(panel_chain_kernel, dim3(e->chain_cus), dim3(512), 0, chainS, e->dchain + e->chain_off[pi],
-                     e->chain_cnt[pi], e->dsync, e->dsignal, seq, stamps);
-  ev_end(e);
-  HIP_TRY(e, hipGetLastError());
-  HIP_TRY(e, hipStreamWaitValue32(bulkS, e->dsignal, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
-  return GMB_OK;
-}
-
 // Full-height variant: the panel chain (leaf, strip solve and updates over ALL rows below) runs on
 // the auxiliary stream beside U2; U1 = the next panel's columns over all rows.
 int chol_lookahead_full(gmb_engine* e) {
@@ -910,157 +732,9 @@ int chol_lookahead_full(gmb_engine* e) {
   const int w = e->panel_blocks;
   hipStream_t mainS = e->stream, auxS = e->aux[0];
   e->sync_next = 0;
-  e->sched_next = 0;
-  HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
-  int rc;
-  const bool fused = e->chain_kernel && e->dsignal && build_chain_plan(e) == GMB_OK;
-  e->cur = mainS;
-  if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
-  for (int c0 = 0; c0 < nct; c0 += w) {
-    const int c1 = std::min(c0 + w, nct);
-    const int n0 = c1, n1 = std::min(c1 + w, nct);
-    if (n0 >= nct) break;
-    auto update = [&](int col_lo, int col_hi, bool bulk = false) {
-      GemmArgs g{};
-      g.C = e->dA + (int64_t)col_lo * TILE + (int64_t)col_lo * TILE * e->ld;
-      g.ldc = e->ld;
-      g.A = e->dA + (int64_t)col_lo * TILE + (int64_t)c0 * TILE * e->ld;
-      g.lda = e->ld;
-      g.B = g.A;
-      g.ldb = e->ld;
-      g.mt = col_hi - col_lo;
-      g.nt = nrt - col_lo;
-      g.k = (c1 - c0) * TILE;
-      g.alpha = -1.0;
-      g.beta = 1.0;
-      g.tri = 1;
-      return launch_gemm(e, g, 0, bulk);
-    };
-    e->cur = mainS;
-    if ((rc = update(n0, n1))) return rc;                 // U1
-    if ((rc = order_after(e, mainS, auxS))) return rc;
-    e->cur = auxS;
-    if (fused) {                                          // panel p+1 as ONE resident kernel, beside U2
-      if ((rc = launch_panel_chain(e, n0 / w, auxS, mainS))) return rc;
-    } else if ((rc = chol_cols(e, n0, n1, nrt))) {        // ... or as ~24 launches
-      return rc;
-    }
-    e->cur = mainS;
-    if (n1 < nct && (rc = update(n1, nct, true))) return rc;    // U2
-    if ((rc = order_after(e, auxS, mainS))) return rc;
-  }
-  e->cur = mainS;
-  return GMB_OK;
-}
-
-// Plain right-looking panels on ONE stream, no look-ahead (scheme 3): since the chain and the bulk
-// update serialise in practice, one merged update per panel has the better tile quantisation.
-int chol_panels_serial(gmb_engine* e) {
-  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
-  const int w = e->panel_blocks;
-  int rc;
-  e->cur = e->stream;
-  for (int c0 = 0; c0 < nct; c0 += w) {
-    const int c1 = std::min(c0 + w, nct);
-    if ((rc = chol_cols(e, c0, c1, nrt))) return rc;
-    if (c1 >= nct) break;
-    GemmArgs g{};
-    g.C = e->dA + (int64_t)c1 * TILE + (int64_t)c1 * TILE * e->ld;
-    g.ldc = e->ld;
-    g.A = e->dA + (int64_t)c1 * TILE + (int64_t)c0 * TILE * e->ld;
-    g.lda = e->ld;
-    g.B = g.A;
-    g.ldb = e->ld;
-    g.mt = nct - c1;
-    g.nt = nrt - c1;
-    g.k = (c1 - c0) * TILE;
-    g.alpha = -1.0;
-    g.beta = 1.0;
-    g.tri = 1;
-    if ((rc = launch_gemm(e, g, 0))) return rc;
-  }
-  return GMB_OK;
-}
-
-// Full-height chain on the MAIN stream, U2 on the CU-masked stream (scheme 2).
-int chol_lookahead_masked(gmb_engine* e) {
-  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
-  const int w = e->panel_blocks;
-  hipStream_t mainS = e->stream, bulkS = e->aux[2];
-  e->sync_next = 0;
-  e->sched_next = 0;
-  HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
   int rc;
   e->cur = mainS;
   if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
-  for (int c0 = 0; c0 < nct; c0 += w) {
-    const int c1 = std::min(c0 + w, nct);
-    const int n0 = c1, n1 = std::min(c1 + w, nct);
-    if (n0 >= nct) break;
-    auto update = [&](int col_lo, int col_hi, bool bulk = false) {
-      GemmArgs g{};
-      g.C = e->dA + (int64_t)col_lo * TILE + (int64_t)col_lo * TILE * e->ld;
-      g.ldc = e->ld;
-      g.A = e->dA + (int64_t)col_lo * TILE + (int64_t)c0 * TILE * e->ld;
-      g.lda = e->ld;
-      g.B = g.A;
-      g.ldb = e->ld;
-      g.mt = col_hi - col_lo;
-      g.nt = nrt - col_lo;
-      g.k = (c1 - c0) * TILE;
-      g.alpha = -1.0;
-      g.beta = 1.0;
-      g.tri = 1;
-      return launch_gemm(e, g, 0, bulk);
-    };
-    e->cur = mainS;
-    if ((rc = order_after(e, bulkS, mainS))) return rc;   // U2(p-1) reached these columns
-    if ((rc = update(n0, n1))) return rc;                 // U1
-    if ((rc = order_after(e, mainS, bulkS))) return rc;
-    e->cur = bulkS;
-    rc = (n1 < nct) ? update(n1, nct, true) : 0;          // U2, on the compute units its mask allows
-    e->cur = mainS;
-    if (rc) return rc;
-    if (e->chain_shared && n1 < nct) {
-      // panel p+1 on the stream that owns the XCD the bulk stream leaves free
-      hipStream_t chainS = e->aux[1];
-      if ((rc = order_after(e, mainS, chainS))) return rc;
-      e->cur = chainS;
-      rc = chol_cols(e, n0, n1, nrt);
-      e->cur = mainS;
-      if (rc) return rc;
-      if ((rc = order_after(e, chainS, mainS))) return rc;
-    } else if ((rc = chol_cols(e, n0, n1, nrt))) {        // panel p+1, beside U2
-      return rc;
-    }
-  }
-  e->cur = mainS;
-  return order_after(e, bulkS, mainS);
-}
-
-
-// Partitioned schedule (GMB_CHOL_SCHEME=4 with GMB_MASK_XCD / GMB_MASK_CHAIN): the chain of panel p+1
-// runs on the stream that owns one XCD, every update of the trailing matrix on the stream that owns
-// the other seven, and the update of the NEXT panel's columns (U1) is issued in the pieces the panel
-// recursion consumes them in (1, 1, 2, 4 ... block columns), each followed by an event the chain
-// waits for just before it first touches those columns: only the first piece is on the critical path.
-//
-//   chain :  panel 0 (whole chip) | wait piece events ... panel 1 ...          | panel 2 ...
-//   bulk  :                       | U1(0) pieces | U2(0)   | wait panel 1 | U1(1) pieces | U2(1) ...
-int chol_partitioned(gmb_engine* e) {
-  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
-  const int w = e->panel_blocks;
-  hipStream_t mainS = e->stream, bulkS = e->aux[2], chainS = e->chain_shared ? e->aux[1] : e->stream;
-  e->sync_next = 0;
-  e->sched_next = 0;
-  HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
-  int rc;
-  e->col_event.assign(nct, nullptr);
-  e->cur = mainS;
-  rc = chol_cols(e, 0, std::min(w, nct), nrt);  // panel 0 on the whole chip (no events yet)
-  if (rc) { e->col_event.clear(); return rc; }
-  if ((rc = order_after(e, mainS, bulkS))) { e->col_event.clear(); return rc; }
-  if ((rc = order_after(e, mainS, chainS))) { e->col_event.clear(); return rc; }
   for (int c0 = 0; c0 < nct; c0 += w) {
     const int c1 = std::min(c0 + w, nct);
     const int n0 = c1, n1 = std::min(c1 + w, nct);
@@ -1081,111 +755,57 @@ int chol_partitioned(gmb_engine* e) {
       g.tri = 1;
       return launch_gemm(e, g, 0);
     };
-    // bulk side: U1(p) in the pieces of the recursion over [n0, n1), then U2(p)
-    e->cur = bulkS;
-    int covered = n0;
-    std::function<int(int, int)> pieces = [&](int a, int b) -> int {
-      auto emit = [&](int lo, int hi) -> int {
-        int r = update(lo, hi);
-        if (r) return r;
-        hipEvent_t ev = next_sync_event(e);
-        if (hipEventRecord(ev, bulkS) != hipSuccess) return fail(e, GMB_EHIP, "event record");
-        for (int c = lo; c < hi; ++c) e->col_event[c] = ev;
-        covered = hi;
-        return GMB_OK;
-      };
-      if (b - a == 1) return a >= covered ? emit(a, b) : GMB_OK;
-      const int mid = a + (b - a + 1) / 2;
-      int r = pieces(a, mid);
-      if (r) return r;
-      if (b > covered && (r = emit(std::max(mid, covered), b))) return r;
-      return pieces(mid, b);
-    };
-    if ((rc = pieces(n0, n1))) break;
-    if (n1 < nct && (rc = update(n1, nct))) break;  // U2(p)
-    // chain side: panel p+1 (its kernels wait for the piece events), then the bulk side may go on
-    e->cur = chainS;
-    if ((rc = chol_cols(e, n0, n1, nrt))) break;
-    if ((rc = order_after(e, chainS, bulkS))) break;
+    e->cur = mainS;
+    if ((rc = update(n0, n1))) return rc;                 // U1
+    if ((rc = order_after(e, mainS, auxS))) return rc;
+    e->cur = auxS;
+    if ((rc = chol_cols(e, n0, n1, nrt))) return rc;      // panel p+1 (~24 small launches) beside U2
+    e->cur = mainS;
+    if (n1 < nct && (rc = update(n1, nct))) return rc;    // U2
+    if ((rc = order_after(e, auxS, mainS))) return rc;
   }
   e->cur = mainS;
-  e->col_event.clear();
-  if (rc) return rc;
-  if ((rc = order_after(e, chainS, mainS))) return rc;
-  return order_after(e, bulkS, mainS);
+  return GMB_OK;
 }
 
-// ---- Cholesky with panel look-ahead -------------------------------------------------------------
-// Right-looking over panels of `panel_blocks` block columns [c0, c1).  Only the panel's diagonal
-// SQUARE is factored by the latency-bound chain (leaf, strip solve, small updates); everything
-// else is bulk MFMA work:
-//
-//   main :  square(p) | solve rows below: A[c1:, c0:c1] L_pp^-T | U1(p): next square | square(p+1) ...
-//   bulk :                                                       | wait U1; U2(p): rest of the trailing update
-//
-// square(p+1) needs only U1(p), so the chain of the next panel runs beside U2(p).  For that to
-// happen the chain's kernels must actually find a compute unit while U2's grid is resident (the
-// leaf needs 150 KB of LDS, i.e. an EMPTY compute unit; a GEMM workgroup of U2 holds its unit for
-// hundreds of microseconds, so a late kernel waits that long for a slot): U2 is launched as a
-// PERSISTENT grid of whole-compute-unit workgroups, `reserve_cus` fewer than the chip has compute
-// units, that draw their tiles from per-XCD counters.  The streams are ordered with events.
-int chol_lookahead(gmb_engine* e) {
+// Full-height chain on the MAIN stream, U2 on the CU-masked stream (scheme 2).
+int chol_lookahead_masked(gmb_engine* e) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
   const int w = e->panel_blocks;
   hipStream_t mainS = e->stream, bulkS = e->aux[2];
   e->sync_next = 0;
-  e->sched_next = 0;
-  HIP_TRY(e, hipMemsetAsync(e->dsched, 0, SCHED_RING * 8 * sizeof(int32_t), mainS));
   int rc;
   e->cur = mainS;
+  if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
   for (int c0 = 0; c0 < nct; c0 += w) {
-    const int c1 = std::min(c0 + w, nct), c2 = std::min(c1 + w, nct);
-    // the panel's diagonal square (for the last panel: including the y row block, if separate)
-    const int rend = (c1 == nct) ? nrt : c1;
-    if ((rc = chol_cols(e, c0, c1, rend))) return rc;
-    if (c1 == nct) break;
-    // rows below the square, once the previous bulk update has reached them
-    if ((rc = order_after(e, bulkS, mainS))) return rc;
-    if ((rc = trsm_cols(e, e->dA + (int64_t)c1 * TILE, e->ld, nrt - c1, c0, c1, 2, 5))) return rc;
-    GemmArgs g{};
-    g.lda = g.ldb = g.ldc = e->ld;
-    g.k = (c1 - c0) * TILE;
-    g.alpha = -1.0;
-    g.beta = 1.0;
-    g.tri = 1;
-    // U1: the next diagonal square (with the y row block when it closes the matrix)
-    const int r2 = (c2 == nct) ? nrt : c2;
-    g.C = e->dA + (int64_t)c1 * TILE + (int64_t)c1 * TILE * e->ld;
-    g.A = e->dA + (int64_t)c1 * TILE + (int64_t)c0 * TILE * e->ld;
-    g.B = g.A;
-    g.mt = c2 - c1;
-    g.nt = r2 - c1;
-    if ((rc = launch_gemm(e, g, 0))) return rc;
-    if (r2 < nrt) {
-      // U2: rows [c2, nrt) x columns [c1, nct) of the trailing matrix, on the bulk stream
-      if ((rc = order_after(e, mainS, bulkS))) return rc;
-      e->cur = bulkS;
-      g.C = e->dA + (int64_t)c2 * TILE + (int64_t)c1 * TILE * e->ld;
-      g.B = e->dA + (int64_t)c2 * TILE + (int64_t)c0 * TILE * e->ld;
-      g.mt = (nct - c1) & ~1;  // the persistent tiling is 256 columns wide
-      g.nt = nrt - c2;
-      g.tri_off = (c2 - c1) * TILE;
-      rc = launch_gemm(e, g, 0, true);
-      if (!rc && ((nct - c1) & 1)) {  // odd block column left over: the last one
-        const int cl = nct - 1, rl = std::max(c2, cl);
-        g.C = e->dA + (int64_t)rl * TILE + (int64_t)cl * TILE * e->ld;
-        g.A = e->dA + (int64_t)cl * TILE + (int64_t)c0 * TILE * e->ld;
-        g.B = e->dA + (int64_t)rl * TILE + (int64_t)c0 * TILE * e->ld;
-        g.mt = 1;
-        g.nt = nrt - rl;
-        g.tri = 0;
-        g.tri_off = 0;
-        rc = launch_gemm(e, g, 0);
-        g.tri = 1;
-      }
-      e->cur = mainS;
-      if (rc) return rc;
-    }
+    const int c1 = std::min(c0 + w, nct);
+    const int n0 = c1, n1 = std::min(c1 + w, nct);
+    if (n0 >= nct) break;
+    auto update = [&](int col_lo, int col_hi) {
+      GemmArgs g{};
+      g.C = e->dA + (int64_t)col_lo * TILE + (int64_t)col_lo * TILE * e->ld;
+      g.ldc = e->ld;
+      g.A = e->dA + (int64_t)col_lo * TILE + (int64_t)c0 * TILE * e->ld;
+      g.lda = e->ld;
+      g.B = g.A;
+      g.ldb = e->ld;
+      g.mt = col_hi - col_lo;
+      g.nt = nrt - col_lo;
+      g.k = (c1 - c0) * TILE;
+      g.alpha = -1.0;
+      g.beta = 1.0;
+      g.tri = 1;
+      return launch_gemm(e, g, 0);
+    };
+    e->cur = mainS;
+    if ((rc = order_after(e, bulkS, mainS))) return rc;   // U2(p-1) reached these columns
+    if ((rc = update(n0, n1))) return rc;                 // U1
+    if ((rc = order_after(e, mainS, bulkS))) return rc;
+    e->cur = bulkS;
+    rc = (n1 < nct) ? update(n1, nct) : 0;          // U2, on the compute units its mask allows
+    e->cur = mainS;
+    if (rc) return rc;
+    if ((rc = chol_cols(e, n0, n1, nrt))) return rc;      // panel p+1, beside U2
   }
   e->cur = mainS;
   return order_after(e, bulkS, mainS);
@@ -1269,7 +889,7 @@ int winv_level_batched(gmb_engine* e, const gmb_engine::InvLevelPlan& lp);
 int winv_levels(gmb_engine* e, int nt) {
   std::vector<std::vector<InvNode>> levels;
   collect_inv_nodes(0, nt, 0, levels);
-  hipStream_t streams[4] = {e->stream, e->aux[0], e->chain_shared ? e->stream : e->aux[1], e->aux_shared ? e->aux[0] : e->aux[2]};
+  hipStream_t streams[4] = {e->stream, e->aux[0], e->aux[1], e->aux_shared ? e->aux[0] : e->aux[2]};
   int rc;
   for (int a = 1; a < 4; ++a)
     if ((rc = order_after(e, streams[0], streams[a]))) return rc;
@@ -1421,8 +1041,7 @@ int build_inv_plan(gmb_engine* e, const std::vector<std::vector<InvNode>>& level
         g.order = e->lpt_order ? (b == 0 ? 1 : 2) : 0;
         double fl = 0.0;
         const int nb = gemm_schedule(g, BMs[variant], BNs[variant], &fl);
-        g.sched = nullptr;
-        lp.grid_x[b] = std::max(lp.grid_x[b], nb);
+            lp.grid_x[b] = std::max(lp.grid_x[b], nb);
         lp.flops[b] += fl;
         hg.push_back(g);
       }
@@ -1712,21 +1331,39 @@ int require_ready(gmb_engine* e, bool need_factor) {
 
 }  // namespace
 
-// =============================================================================================
-// C ABI
-// =============================================================================================
-extern "C" {
+namespace {
 
-int gmb_abi_version(void) { return GMB_ABI_VERSION; }
-
-int gmb_device_count(void) {
-  int n = 0;
-  hipError_t s = hipGetDeviceCount(&n);
-  if (s != hipSuccess || n <= 0) return GMB_ENODEVICE;
-  return n;
+// ONE CU-masked bulk stream per process and device, created on first use and never destroyed (masked
+// streams that were created and destroyed with every engine made kernel timings depend on the queue
+// history of the process).  It leaves `part_cus / 8` compute units of every XCD free for the latency-bound
+// panel chain of chol_lookahead_masked; the runtime applies a CU mask symmetrically to all XCDs (bit i <->
+// XCD i % 8, compute unit i / 8 of it -- tools/probes/cumask_probe.hip).  Engines on one device share it,
+// i.e. their trailing updates serialise on it; every engine joins it back into its own stream before
+// gmb_factorize returns.
+hipStream_t shared_masked_stream(int device, int part_cus, int* ncu_out) {
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  static int ncus[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  hipStream_t& st = streams[device & 63];
+  if (!st) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int i = part_cus; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+      st = nullptr;
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    ncus[device & 63] = ncu;
+  }
+  if (ncu_out) *ncu_out = ncus[device & 63];
+  return st;
 }
 
-int gmb_create(gmb_engine** out, int32_t device, void* stream) {
+int gmb_create_impl(gmb_engine** out, int32_t device, void* stream) {
   if (!out) return GMB_EINVAL;
   *out = nullptr;
   int n = gmb_device_count();
@@ -1744,144 +1381,61 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
     }
     e->own_stream = true;
   }
-  const char* nl = getenv("GMB_LEAF_NAIVE");
-  e->naive_leaf = nl && nl[0] == '1';
-  const char* st = getenv("GMB_SMALL_TILES");  // tuning switch: 0 forces the 128 x 128 tiling
-  e->small_tiles = !(st && st[0] == '0');
-  const char* gv = getenv("GMB_GEMM_VARIANT");  // tuning: 0 = 128x128/4 waves, 4 = 128x128/8 waves, 5 = 128x256/8 waves
-  if (gv && gv[0] >= '0' && gv[0] <= '5') e->gemm_variant = gv[0] - '0';
-  e->force_variant = gv != nullptr;
-  const char* la = getenv("GMB_LOOKAHEAD");    // tuning switches for the multi-stream schedules
-  e->lookahead = !(la && la[0] == '0');
-  const char* bv = getenv("GMB_BULK_VARIANT");
-  if (bv && bv[0] >= '0' && bv[0] <= '3') e->bulk_variant = bv[0] - '0';
-  const char* lo = getenv("GMB_LPT_ORDER");  // tuning: 0 = XCD-run order for every launch
-  e->lpt_order = !(lo && lo[0] == '0');
-  const char* bi = getenv("GMB_BATCH_INVERSE");  // tuning: 0 = one launch per node on four streams
-  e->batch_inverse = !(bi && bi[0] == '0');
-  const char* pi = getenv("GMB_PAR_INVERSE");
-  e->par_inverse = !(pi && pi[0] == '0');
+  auto flag = [](const char* name, bool dflt) {
+    const char* v = getenv(name);
+    return v && v[0] ? v[0] != '0' : dflt;
+  };
+  // Tuning / debugging switches (none changes results beyond rounding; the defaults are what the tests and
+  // the bench run): the reference leaf kernel, tile-shape pinning, the two fallbacks of the look-ahead
+  // Cholesky (plain recursion, unmasked schedule), the inverse's launch structure.
+  e->naive_leaf = flag("GMB_LEAF_NAIVE", false);
+  e->small_tiles = flag("GMB_SMALL_TILES", true);
+  const char* gv = getenv("GMB_GEMM_VARIANT");  // pins the tile shape of every out-of-place GEMM: 0 .. 3
+  if (gv && gv[0] >= '0' && gv[0] <= '3') {
+    e->gemm_variant = gv[0] - '0';
+    e->force_variant = true;
+  }
+  e->lookahead = flag("GMB_LOOKAHEAD", true);
+  e->lpt_order = flag("GMB_LPT_ORDER", true);
+  e->batch_inverse = flag("GMB_BATCH_INVERSE", true);
+  e->par_inverse = flag("GMB_PAR_INVERSE", true);
   const char* pb = getenv("GMB_PANEL_BLOCKS");
   if (pb && atoi(pb) > 0) {
     e->panel_blocks = atoi(pb);
     e->panel_auto = false;
   }
+  const char* cs = getenv("GMB_CHOL_SCHEME");  // 0 = unmasked look-ahead, 2 = masked bulk stream, default by size
+  if (cs) e->chol_scheme = atoi(cs);
+  const char* mb = getenv("GMB_MASKED_MAX_BLOCKS");
+  if (mb) e->masked_max_blocks = atoi(mb);
   e->cur = e->stream;
-  // aux[0], aux[1]: highest queue priority (independent merges of the triangular inverse);
-  // aux[2]: LOWEST priority -- it carries the bulk trailing updates of the look-ahead Cholesky,
-  // whose workgroups must not be placed ahead of the latency-bound chain on the main stream.
-  // (No fifth stream: beyond four hardware queues the runtime multiplexes streams and every
-  // kernel of the process slows down -- measured.)
+  // Exactly four streams per engine (beyond four hardware queues the runtime multiplexes streams and every
+  // kernel of the process slows down -- measured): the caller's, aux[0] / aux[1] at the highest queue
+  // priority (panel chain of the unmasked look-ahead; independent merges of the triangular inverse), and
+  // aux[2] = the bulk stream of the trailing updates: the process-wide CU-masked stream (GMB_PART_CUS
+  // compute units left free, default 32; 0 = an ordinary lowest-priority stream, unmasked schedules only).
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  const char* ap = getenv("GMB_AUX_PRIORITY");
-  const bool use_prio = !(ap && ap[0] == '0');
-  const char* mk = getenv("GMB_MASK_CUS");  // tuning: compute units (multiple of 8) the bulk stream leaves free
-  const int mask_cus = mk ? atoi(mk) : 0;
+  const char* pc = getenv("GMB_PART_CUS");
+  const int part = pc ? atoi(pc) : 32;
   for (int a = 0; a < 3; ++a) {
-    hipError_t st2;
-    hipDeviceProp_t prop;
-    static hipStream_t shared_masked_dev[64] = {};  // GMB_MASK_XCD: ONE masked stream per process and device, never destroyed
-    hipStream_t& shared_masked = shared_masked_dev[device & 63];
-    // aux[2] is the BULK stream of the masked look-ahead schedule (chol_lookahead_masked): a CU-masked
-    // stream that leaves `part` / 8 compute units of every XCD to the latency-bound chain on the main
-    // stream.  The mask applies symmetrically to all XCDs (bit i <-> XCD i % 8, compute unit i / 8 of
-    // it; a mask naming a single XCD is not honoured -- tools/probes/cumask_probe.hip).  ONE such
-    // stream per process and device, created on first use and never destroyed: masked streams that
-    // were created and destroyed with every engine made the timings depend on the queue history of
-    // the process.  GMB_PART_CUS=0 disables it (then aux[2] is an ordinary low-priority stream).
-    const char* mx = getenv("GMB_MASK_XCD");     // experiment: XCD form of the masks (not honoured by the runtime)
-    const char* pc = getenv("GMB_PART_CUS");
-    const int part = pc ? atoi(pc) : 32;
-    if (a == 2 && (mx || part > 0) && hipGetDeviceProperties(&prop, device) == hipSuccess) {
-      if (!shared_masked) {
-        const int ncu = prop.multiProcessorCount, xcd = mx ? atoi(mx) : 0;
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int i = 0; i < ncu; ++i)
-          if (part > 0 ? i >= part : (i & 7) != xcd) mask[i / 32] |= 1u << (i % 32);
-        if (hipExtStreamCreateWithCUMask(&shared_masked, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-          shared_masked = nullptr;
-          (void)hipGetLastError();
-        }
-      }
-      if (shared_masked) {
-        e->aux[a] = shared_masked;
-        e->aux_shared = true;
-        e->part_cus = part > 0 ? part : prop.multiProcessorCount / 8;
-        st2 = hipSuccess;
-      } else {  // no masked stream on this system: ordinary stream, unmasked schedules only
-        st2 = hipStreamCreateWithPriority(&e->aux[a], hipStreamNonBlocking, prio_lo);
-      }
-    } else if (a == 1 && mx && getenv("GMB_MASK_CHAIN") && hipGetDeviceProperties(&prop, device) == hipSuccess) {
-      // ... and the chain stream the complement: only that XCD
-      static hipStream_t shared_chain_dev[64] = {};
-      hipStream_t& shared_chain = shared_chain_dev[device & 63];
-      if (!shared_chain) {
-        const int ncu = prop.multiProcessorCount, xcd = atoi(mx);
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int i = 0; i < ncu; ++i)
-          if (part > 0 ? i < part : (i & 7) == xcd) mask[i / 32] |= 1u << (i % 32);
-        if (hipExtStreamCreateWithCUMask(&shared_chain, (uint32_t)mask.size(), mask.data()) != hipSuccess) shared_chain = nullptr;
-      }
-      e->aux[a] = shared_chain;
-      e->chain_shared = true;
-      st2 = shared_chain ? hipSuccess : hipErrorUnknown;
-    } else if (a == 2 && mask_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess) {
-      // mask bit i addresses XCD i % 8 (then shader engine, then CU): clearing the first mask_cus
-      // bits takes mask_cus / 8 compute units from every XCD
-      const int ncu = prop.multiProcessorCount;
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      for (int i = 0; i < ncu; ++i)
-        if (i >= mask_cus) mask[i / 32] |= 1u << (i % 32);
-      st2 = hipExtStreamCreateWithCUMask(&e->aux[a], (uint32_t)mask.size(), mask.data());
-    } else
-    st2 = use_prio ? hipStreamCreateWithPriority(&e->aux[a], hipStreamNonBlocking, a == 2 ? prio_lo : prio_hi)
-                   : hipStreamCreateWithFlags(&e->aux[a], hipStreamNonBlocking);
+    hipError_t st2 = hipSuccess;
+    int ncu = 0;
+    hipStream_t masked = (a == 2 && part > 0) ? shared_masked_stream(device, part, &ncu) : nullptr;
+    if (masked) {
+      e->aux[a] = masked;
+      e->aux_shared = true;
+      e->part_cus = part;
+    } else {
+      st2 = hipStreamCreateWithPriority(&e->aux[a], hipStreamNonBlocking, a == 2 ? prio_lo : prio_hi);
+    }
     if (st2 != hipSuccess) {
       gmb_destroy(e);
       return GMB_EHIP;
     }
   }
-  {
-    const char* cs = getenv("GMB_CHOL_SCHEME");
-    if (cs) e->chol_scheme = atoi(cs);
-    const char* mb = getenv("GMB_MASKED_MAX_BLOCKS");
-    if (mb) e->masked_max_blocks = atoi(mb);
-    const char* rs = getenv("GMB_RESERVE_CUS");  // tuning: 0 = ordinary (chip-filling) bulk launches
-    if (rs) e->reserve_cus = atoi(rs);
-    const char* rsl = getenv("GMB_RESERVE_SLOTS");
-    if (rsl) e->reserve_slots = atoi(rsl);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-      e->wg_slots = 2LL * prop.multiProcessorCount;
-      const int wgs = prop.multiProcessorCount - e->reserve_cus;
-      e->persist_wgs = (e->reserve_cus > 0 && wgs >= 64) ? (wgs / 8) * 8 : 0;
-    }
-    const char* sl = getenv("GMB_STRIP_LDS");
-    e->strip_lds = sl && sl[0] == '1';
-    const char* fc = getenv("GMB_FUSED_COLUMN");  // tuning: 1 = leaf and strip as one launch (chol_column_kernel)
-    e->fused_column = fc && fc[0] == '1';
-    const char* ck = getenv("GMB_CHAIN_KERNEL");
-    e->chain_kernel = ck && ck[0] == '1';
-    const char* cc = getenv("GMB_CHAIN_CUS");
-    if (cc && atoi(cc) > 0) e->chain_cus = atoi(cc);
-    e->chain_cus = std::max(8, std::min(e->chain_cus, (int)(e->wg_slots / 2) - 8));
-    int can_wait = 0;
-    (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device);
-    if (can_wait && hipMalloc((void**)&e->dsync, sizeof(ChainSync)) == hipSuccess &&
-        hipMemset(e->dsync, 0, sizeof(ChainSync)) == hipSuccess) {
-      if (hipExtMallocWithFlags((void**)&e->dsignal, 8, hipMallocSignalMemory) != hipSuccess) {
-        (void)hipGetLastError();
-        e->dsignal = nullptr;
-      } else {
-        (void)hipMemset(e->dsignal, 0, 8);
-      }
-    }
-    if (hipMalloc((void**)&e->dsched, SCHED_RING * 8 * sizeof(int32_t)) != hipSuccess) {
-      gmb_destroy(e);
-      return GMB_EHIP;
-    }
-  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->wg_slots = 2LL * prop.multiProcessorCount;
   if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
     gmb_destroy(e);
@@ -1891,17 +1445,39 @@ int gmb_create(gmb_engine** out, int32_t device, void* stream) {
   return GMB_OK;
 }
 
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int gmb_abi_version(void) { return GMB_ABI_VERSION; }
+
+int gmb_device_count(void) {
+  int n = 0;
+  hipError_t s = hipGetDeviceCount(&n);
+  if (s != hipSuccess || n <= 0) return GMB_ENODEVICE;
+  return n;
+}
+
+int gmb_create(gmb_engine** out, int32_t device, void* stream) { return gmb_create_impl(out, device, stream); }
+
 void gmb_destroy(gmb_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  // the engine's own work on every stream it used (the shared bulk stream is joined into e->stream at the
+  // end of every factorisation, but an error return may have skipped that)
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->dchain_stamps, e->dchain, e->dsync, e->dsignal, e->dplan_gemm, e->dplan_tr, e->dsched, e->dDinv16, e->dX,   e->dy,   e->dA,   e->xs,    e->xl,   e->cat,    e->dtabs,
-                  e->dnoise, e->dscal, e->dinfo, e->dv,  e->dV,    e->dXs,  e->txs,    e->txl,
-                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW,   e->dalpha, e->dgpart};
+  for (int a = 0; a < 3; ++a)
+    if (e->aux[a]) (void)hipStreamSynchronize(e->aux[a]);
+  void* ptrs[] = {e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
+                  e->dnoise, e->dscal, e->dinfo, e->dv, e->dV, e->dXs, e->txs, e->txl,
+                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int a = 0; a < 3; ++a)
-    if (e->aux[a] && !(a == 2 && e->aux_shared) && !(a == 1 && e->chain_shared)) (void)hipStreamDestroy(e->aux[a]);
+    if (e->aux[a] && !(a == 2 && e->aux_shared)) (void)hipStreamDestroy(e->aux[a]);
   for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1935,8 +1511,14 @@ int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t l
     if (rc) return rc;
   }
   HIP_TRY(e, hipSetDevice(e->device));
+  // not ready until every allocation below has succeeded; workspaces sized for the previous N / D are dropped
   e->factored = false;
-  e->N = N;
+  e->have_theta = false;
+  e->N = 0;
+  e->cap_pts = 0;
+  e->Mt_cap = 0;
+  e->cap_part = 0;
+  e->plan_N = -1;
   e->D = D;
   e->Np = round_up(N, TILE);
   e->Nr = round_up(N + 1, TILE);
@@ -1953,8 +1535,7 @@ int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t l
   HIP_TRY(e, hipMemsetAsync(e->dy, 0, e->Np * sizeof(double), e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->dy, y, N * sizeof(double), kind, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  e->cap_pts = 0;  // prepared coordinates must be rebuilt
-  e->have_theta = false;
+  e->N = N;
   return GMB_OK;
 }
 
@@ -2075,11 +1656,8 @@ int gmb_factorize(gmb_engine* e) {
     // default (chol_scheme < 0): small matrices are chain-bound -- the masked bulk stream lets the chain run
     // beside the trailing updates (N = 10k: 9.8 -> 9.0 ms); large ones lose more to the 12 % of compute
     // units taken from the updates than the chain is worth (N = 30k: +5 %), they keep the full chip
-    if (e->chol_scheme < 0)
-      rc = (e->aux_shared && e->Np / TILE <= e->masked_max_blocks) ? chol_lookahead_masked(e) : chol_lookahead_full(e);
-    else
-    rc = (e->chol_scheme == 0 ? chol_lookahead_full(e) : (e->chol_scheme == 2 ? chol_lookahead_masked(e) : (e->chol_scheme == 3 ? chol_panels_serial(e) : ((e->chol_scheme == 4 && e->aux_shared) ? chol_partitioned(e) : chol_lookahead(e)))));
-    if (rc) return rc;
+    const bool masked = e->aux_shared && (e->chol_scheme == 2 || (e->chol_scheme < 0 && e->Np / TILE <= e->masked_max_blocks));
+    if ((rc = masked ? chol_lookahead_masked(e) : chol_lookahead_full(e))) return rc;
   } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) {
     return rc;
   }
@@ -2092,28 +1670,7 @@ int gmb_factorize(gmb_engine* e) {
   int32_t info = 0;
   HIP_TRY(e, hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-  ChainSync hsync{};
-  if ((e->chain_kernel || e->fused_column) && e->dsync)
-    HIP_TRY(e, hipMemcpyAsync(&hsync, e->dsync, sizeof(ChainSync), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  if (e->chain_dbg_panel >= 0 && e->dchain_stamps) {
-    const int pi = e->chain_dbg_panel, n = e->chain_cnt[pi];
-    std::vector<long long> st(2 * n + 1);
-    (void)hipMemcpy(st.data(), e->dchain_stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[chain panel %d: %d ops, total %.1f us]\n", pi, n, (st[2 * n] - st[0]) / 100.0);
-    for (int i = 0; i < n; ++i) {
-      const ChainOp& op = e->chain_host[e->chain_off[pi] + i];
-      fprintf(stderr, "  op %2d type %d  work %7.1f us  barrier %6.1f us  (nblocks %d, rows %lld, k %d)\n", i, op.type,
-              (st[2 * i + 1] - st[2 * i]) / 100.0, (st[2 * i + 2] - st[2 * i + 1]) / 100.0, op.nblocks,
-              (long long)op.trsm.nrows, op.gemm.k);
-    }
-    e->chain_dbg_panel = -1;
-  }
-  if (hsync.abort) {
-    (void)hipMemset(e->dsync, 0, sizeof(ChainSync));
-    ev_collect(e);
-    return fail(e, GMB_EHIP, "fused Cholesky kernel: watchdog fired while waiting for another workgroup");
-  }
   tm.kbuild_ms = tk.ms();
   tm.chol_ms = tc.ms();
   tm.kbuild_bytes = 8.0 * (double)e->N * (double)(e->N + 1) / 2.0 +
@@ -2431,12 +1988,10 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
   const int per_cu = (eb && atoi(eb) > 0) ? atoi(eb) : 2;
   const double scale = ez ? atof(ez) : 1.0;
   const char* ei = getenv("GMB_PEAK_ITERS");
-  const char* es = getenv("GMB_PEAK_SKIP_XCD");  // partition probe: leave one XCD to other kernels
-  const int skip_xcd = es ? atoi(es) : -1;
   const int blocks = 256 * per_cu, iters = (ei && atoi(ei) > 0) ? atoi(ei) : 2000;
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100, scale, skip_xcd);  // warm-up
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100, scale);  // warm-up
   (void)hipEventRecord(a, 0);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, scale, skip_xcd);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, scale);
   (void)hipEventRecord(b, 0);
   int rc = GMB_OK;
   if (hipEventSynchronize(b) != hipSuccess || hipGetLastError() != hipSuccess) rc = GMB_EHIP;

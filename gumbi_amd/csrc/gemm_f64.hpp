@@ -77,11 +77,6 @@ struct GemmArgs {
   // runs 1.1 ms of a 2.8 ms launch and must not start late.  Consecutive blocks land on
   // consecutive XCDs, which deals every length class evenly over the 8 XCDs.
   int32_t order;
-  // Persistent mode (sched != nullptr): the grid is SMALLER than the tile list and every workgroup
-  // keeps drawing the next tile of its XCD's run from sched[xcd] (8 zero-initialised counters)
-  // until the run is exhausted.  The launch then occupies exactly gridDim.x workgroup slots for
-  // its whole duration and leaves the rest of the chip to concurrent latency-bound kernels.
-  int32_t* sched;
 };
 
 // XCD-aware tile order.  The dispatcher places block b on XCD b % 8 (observed, speed only), and
@@ -117,7 +112,7 @@ __host__ __device__ __forceinline__ int gemm_first_tn(int64_t T, int bn, int str
 // whole N = 30k Cholesky, 44 -> 59 TF/s on the predict GEMMs (measured A/B on MI355X).
 // `vbid`: the block index this call stands for (blockIdx.x in the plain kernels; a fused kernel
 // that walks a tile list with fewer workgroups passes its own counter).
-template <int WGM, int WGN, int WTM, int WTN, bool PERSIST, bool PFC = false>
+template <int WGM, int WGN, int WTM, int WTN, bool PFC = false>
 __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid) {
   constexpr int NT = 64 * WGM * WGN;                      // threads: WGM x WGN waves
   constexpr int BM = 16 * WTM * WGM, BN = 16 * WTN * WGN; // block tile; wave tile 16*WTM x 16*WTN
@@ -127,22 +122,11 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
   static_assert(NA >= 1 && NB >= 1 && NA * RA == KT && NB * RB == KT, "staging must tile the k-tile");
   __shared__ double lds[2][KT * (PA + PB)];
 
-  __shared__ int next_tile;
   const int xcd = vbid & 7;
-  for (int round = 0;; ++round) {
   // compact index of this block's tile within its XCD's run, then (tm, tn) by walking the rows
   int tm, tn;
   {
-    int ci;
-    if constexpr (PERSIST) {
-      if (threadIdx.x == 0) next_tile = atomicAdd(&g.sched[xcd], 1);
-      __syncthreads();
-      ci = g.xstart[xcd] + next_tile;
-      __syncthreads();
-    } else {
-      if (round) return;
-      ci = g.xstart[xcd] + (vbid >> 3);
-    }
+    int ci = g.xstart[xcd] + (vbid >> 3);
     if (g.order == 0) {
       if (ci >= g.xstart[xcd + 1]) return;
       if (!g.tri) {
@@ -305,12 +289,11 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
         for (int j = 0; j < WTN; ++j) row[j * 16] = g.beta * c[j] + g.alpha * acc[i][j][r];
       }
   }
-  }  // persistent tile loop
 }
 
-template <int WGM, int WGN, int WTM, int WTN, int OCC, bool PERSIST = false, bool PFC = false>
+template <int WGM, int WGN, int WTM, int WTN, int OCC, bool PFC = false>
 __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs g) {
-  gemm_f64_body<WGM, WGN, WTM, WTN, PERSIST, PFC>(g, blockIdx.x);
+  gemm_f64_body<WGM, WGN, WTM, WTN, PFC>(g, blockIdx.x);
 }
 
 // Batched form: blockIdx.y selects one of several INDEPENDENT products whose descriptors sit in
@@ -320,20 +303,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs 
 template <int WGM, int WGN, int WTM, int WTN, int OCC>
 __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_batched_kernel(const GemmArgs* __restrict__ batch) {
   const GemmArgs g = batch[blockIdx.y];  // uniform address, read before any store: scalar loads
-  gemm_f64_body<WGM, WGN, WTM, WTN, false>(g, blockIdx.x);
+  gemm_f64_body<WGM, WGN, WTM, WTN>(g, blockIdx.x);
 }
 
 // MFMA-only microbenchmark: the GEMM's own register pattern (4 x 4 independent accumulators fed
 // by 4 + 4 operand registers) with no memory traffic -- the f64 matrix rate a kernel of this shape
 // can sustain, i.e. the practical ceiling the roofline is compared with.
-// `skip_xcd` >= 0: workgroups that land on that XCD leave at once (the software XCD partition probe,
-// tools/gpu_xcd_partition_probe.py: MFMA-saturating background load on seven XCDs).
-__global__ __launch_bounds__(256, 2) void mfma_f64_peak_kernel(double* sink, int iters, double scale, int skip_xcd = -1) {
-  if (skip_xcd >= 0) {
-    unsigned int x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    if ((int)(x & 7u) == skip_xcd) return;
-  }
+__global__ __launch_bounds__(256, 2) void mfma_f64_peak_kernel(double* sink, int iters, double scale) {
   d4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)

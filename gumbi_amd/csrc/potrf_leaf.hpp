@@ -79,7 +79,6 @@ struct LeafArgs {
   int32_t* info;    // set to row0 + c + 1 of the first non-positive pivot (0 = ok)
   int64_t row0;     // global index of the block's first row (for info)
   double* dbg;      // optional: 8 wall-clock stamps (100 MHz) at the phase boundaries
-  int32_t xcd_only; // 0 = any; x + 1: the launch has 8 workgroups and only the one on XCD x works
                     // (software XCD partition probe, GMB_PROBE_XCD)
 };
 
@@ -495,11 +494,6 @@ __device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
 // 8 wavefronts: wave 0 carries the dependent diagonal chain, the other seven share the rank-16
 // update tiles and the write-back (3.5 us faster per block than with four).
 __global__ __launch_bounds__(512) void potrf_leaf_kernel(LeafArgs g) {
-  if (g.xcd_only) {
-    unsigned int x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    if ((int)(x & 7u) + 1 != g.xcd_only) return;
-  }
   potrf_leaf_body<8>(g);
 }
 

@@ -94,83 +94,4 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(TrsmArgs g) {
   trsm_strip_slab(g, r0);
 }
 
-// LDS-staged variant: the workgroup first copies the lower block triangle of L_kk into LDS with
-// wide coalesced loads that are all in flight together (one memory latency), together with the
-// sub-block inverses; the 144 MFMA operands of the solve then come from LDS.  The register-only kernel above reads L_kk with 144 eight-byte loads that the compiler
-// keeps ~10 deep, i.e. it pays the L2 latency a dozen times (11.4 us per strip).  Measured: this
-// variant is no faster -- the 92 KB burst itself takes ~4 us, like the leaf's load phase -- so the
-// engine keeps the register-only kernel (GMB_STRIP_LDS=1 selects this one).  Packed layout as in potrf_leaf.hpp: block column t keeps rows 16 t .. 127, pitch 130 - 16 t.
-__host__ __device__ constexpr int strip_off(int t) { return 16 * t * (138 - 8 * t); }
-__host__ __device__ constexpr int strip_pitch(int t) { return 130 - 16 * t; }
-
-__global__ __launch_bounds__(256) void trsm_strip_lds_kernel(TrsmArgs g) {
-  typedef strip_d4 d4;
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  __shared__ double Ls[strip_off(8)];  // 75,776 B
-  __shared__ double Ds[8 * 256];       // 16,384 B  sub-block inverses
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
-  const bool active = r0 < g.nrows;
-  // (1) everything this wavefront needs from global memory, issued before the first use
-  d4 X[8];
-  if (active) trsm_strip_load(g, r0, X);
-  {
-    d2 dbuf[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dbuf[i] = *reinterpret_cast<const d2*>(g.dinv16 + 2 * (tid + 256 * i));
-    d2 buf[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int p = tid + 256 * i;  // pair index: column p / 64, rows 2 (p % 64), +1
-      const int c = p >> 6, r = (p & 63) * 2;
-      if (r >= (c & ~15)) buf[i] = *reinterpret_cast<const d2*>(g.L + r + (int64_t)c * g.ldl);
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int p = tid + 256 * i;
-      const int c = p >> 6, r = (p & 63) * 2;
-      if (r >= (c & ~15)) {
-        d2 v = buf[i];
-        // rows >= nvalid of the block are identity padding: they take no part in the off-diagonal products
-        if (r >= g.nvalid) v[0] = 0.0;
-        if (r + 1 >= g.nvalid) v[1] = 0.0;
-        const int t = c >> 4;
-        const int a = strip_off(t) + (c & 15) * strip_pitch(t) + r - 16 * t;
-        Ls[a] = v[0];
-        Ls[a + 1] = v[1];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(&Ds[2 * (tid + 256 * i)]) = dbuf[i];
-  }
-  __syncthreads();
-  if (!active) return;
-  // (2) blocked forward substitution, operands from LDS / registers
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    d4 y = X[s];
-#pragma unroll
-    for (int t = 0; t < s; ++t) {
-      const double* Lt = &Ls[strip_off(t) + 16 * (s - t) + r16];  // rows 16 s .. of block column t
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const double a = -Lt[(4 * kk + kq) * strip_pitch(t)];
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[t][kk], y, 0, 0, 0);
-      }
-    }
-    d4 x = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      x = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[s * 256 + (4 * kk + kq) * 16 + r16], y[kk], x, 0, 0, 0);
-    X[s] = x;
-  }
-  double* Bp = g.B + r0 + r16;
-#pragma unroll
-  for (int s = 0; s < 8; ++s)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb] = X[s][q];
-}
-
 }  // namespace gmb

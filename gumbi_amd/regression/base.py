@@ -175,7 +175,8 @@ class Regressor(ABC):
             bad = [d for d in levels if d not in dims]
             if bad:
                 raise KeyError(f"Dimensions {bad} specified in *levels not found in *dims")
-            bad = {k: v for k, vs in levels.items() for v in vs if v not in tidy[k].unique()}
+            seen = {k: set(tidy[k].unique().tolist()) for k in levels}
+            bad = {k: v for k, vs in levels.items() for v in vs if v not in seen[k]}
             if bad:
                 raise ValueError(f"Values specified in *levels not found in tidy: {bad}")
             for dim in dims:

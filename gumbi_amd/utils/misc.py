@@ -44,14 +44,19 @@ def assert_in(label, value, allowed):
 
 
 def assert_is_subset(label, subset, superset):
-    """Raise ``ValueError`` unless every element of ``subset`` is found in ``superset``."""
+    """Raise ``ValueError`` unless every element of ``subset`` is found in ``superset``.
+
+    Set membership, as the reference does (``gumbi/utils/misc.py:100-107``): ``specify_model`` calls
+    this with the N observed values of every continuous dimension, so a list scan would be O(N^2)."""
     sub = listify(subset)
     sup = superset
-    if isinstance(sup, np.ndarray):
-        sup = sup.tolist()
-    elif hasattr(sup, "tolist") and not isinstance(sup, (list, tuple, set, dict)):
-        sup = sup.tolist()  # pandas Index / Series
-    sup = listify(sup)
-    missing = [item for item in sub if item not in sup]
+    if hasattr(sup, "tolist") and not isinstance(sup, (list, tuple, set, frozenset, dict)):
+        sup = sup.tolist()  # numpy array / pandas Index / Series -> python scalars
+    try:
+        have = set(sup)
+        missing = [item for item in sub if item not in have]
+    except TypeError:  # unhashable elements: fall back to equality scans
+        sup = listify(sup)
+        missing = [item for item in sub if item not in sup]
     if missing:
         raise ValueError(f"{label} {missing} not found among the allowed values")

@@ -1,0 +1,44 @@
+"""numpy stand-in for ``gumbi_amd.engine.Engine`` built on the CPU oracle.  TEST INFRASTRUCTURE ONLY: the
+tests monkeypatch it into ``gumbi_amd.regression.hip_gp`` / ``icm`` to run the host-side logic (plumbing,
+priors, MAP loop, result wrapping) without a GPU, and to produce reference values the HIP path is compared
+with.  Nothing under ``gumbi_amd/`` imports this."""
+import numpy as np
+
+from oracle import gp_oracle as O
+
+
+class OracleEngine:
+    """numpy stand-in for ``gumbi_amd.engine.Engine`` (test infrastructure only)."""
+
+    def __init__(self, device=0, stream=None):
+        self.X = self.y = self.spec = self.theta = None
+
+    def set_data(self, X, y):
+        self.X, self.y = np.asarray(X, float), np.asarray(y, float)
+
+    def set_kernel(self, spec):
+        self.spec = spec.as_dict()
+
+    def set_theta(self, theta):
+        self.theta = np.asarray(theta, float).copy()
+
+    def factorize(self):
+        O.factorize(self.spec, self.theta, self.X, self.y, dist_mode="direct")  # raises LinAlgError if not PD
+
+    def nlml(self, grad=False):
+        if not grad:
+            return O.nlml(self.spec, self.theta, self.X, self.y, dist_mode="direct")
+        return O.nlml_and_grad(self.spec, self.theta, self.X, self.y, dist_mode="direct")
+
+    def predict(self, Xs, with_noise=True):
+        return O.predict(self.spec, self.theta, self.X, self.y, np.asarray(Xs, float), with_noise=with_noise,
+                         dist_mode="direct")
+
+    def copy_alpha(self):
+        from scipy.linalg import solve_triangular
+
+        L, v = O.factorize(self.spec, self.theta, self.X, self.y, dist_mode="direct")
+        return solve_triangular(L, v, lower=True, trans="T")
+
+    def close(self):
+        pass

@@ -12,7 +12,8 @@ from pathlib import Path
 import numpy as np
 import pandas as pd
 
-from oracle import gp_oracle as O
+from oracle import gp_oracle as O  # noqa: F401
+from oracle_engine import OracleEngine
 
 GOLD = Path(__file__).resolve().parent / "golden"
 
@@ -26,43 +27,6 @@ NB_S2 = np.array([[0.01676639, 1.22016392e-04, 0.00134064, 1.22105406e-05, 2.800
                   [0.00455407, 9.92785623e-05, 0.00110227, 9.91092000e-06, 8.03754540e-05],
                   [0.00462973, 1.04073081e-04, 0.00115023, 1.03548470e-05, 8.16411508e-05],
                   [0.01685376, 1.22594426e-04, 0.00134647, 1.22658105e-05, 2.81471085e-04]])
-
-
-class OracleEngine:
-    """numpy stand-in for ``gumbi_amd.engine.Engine`` (test infrastructure only)."""
-
-    def __init__(self, device=0, stream=None):
-        self.X = self.y = self.spec = self.theta = None
-
-    def set_data(self, X, y):
-        self.X, self.y = np.asarray(X, float), np.asarray(y, float)
-
-    def set_kernel(self, spec):
-        self.spec = spec.as_dict()
-
-    def set_theta(self, theta):
-        self.theta = np.asarray(theta, float).copy()
-
-    def factorize(self):
-        O.factorize(self.spec, self.theta, self.X, self.y, dist_mode="direct")  # raises LinAlgError if not PD
-
-    def nlml(self, grad=False):
-        if not grad:
-            return O.nlml(self.spec, self.theta, self.X, self.y, dist_mode="direct")
-        return O.nlml_and_grad(self.spec, self.theta, self.X, self.y, dist_mode="direct")
-
-    def predict(self, Xs, with_noise=True):
-        return O.predict(self.spec, self.theta, self.X, self.y, np.asarray(Xs, float), with_noise=with_noise,
-                         dist_mode="direct")
-
-    def copy_alpha(self):
-        from scipy.linalg import solve_triangular
-
-        L, v = O.factorize(self.spec, self.theta, self.X, self.y, dist_mode="direct")
-        return solve_triangular(L, v, lower=True, trans="T")
-
-    def close(self):
-        pass
 
 
 def _fit_and_predict(monkeypatch, jacobian, kronecker=False):
