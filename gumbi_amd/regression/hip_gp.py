@@ -27,6 +27,7 @@ confirmed against the predictions printed in the reference's Multioutput_Regress
 
 from __future__ import annotations
 
+import warnings
 from math import lgamma
 
 import numpy as np
@@ -39,6 +40,8 @@ from ..utils.misc import assert_in
 from .base import Regressor
 
 __all__ = ["HipGP"]
+
+_REJECTED = 1e100  # objective value of a rejected step (non-PD covariance); far above any real NLML
 
 
 class HipModel:
@@ -98,6 +101,7 @@ class HipGP(Regressor):
             "n_u": self.n_u,
         }
         self.nlml_trace = []
+        self._rejected = 0
         self._theta_fitted = None
 
     # ------------------------------------------------------------------------------------------
@@ -314,15 +318,25 @@ class HipGP(Regressor):
             eng.set_theta(theta)
             eng.factorize()
             nlml, g_nlml = eng.nlml(grad=True)
-        except (np.linalg.LinAlgError, ValueError):
-            return 1e100, np.zeros_like(u)
+        except np.linalg.LinAlgError:  # covariance not positive definite at this theta: reject the step
+            self._rejected += 1
+            return _REJECTED, np.zeros_like(u)
+        except ValueError as err:
+            # parameters the engine refuses on their VALUE (a length scale or kappa that underflowed to zero,
+            # an overflow to inf) are rejected steps as well; anything else -- call order, packing, shapes --
+            # is a bug and must surface
+            if "must be positive" in str(err) or "not finite" in str(err):
+                self._rejected += 1
+                return _REJECTED, np.zeros_like(u)
+            raise
         lp, g_lp = self._log_prior(theta)
         J = 1.0 if self.map_includes_jacobian else 0.0
         f = nlml - lp - J * np.sum(u[pos])
         g = g_nlml - g_lp
         g = np.where(pos, g * theta - J, g)
         if not np.isfinite(f):
-            return 1e100, np.zeros_like(u)
+            self._rejected += 1
+            return _REJECTED, np.zeros_like(u)
         self.nlml_trace.append(float(nlml))
         return float(f), g
 
@@ -342,6 +356,7 @@ class HipGP(Regressor):
         if start is not None:
             theta0 = self._theta_from_dict(start, theta0)
         self.nlml_trace = []
+        self._rejected = 0
         if theta is not None:
             th = self._theta_from_dict(theta, theta0) if isinstance(theta, dict) else np.asarray(theta, float)
             self.n_eval = 0
@@ -353,6 +368,16 @@ class HipGP(Regressor):
             th = np.where(pos, np.exp(res.x), res.x)
             self.n_eval = int(res.nfev)
             self.opt_result = res
+            # pm.find_MAP reports what the optimiser did; a fit that never left the rejection plateau (every
+            # evaluation non-PD: L-BFGS-B sees a zero gradient and "converges" at the start) or that scipy
+            # flags as failed must not pass silently
+            if res.fun >= _REJECTED or not self.nlml_trace:
+                warnings.warn("find_MAP: no admissible evaluation -- the covariance was not positive definite at "
+                              f"every one of the {self.n_eval} points tried; MAP is the starting point",
+                              RuntimeWarning, stacklevel=2)
+            elif not res.success and res.status != 1:  # status 1 = evaluation budget (maxeval) reached
+                warnings.warn(f"find_MAP: L-BFGS-B stopped without converging ({res.message})", RuntimeWarning,
+                              stacklevel=2)
         # leave the engine factorised at the MAP so predict() reuses the resident factor
         self.engine.set_theta(th)
         self.engine.factorize()

@@ -2,7 +2,10 @@
 
     python tools/pmc_summary.py gpurun_out/pmc profiles/r01_pmc_summary.csv
 
-MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs) (rocprofv3's own formula);
+MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): rocprofv3 reports
+GRBM_GUI_ACTIVE summed over the 8 XCDs, so the per-SIMD busy fraction needs the per-XCD cycle count (the
+round-1 summaries divided by the sum and read 8x low: the register-only MFMA microbenchmark showed 12.25 %
+at 71.8 TF/s; with this normalisation it reads ~98 % of the cycles at the clock the chip actually ran);
 achieved f64 MFMA rate from SQ_INSTS_VALU_MFMA_MOPS_F64 * 512 / duration.  FETCH_SIZE is doubled
 per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for wide coalesced streams);
 WRITE_SIZE is reported as counted (uncalibrated).
@@ -41,7 +44,7 @@ def main(root, out):
         gui = c.get("GRBM_GUI_ACTIVE", 0.0)
         mfma_busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
-        util = 100.0 * mfma_busy / (gui * 1024.0) if gui else 0.0
+        util = 100.0 * mfma_busy / (gui / 8.0 * 1024.0) if gui else 0.0
         tf = mops * 512.0 / (d1[k] * 1e-9) / 1e12 if d1[k] else 0.0
         fetch_gb = 2.0 * p2.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0 / 1e9
         write_gb = p3.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0 / 1e9
