@@ -188,6 +188,10 @@ struct CovTileArgs {
   // Additive models (sum of kernels): passes after the first ADD their term to the real entries and
   // leave padding, y row and the noise diagonal (written by the first pass) alone.
   int32_t accumulate;
+  // One rank's block rows of the lower triangle (multi-GPU K-build, i0 == j0 == 0, lower_only): the grid
+  // enumerates, block row by owned block row row_first, row_first + row_stride, ... (< ti), the tiles
+  // tj = 0 .. min(row, tj - 1).  row_stride == 0: off.
+  int32_t row_first, row_stride;
 };
 
 template <int KIND, int NC>
@@ -203,7 +207,17 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
   // tiles below the diagonal), so contiguous per-XCD runs would leave the last XCDs idle; dealing
   // consecutive tiles round-robin over the XCDs (the hardware's own order) balances them.
   int tjx, tix;
-  if (a.tri_grid) {  // block b -> b-th tile of the lower triangle, column by column
+  if (a.row_stride > 0) {
+    int rem = blockIdx.x;
+    tix = a.row_first;
+    for (;;) {
+      const int cnt = (tix + 1 < a.tj) ? tix + 1 : a.tj;
+      if (rem < cnt) break;
+      rem -= cnt;
+      tix += a.row_stride;
+    }
+    tjx = rem;
+  } else if (a.tri_grid) {  // block b -> b-th tile of the lower triangle, column by column
     int rem = blockIdx.x;
     tjx = 0;
     while (rem >= a.ti - tjx) {

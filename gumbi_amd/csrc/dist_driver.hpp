@@ -1,0 +1,567 @@
+// dist_driver.hpp -- ONE GP over the GPUs of a node: native driver loop of the
+// multi-GPU Cholesky, the row-partitioned NLML gradient and the sharded prediction.  Included at the end of
+// engine.hip (same translation unit: it drives the single-GPU building blocks chol_cols / trsm_cols /
+// launch_gemm / launch_cov on this rank's share).
+//
+// There is no reference counterpart (the reference is single-process); the work replaced is what
+// `pm.find_MAP` / `pm.gp.Marginal.predict` do per evaluation (gumbi/regression/pymc/GP.py:811, 845-847).
+//
+// Partition.  One process per GPU.  128-row blocks of the bordered covariance matrix (row N carries y) are
+// dealt round-robin: rank g of G owns block rows b = g (mod G) -- a 1-D block-cyclic ROW partition, so the
+// long late rows are spread evenly and X (replicated, 8 N d bytes) lets every rank build its rows with no
+// communication.  Every rank keeps a FULL-size factor buffer (80 GB at N = 1e5 of 288 GB) and ends with the
+// complete factor, so prediction shards over the test points with no further exchange.
+//
+// Right-looking over panels [c0, c1) of `w` block columns, ONE collective type (all-gather), two per panel:
+//   SQUARE  the panel's diagonal square is spread over the ranks (block row i belongs to rank i mod G):
+//           all-gather its block rows (w x w blocks, <= a few MB), then EVERY rank factors the square itself
+//           with the single-GPU chain (redundant ~w^3 128^3 / 3 flops, but no broadcast hop, no owner
+//           bottleneck, and log-det / failure index come out identical on all ranks with no reduction);
+//   PANEL   every rank solves ITS block rows below the square against it (packed, trsm_cols) and one
+//           all-gather delivers the finished panel column to all ranks -- the north star's "panel
+//           broadcast": with one sender per block row an all-gather is what drives all 7 xGMI links of
+//           every GPU at once;
+//   UPDATE  the trailing update is purely local: rank g updates its own block rows (strided n index of the
+//           MFMA GEMM) with the panel everybody now holds.
+// Look-ahead: the update by panel p is split into U1 (the columns of panel p+1, main stream) and U2 (the
+// rest, bulk stream = the CU-masked stream when available, so the chain's small kernels and RCCL's
+// workgroups find free compute units); SQUARE / PANEL of p+1 run on the main stream beside U2(p).
+//
+//   main :  SQUARE(0) PANEL(0) | U1(0) SQUARE(1) PANEL(1) | wait U2(0); U1(1) SQUARE(2) PANEL(2) | ...
+//   bulk :                     | U2(0) ........................| U2(1) ..........................| ...
+//
+// The schedule is built as a PLAN first (dist_build_plan: host-only, pure integer arithmetic, exported as
+// gmb_dist_plan) and then executed; the CPU tests replay the same plan with numpy blocks over gloo.
+//
+// Gradient (gmb_dist_nlml): U = L^-T BY ROWS -- rank g solves V <- V L^-T for its block rows of the identity
+// (no communication, ~N^3/(2G) flops with the structural zeros skipped), in column chunks: while chunk j+1
+// is being solved, chunk j travels (all-gather on a second stream) straight into the upper triangle of every
+// rank's factor buffer; then each rank forms ITS block rows of Sigma^-1 = U U^T (packed, in the buffer V
+// occupied) and the fused trace reductions over them; the accumulators are all-gathered and summed in rank
+// order, so every rank holds bit-identical (value, gradient) and an optimiser runs in lock step.
+#pragma once
+#include <dlfcn.h>
+
+#include <rccl/rccl.h>  // types and prototypes only: librccl is resolved at run time with dlopen
+
+namespace {
+
+enum DistOp : int32_t { DIST_KBUILD = 0, DIST_SQUARE = 1, DIST_PANEL = 2, DIST_UPDATE = 3, DIST_FORK = 4, DIST_JOIN = 5 };
+
+// block rows of [lo, hi) owned by `rank`: first + t * G, t < count
+inline void dist_owned(int rank, int G, int lo, int hi, int* first, int* count) {
+  int f = lo + (((rank - lo) % G) + G) % G;
+  *first = f;
+  *count = f < hi ? (hi - f + G - 1) / G : 0;
+}
+inline int dist_max_owned(int G, int lo, int hi) { return hi > lo ? (hi - lo + G - 1) / G : 0; }
+
+int dist_default_panel(int nct) { return std::max(8, ((nct / 16 + 4) / 8) * 8); }
+
+std::vector<gmb_dist_step> dist_build_plan(int64_t N, int rank, int G, int w) {
+  std::vector<gmb_dist_step> plan;
+  const int nct = (int)((N + TILE - 1) / TILE), nrt = (int)((N + 1 + TILE - 1) / TILE);
+  if (w <= 0) w = dist_default_panel(nct);
+  auto push = [&](int op, int c0, int c1, int lo, int hi, int stream) {
+    gmb_dist_step s{};
+    s.op = op;
+    s.c0 = c0;
+    s.c1 = c1;
+    s.lo = lo;
+    s.hi = hi;
+    s.stream = stream;
+    dist_owned(rank, G, lo, hi, &s.first, &s.count);
+    if (op == DIST_UPDATE) dist_owned(rank, G, lo, nrt, &s.first, &s.count);  // rows run to the end
+    s.maxcount = dist_max_owned(G, lo, hi);
+    s.elems = (op == DIST_SQUARE || op == DIST_PANEL) ? (int64_t)s.maxcount * TILE * (int64_t)(c1 - c0) * TILE : 0;
+    plan.push_back(s);
+  };
+  push(DIST_KBUILD, 0, nct, 0, nrt, 0);
+  auto chain = [&](int c0, int c1) {
+    push(DIST_SQUARE, c0, c1, c0, c1, 0);
+    if (nrt > c1) push(DIST_PANEL, c0, c1, c1, nrt, 0);
+  };
+  chain(0, std::min(w, nct));
+  for (int c0 = 0; c0 < nct; c0 += w) {
+    const int c1 = std::min(c0 + w, nct), c2 = std::min(c1 + w, nct);
+    if (c1 >= nct) break;
+    if (c0 > 0) push(DIST_JOIN, 0, 0, 0, 0, 0);        // U2(p-1) has reached panel p+1's columns
+    push(DIST_FORK, 0, 0, 0, 0, 0);                    // bulk: PANEL(p) is complete
+    push(DIST_UPDATE, c0, c1, c1, c2, 0);              // U1(p)
+    if (c2 < nct) push(DIST_UPDATE, c0, c1, c2, nct, 1);  // U2(p)
+    chain(c1, c2);
+  }
+  push(DIST_JOIN, 0, 0, 0, 0, 0);
+  return plan;
+}
+
+int dist_pack(gmb_engine* e, hipStream_t st, double* mat, int64_t ld, double* packed, int64_t ldp, int64_t seg_elems,
+              int ncols, bool to_packed, int nseg, int first, int count, int stride, int lo, int hi, int maxcount) {
+  if (ncols <= 0 || maxcount <= 0) return GMB_OK;
+  PackArgs a{};
+  a.mat = mat;
+  a.ld = ld;
+  a.packed = packed;
+  a.ldp = ldp;
+  a.seg_elems = seg_elems;
+  a.ncols = ncols;
+  a.to_packed = to_packed ? 1 : 0;
+  a.nseg = nseg;
+  a.first = first;
+  a.count = count;
+  a.stride = stride;
+  a.lo = lo;
+  a.hi = hi;
+  if (nseg == 1 && count <= 0) return GMB_OK;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)(nseg == 1 ? count : maxcount), (unsigned)((ncols + 3) / 4), (unsigned)nseg),
+                     dim3(256), 0, st, a);
+  HIP_TRY(e, hipGetLastError());
+  return GMB_OK;
+}
+
+int dist_all_gather(gmb_engine* e, const gmb_comm* comm, hipStream_t st, const double* send, double* recv, int64_t count) {
+  const int32_t rc = comm->all_gather(comm->ctx, send, recv, count, (void*)st);
+  if (rc != 0) return fail(e, GMB_EHIP, "all-gather of %lld doubles failed on rank %d (transport status %d)",
+                           (long long)count, comm->rank, rc);
+  return GMB_OK;
+}
+
+int dist_check_comm(gmb_engine* e, const gmb_comm* comm) {
+  if (!comm || !comm->all_gather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)
+    return fail(e, GMB_EINVAL, "bad communicator");
+  return GMB_OK;
+}
+
+int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  if ((rc = dist_check_comm(e, comm))) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const int G = comm->world, rank = comm->rank;
+  e->factored = false;
+  e->factor_consumed = false;
+  e->notpd = -1;
+  gmb_timings& tm = e->tm;
+  tm.kbuild_ms = tm.chol_ms = tm.chol_gemm_ms = tm.chol_gemm_flops = 0.0;
+  tm.chol_leaf_ms = tm.chol_trsm_ms = 0.0;
+  tm.chol_gemm_launches = 0;
+  HIP_TRY(e, hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream));
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  const std::vector<gmb_dist_step> plan = dist_build_plan(e->N, rank, G, panel_blocks > 0 ? panel_blocks : (e->panel_auto ? 0 : e->panel_blocks));
+  int64_t need = 0;
+  for (const gmb_dist_step& s : plan) need = std::max(need, s.elems);
+  if ((rc = ensure(e, &e->dsend, &e->cap_send, need))) return rc;
+  if ((rc = ensure(e, &e->drecv, &e->cap_recv, need * G))) return rc;
+  hipStream_t mainS = e->stream, bulkS = e->aux[2];
+  e->sync_next = 0;
+  e->cur = mainS;
+  PhaseTimer tk(e);
+  PhaseTimer* tc = nullptr;
+  for (const gmb_dist_step& s : plan) {
+    const int64_t W = (int64_t)(s.c1 - s.c0) * TILE;
+    switch (s.op) {
+      case DIST_KBUILD: {  // this rank's block rows of the lower triangle, y row and padding included
+        CovTileArgs a{};
+        a.p = e->cp;
+        a.rows = train_set(e);
+        a.cols = train_set(e);
+        a.out = e->dA;
+        a.ldo = e->ld;
+        a.ti = nrt;
+        a.tj = nct;
+        a.mode = COV_TRAIN;
+        a.lower_only = 1;
+        a.row_first = rank;
+        a.row_stride = G;
+        a.y = e->dy;
+        if ((rc = launch_cov(e, a))) return rc;
+        for (size_t t = 1; t < e->terms.size(); ++t) {  // additive models: accumulating passes
+          if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[t].pa))) return rc;
+          a.p = e->terms[t].cp;
+          a.accumulate = 1;
+          if ((rc = launch_cov(e, a))) return rc;
+        }
+        if (e->terms.size() > 1 &&
+            (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
+          return rc;
+        tk.stop();
+        tc = new PhaseTimer(e);
+        break;
+      }
+      case DIST_SQUARE: {
+        double* cols = e->dA + (int64_t)s.c0 * TILE * e->ld;  // column block c0 of the factor buffer
+        const int64_t ldp = (int64_t)s.maxcount * TILE;
+        if ((rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, true, 1, s.first, s.count, G, 0, 0, s.maxcount))) break;
+        if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems))) break;
+        if ((rc = dist_pack(e, mainS, cols, e->ld, e->drecv, ldp, s.elems, (int)W, false, G, 0, 0, G, s.lo, s.hi, s.maxcount))) break;
+        e->cur = mainS;
+        rc = chol_cols(e, s.c0, s.c1, s.c1);  // the square only: rows below are PANEL's
+        break;
+      }
+      case DIST_PANEL: {
+        double* cols = e->dA + (int64_t)s.c0 * TILE * e->ld;
+        const int64_t ldp = (int64_t)s.maxcount * TILE;
+        if ((rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, true, 1, s.first, s.count, G, 0, 0, s.maxcount))) break;
+        e->cur = mainS;
+        if (s.count > 0 &&
+            (rc = trsm_cols(e, e->dsend - (int64_t)s.c0 * TILE * ldp, ldp, s.count, s.c0, s.c1, 2, 5)))
+          break;
+        if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems))) break;
+        rc = dist_pack(e, mainS, cols, e->ld, e->drecv, ldp, s.elems, (int)W, false, G, 0, 0, G, s.lo, s.hi, s.maxcount);
+        break;
+      }
+      case DIST_UPDATE: {
+        if (s.count <= 0) break;
+        GemmArgs g{};
+        g.C = e->dA + (int64_t)s.first * TILE + (int64_t)s.lo * TILE * e->ld;
+        g.ldc = e->ld;
+        g.A = e->dA + (int64_t)s.lo * TILE + (int64_t)s.c0 * TILE * e->ld;
+        g.lda = e->ld;
+        g.B = e->dA + (int64_t)s.first * TILE + (int64_t)s.c0 * TILE * e->ld;
+        g.ldb = e->ld;
+        g.mt = s.hi - s.lo;
+        g.nt = s.count;
+        g.k = (int)W;
+        g.alpha = -1.0;
+        g.beta = 1.0;
+        g.tri = 1;
+        g.tri_off = (s.first - s.lo) * TILE;
+        g.nblk_stride = G;
+        e->cur = s.stream ? bulkS : mainS;
+        rc = launch_gemm(e, g, 0);
+        e->cur = mainS;
+        break;
+      }
+      case DIST_FORK: rc = order_after(e, mainS, bulkS); break;
+      case DIST_JOIN: rc = order_after(e, bulkS, mainS); break;
+    }
+    if (rc) {
+      delete tc;
+      return rc;
+    }
+  }
+  // v = L^-1 y is row N of the (now complete, replicated) factor
+  hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv, e->dscal + 1);
+  if (tc) tc->stop();
+  double hs[2];
+  int32_t info = 0;
+  hipError_t st = hipGetLastError();
+  if (st == hipSuccess) st = hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+  if (st == hipSuccess) st = hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
+  if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+  if (st != hipSuccess) {
+    delete tc;
+    return fail(e, GMB_EHIP, "distributed factorisation failed: %s", hipGetErrorString(st));
+  }
+  tm.kbuild_ms = tk.ms();
+  tm.chol_ms = tc ? tc->ms() : 0.0;
+  delete tc;
+  // this rank's share of the K-build bytes
+  tm.kbuild_bytes = (8.0 * (double)e->N * (double)(e->N + 1) / 2.0) / G + 8.0 * (double)e->N * (double)(e->spec.n_cont + 1);
+  ev_collect(e);
+  if (e->profiling) {
+    tm.total_kbuild_ms += tm.kbuild_ms;
+    tm.total_kbuild_bytes += tm.kbuild_bytes;
+    tm.total_kbuild_launches += 1;
+  }
+  // every rank factored every diagonal square itself: log-det and the failure index are already global and
+  // identical on all ranks (same kernels on the same bits) -- no reduction
+  if (info != 0) {
+    e->notpd = (int64_t)info - 1;
+    return fail(e, GMB_ENOTPD, "covariance matrix is not positive definite at row %lld", (long long)e->notpd);
+  }
+  e->logdet = hs[0];
+  e->vnorm2 = hs[1];
+  if (!std::isfinite(e->logdet) || !std::isfinite(e->vnorm2)) {
+    e->notpd = 0;
+    return fail(e, GMB_ENOTPD, "factorisation produced non-finite values");
+  }
+  e->factored = true;
+  return GMB_OK;
+}
+
+// ---- gradient ----------------------------------------------------------------------------------------
+constexpr int DIST_INV_CHUNK = 32;  // block columns of U = L^-T per pipeline stage (4096 columns)
+
+int dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
+  int rc = require_ready(e, true);
+  if (rc) return rc;
+  if ((rc = dist_check_comm(e, comm))) return rc;
+  if (!nlml) return fail(e, GMB_EINVAL, "nlml output pointer is null");
+  *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
+  if (!grad) return GMB_OK;
+  if (e->factor_consumed) return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const int G = comm->world, rank = comm->rank;
+  const int nt = (int)(e->Np / TILE);
+  int first, owned;
+  dist_owned(rank, G, 0, nt, &first, &owned);
+  const int maxown = dist_max_owned(G, 0, nt);
+  const int64_t ldv = (int64_t)maxown * TILE;
+  gmb_timings& tm = e->tm;
+  tm.grad_ms = tm.grad_gemm_ms = tm.grad_gemm_flops = 0.0;
+  // V = this rank's block rows of U (later: of Sigma^-1), (maxown * 128) x Np column-major
+  if ((rc = ensure(e, &e->dW, &e->cap_W, ldv * e->Np))) return rc;
+  if ((rc = grad_workspace(e))) return rc;
+  const int cw = std::min(DIST_INV_CHUNK, nt);
+  const int64_t chunk_elems = (int64_t)maxown * TILE * (int64_t)cw * TILE;
+  const int64_t send_need = std::max<int64_t>(chunk_elems + ldv, GACC_DOUBLES);  // [chunk | this rank's alpha rows]
+  if ((rc = ensure(e, &e->dsend, &e->cap_send, send_need))) return rc;
+  if ((rc = ensure(e, &e->drecv, &e->cap_recv, send_need * G))) return rc;
+  double* V = e->dW;
+  hipStream_t mainS = e->stream, commS = e->aux[0];
+  PhaseTimer tg(e);
+  e->sync_next = 0;
+  e->cur = mainS;
+  e->factor_consumed = true;  // the upper triangle (and the diagonal squares) of the factor buffer become U
+  HIP_TRY(e, hipMemsetAsync(V, 0, (size_t)ldv * e->Np * sizeof(double), mainS));
+  if (owned > 0) hipLaunchKernelGGL(identity_rows_kernel, dim3(owned), dim3(TILE), 0, mainS, V, ldv, first, G);
+  HIP_TRY(e, hipGetLastError());
+  if ((rc = order_after(e, mainS, commS))) return rc;
+  for (int k0 = 0; k0 < nt; k0 += cw) {
+    const int k1 = std::min(k0 + cw, nt);
+    // rows of U with a non-zero in these columns: block rows b < k1, a prefix of the packed rows
+    int f2, mine;
+    dist_owned(rank, G, 0, k1, &f2, &mine);
+    const int mc = dist_max_owned(G, 0, k1);
+    if (mine > 0 && (rc = trsm_cols(e, V, ldv, mine, k0, k1, 4, 6, first, G))) return rc;
+    if ((rc = order_after(e, mainS, commS))) return rc;  // the chunk is final
+    if (mine > 0) {
+      if (k1 < nt) {  // right-looking: V[:, k1:] -= V[:, k0:k1] L[k1:, k0:k1]^T, structural zeros skipped
+        GemmArgs g{};
+        g.C = V + (int64_t)k1 * TILE * ldv;
+        g.ldc = ldv;
+        g.A = e->dA + (int64_t)k1 * TILE + (int64_t)k0 * TILE * e->ld;
+        g.lda = e->ld;
+        g.B = V + (int64_t)k0 * TILE * ldv;
+        g.ldb = ldv;
+        g.mt = nt - k1;
+        g.nt = mine;
+        g.k = (k1 - k0) * TILE;
+        g.alpha = -1.0;
+        g.beta = 1.0;
+        g.klo_n = 1;
+        g.krow_stride = G;
+        g.krow_off = (first - k0) * TILE;
+        if ((rc = launch_gemm(e, g, 4))) return rc;
+      }
+    }
+    // ship the finished chunk while the update above runs (it only READS the chunk, and the unpack writes
+    // rows < k1 of the factor buffer's chunk columns, the update reads rows >= k1 of them): rows b < k1 of
+    // columns [k0, k1) go into the upper triangle of every rank's factor buffer
+    const int ncols = (k1 - k0) * TILE;
+    const int64_t ldp = (int64_t)mc * TILE, elems = ldp * ncols;
+    if ((rc = dist_pack(e, commS, V + (int64_t)k0 * TILE * ldv, ldv, e->dsend, ldp, 0, ncols, true, 1, 0, mine, 1, 0, 0, mc))) return rc;
+    if ((rc = dist_all_gather(e, comm, commS, e->dsend, e->drecv, elems))) return rc;
+    if ((rc = dist_pack(e, commS, e->dA + (int64_t)k0 * TILE * e->ld, e->ld, e->drecv, ldp, elems, ncols, false, G, 0, 0, G, 0, k1, mc))) return rc;
+  }
+  // alpha = U v: this rank's rows, then everybody's
+  if (owned > 0)
+    hipLaunchKernelGGL(urows_v_kernel, dim3(owned * 2), dim3(256), 0, mainS, V, ldv, e->dv, e->N, e->dsend + chunk_elems);
+  HIP_TRY(e, hipGetLastError());
+  if ((rc = order_after(e, mainS, commS))) return rc;
+  {
+    double* a_send = e->dsend + chunk_elems;  // behind the chunk staging area (a chunk may still be in flight)
+    double* a_recv = e->drecv;
+    // the comm stream is strictly ordered: by the time this all-gather runs every chunk has been unpacked
+    if ((rc = dist_all_gather(e, comm, commS, a_send, a_recv, ldv))) return rc;
+    if ((rc = dist_pack(e, commS, e->dalpha, e->Np, a_recv, ldv, ldv, 1, false, G, 0, 0, G, 0, nt, maxown))) return rc;
+  }
+  if ((rc = order_after(e, commS, mainS))) return rc;
+  if (e->Np > e->N)
+    hipLaunchKernelGGL(reset_pad_cols_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, mainS, e->dA, e->ld, e->N, e->Np);
+  HIP_TRY(e, hipGetLastError());
+  // this rank's block rows of Sigma^-1 = U U^T, packed, into the buffer V occupied; reductions over them
+  if ((rc = grad_sigma_inv_rows(e, rank, G, e->dW, ldv, true))) return rc;
+  std::vector<double> h;
+  if ((rc = grad_reduce(e, rank, G, e->dW, ldv, true, h))) return rc;
+  // accumulators of all ranks, summed in rank order on every rank (bit-identical results everywhere)
+  HIP_TRY(e, hipMemcpyAsync(e->dsend, e->dgpart, GACC_DOUBLES * sizeof(double), hipMemcpyDeviceToDevice, mainS));
+  if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, GACC_DOUBLES))) return rc;
+  std::vector<double> all((size_t)G * GACC_DOUBLES);
+  HIP_TRY(e, hipMemcpyAsync(all.data(), e->drecv, all.size() * sizeof(double), hipMemcpyDeviceToHost, mainS));
+  tg.stop();
+  HIP_TRY(e, hipStreamSynchronize(mainS));
+  tm.grad_ms = tg.ms();
+  ev_collect(e);
+  h.assign(GACC_DOUBLES, 0.0);
+  for (int q = 0; q < G; ++q)
+    for (int i = 0; i < GACC_DOUBLES; ++i) h[i] += all[(size_t)q * GACC_DOUBLES + i];
+  return grad_chain_rule(e, h, grad);
+}
+
+// ---- prediction: test points sharded over the ranks, results all-gathered -------------------------------
+int dist_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M, int64_t ldxs, int32_t with_noise,
+                 double* mean, double* var, int32_t memspace) {
+  int rc = require_ready(e, true);
+  if (rc) return rc;
+  if ((rc = dist_check_comm(e, comm))) return rc;
+  if (M < 0 || (M > 0 && (!Xs || !mean || !var)) || ldxs < e->D) return fail(e, GMB_EINVAL, "bad Xs/M/ldxs/mean/var");
+  if (M == 0) return GMB_OK;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const int G = comm->world, rank = comm->rank;
+  auto bound = [&](int q) { return (int64_t)((double)M * q / G); };
+  int64_t width = 0;
+  for (int q = 0; q < G; ++q) width = std::max(width, bound(q + 1) - bound(q));
+  const int64_t lo = bound(rank), cnt = bound(rank + 1) - lo;
+  if ((rc = ensure(e, &e->dsend, &e->cap_send, std::max<int64_t>(2 * width, width * e->D)))) return rc;
+  if ((rc = ensure(e, &e->drecv, &e->cap_recv, std::max<int64_t>(2 * width, width * e->D) * G))) return rc;
+  if (cnt > 0) {
+    const double* xs_dev = Xs + lo * ldxs;
+    int64_t ld_dev = ldxs;
+    if (memspace != GMB_DEVICE) {  // stage this rank's slice (results stay on the device for the all-gather)
+      HIP_TRY(e, hipMemcpy2DAsync(e->drecv, e->D * sizeof(double), Xs + lo * ldxs, ldxs * sizeof(double),
+                                  e->D * sizeof(double), cnt, hipMemcpyHostToDevice, e->stream));
+      xs_dev = e->drecv;
+      ld_dev = e->D;
+    }
+    if ((rc = gmb_predict(e, xs_dev, cnt, ld_dev, with_noise, e->dsend, e->dsend + width, GMB_DEVICE))) return rc;
+  }
+  if ((rc = dist_all_gather(e, comm, e->stream, e->dsend, e->drecv, 2 * width))) return rc;
+  const hipMemcpyKind kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  for (int q = 0; q < G; ++q) {
+    const int64_t lq = bound(q), cq = bound(q + 1) - lq;
+    if (cq <= 0) continue;
+    HIP_TRY(e, hipMemcpyAsync(mean + lq, e->drecv + (int64_t)q * 2 * width, cq * sizeof(double), kind, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(var + lq, e->drecv + (int64_t)q * 2 * width + width, cq * sizeof(double), kind, e->stream));
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return GMB_OK;
+}
+
+// ---- RCCL transport ------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+std::string g_rccl_error;
+
+RcclApi* rccl_api(const char* path) {
+  static std::mutex mu;
+  static RcclApi api;
+  std::lock_guard<std::mutex> lock(mu);
+  if (api.lib) return &api;
+  const char* names[] = {path && path[0] ? path : nullptr, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* n : names)
+    if (n && (lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!lib) {
+    g_rccl_error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+    return nullptr;
+  }
+  RcclApi a;
+  a.lib = lib;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather) {
+    g_rccl_error = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+    return nullptr;
+  }
+  api = a;
+  return &api;
+}
+
+struct RcclCtx {
+  RcclApi* api;
+  ncclComm_t comm;
+};
+
+int32_t rccl_all_gather(void* ctx, const void* send, void* recv, int64_t count, void* stream) {
+  RcclCtx* c = (RcclCtx*)ctx;
+  const ncclResult_t r = c->api->AllGather(send, recv, (size_t)count, ncclFloat64, c->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) {
+    g_rccl_error = std::string("ncclAllGather: ") + (c->api->GetErrorString ? c->api->GetErrorString(r) : "error");
+    return (int32_t)r;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gmb_dist_plan(int64_t N, int32_t rank, int32_t world, int32_t panel_blocks, gmb_dist_step* out, int64_t cap) {
+  if (N < 1 || world < 1 || rank < 0 || rank >= world) return GMB_EINVAL;
+  const std::vector<gmb_dist_step> plan = dist_build_plan(N, rank, world, panel_blocks);
+  if (out)
+    for (int64_t i = 0; i < (int64_t)plan.size() && i < cap; ++i) out[i] = plan[i];
+  return (int64_t)plan.size();
+}
+
+int gmb_dist_factorize(gmb_engine* e, const gmb_comm* comm, int32_t panel_blocks) {
+  if (!e) return GMB_EINVAL;
+  return dist_factorize(e, comm, panel_blocks);
+}
+
+int gmb_dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
+  if (!e) return GMB_EINVAL;
+  return dist_nlml(e, comm, nlml, grad);
+}
+
+int gmb_dist_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M, int64_t ldxs, int32_t with_noise,
+                     double* mean, double* var, int32_t memspace) {
+  if (!e) return GMB_EINVAL;
+  return dist_predict(e, comm, Xs, M, ldxs, with_noise, mean, var, memspace);
+}
+
+const char* gmb_rccl_last_error(void) { return g_rccl_error.c_str(); }
+
+int gmb_rccl_unique_id(const char* librccl_path, void* id128) {
+  if (!id128) return GMB_EINVAL;
+  RcclApi* api = rccl_api(librccl_path);
+  if (!api) return GMB_EHIP;
+  ncclUniqueId id;
+  const ncclResult_t r = api->GetUniqueId(&id);
+  if (r != ncclSuccess) {
+    g_rccl_error = std::string("ncclGetUniqueId: ") + (api->GetErrorString ? api->GetErrorString(r) : "error");
+    return GMB_EHIP;
+  }
+  static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+  std::memcpy(id128, &id, sizeof id);
+  return GMB_OK;
+}
+
+int gmb_rccl_comm_create(gmb_comm** out, const char* librccl_path, const void* id128, int32_t rank, int32_t world,
+                         int32_t device) {
+  if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return GMB_EINVAL;
+  *out = nullptr;
+  RcclApi* api = rccl_api(librccl_path);
+  if (!api) return GMB_EHIP;
+  if (hipSetDevice(device) != hipSuccess) return GMB_EHIP;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof id);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = api->CommInitRank(&comm, world, id, rank);
+  if (r != ncclSuccess) {
+    g_rccl_error = std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "error");
+    return GMB_EHIP;
+  }
+  gmb_comm* c = new gmb_comm();
+  c->rank = rank;
+  c->world = world;
+  c->ctx = new RcclCtx{api, comm};
+  c->all_gather = rccl_all_gather;
+  *out = c;
+  return GMB_OK;
+}
+
+void gmb_rccl_comm_destroy(gmb_comm* c) {
+  if (!c) return;
+  RcclCtx* ctx = (RcclCtx*)c->ctx;
+  if (ctx) {
+    if (ctx->comm) (void)ctx->api->CommDestroy(ctx->comm);
+    delete ctx;
+  }
+  delete c;
+}
+
+}  // extern "C"

@@ -162,6 +162,10 @@ struct gmb_engine {
   bool par_inverse = true;
   bool aux_shared = false;  // aux[2] is the process-wide masked stream (not ours to destroy)
   int part_cus = 0;         // compute units the masked stream leaves free
+  // multi-GPU driver (dist_driver.hpp): packed send / receive staging of the all-gathers
+  double* dsend = nullptr;
+  double* drecv = nullptr;
+  int64_t cap_send = 0, cap_recv = 0;
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
 };
@@ -448,7 +452,11 @@ int launch_leaf(gmb_engine* e, const LeafArgs& a) {
 template <int KIND>
 int launch_cov_nc(gmb_engine* e, const CovTileArgs& a, int nc) {
   long long nb = (long long)a.ti * a.tj;
-  if (a.tri_grid) {
+  if (a.row_stride > 0) {
+    nb = 0;
+    for (int i = a.row_first; i < a.ti; i += a.row_stride) nb += std::min(i + 1, a.tj);
+    if (nb == 0) return GMB_OK;
+  } else if (a.tri_grid) {
     nb = 0;
     for (int j = 0; j < a.tj; ++j) nb += std::max(0, a.ti - j);
   }
@@ -1103,84 +1111,52 @@ int launch_grad_nc(gmb_engine* e, const GradArgs& a, int nblocks) {
 constexpr int GACC_REGION = 64 + MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS + 64;  // accumulators of one term
 constexpr int GACC_DOUBLES = (1 + GMB_MAX_COREG) * GACC_REGION;  // additive models: one region per term
 
-// Device part of the gradient: inverse, alpha, Sigma^-1 and the trace reductions over the block
-// rows shard, shard + nshards, ... of the lower triangle; `h` receives the raw accumulators (they
-// are sums over tiles, so shards of several GPUs add up).
-int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& h, bool external_u = false) {
-  HIP_TRY(e, hipSetDevice(e->device));
-  if (e->factor_consumed)
-    return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
-  const gmb_kernel_spec& s = e->spec;
+// ---- gradient building blocks ---------------------------------------------------------------------
+// (a) grad_sigma_inv_rows: block rows shard, shard + nshards, ... of Sigma^-1 = U U^T (lower triangle) from
+//     U = L^-T in the upper triangle of the factor buffer, into Z -- the full Np x Np matrix (packed = false:
+//     rows at their global position, ldz = Np) or ONLY the owned rows, packed (multi-GPU: ldz = owned * 128);
+// (b) grad_reduce: the fused trace reductions over those rows, one pass per covariance term (additive models
+//     have several); term t accumulates into region t of dgpart: [ls.. | eta | tau | c.. ] at 0, its tables
+//     from 64.  `h` receives the raw accumulators: plain sums over tiles, so shards of several GPUs add up.
+int grad_workspace(gmb_engine* e) {
   int rc;
-  gmb_timings& tm = e->tm;
-  tm.grad_ms = tm.grad_gemm_ms = tm.grad_gemm_flops = 0.0;
-  if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
   if (e->cap_pts_alpha < e->Np) {
     if ((rc = alloc(e, &e->dalpha, e->Np))) return rc;
     e->cap_pts_alpha = e->Np;
   }
   if (!e->dgpart && (rc = alloc(e, &e->dgpart, (int64_t)GACC_DOUBLES))) return rc;
-  PhaseTimer tg(e);
+  return GMB_OK;
+}
+
+int grad_sigma_inv_rows(gmb_engine* e, int shard, int nshards, double* Z, int64_t ldz, bool packed) {
   const int nt = (int)(e->Np / TILE);
-  // external_u: the caller (multi-GPU driver) has already put U = L^-T into the upper triangle of
-  // the factor buffer and alpha into dalpha (gmb_inv_rows on every rank + all-gather)
-  // 0. inverses of all diagonal factor blocks, one workgroup each (kept off the Cholesky's chain)
-  if (!external_u) {
-    InvArgs ia;
-    ia.L = e->dA;
-    ia.lda = e->ld;
-    ia.blk_stride = (int64_t)TILE * (e->ld + 1);
-    ia.dinv16 = e->dDinv16;
-    ia.invL = nullptr;
-    ia.n = e->N;
-    ia.W = e->dW;
-    ia.ldw = e->Np;
-    ia.U = e->dA;
-    ia.ldu = e->ld;
-    hipLaunchKernelGGL(leaf_invert_kernel, dim3(nt), dim3(256), 0, e->stream, ia);
-    HIP_TRY(e, hipGetLastError());
-  }
-  // 1. W = L^-1 (dW, lower) and U = L^-T (factor buffer, upper); the factor is consumed from here on
-  e->factor_consumed = true;
-  e->sync_next = 0;
-  if (!external_u) {
-    if (e->par_inverse) {
-      if ((rc = winv_levels(e, nt))) return rc;
-    } else if ((rc = winv_cols(e, 0, nt))) {
-      return rc;
-    }
-    // 2. alpha = W^T v = Sigma^-1 y   (before Sigma^-1 overwrites W)
-    hipLaunchKernelGGL(wt_v_kernel, dim3((unsigned)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->dW, e->Np,
-                       e->dv, e->N, e->dalpha);
-  }
-  if (e->Np > e->N)
-    hipLaunchKernelGGL(reset_pad_cols_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, e->stream,
-                       e->dA, e->ld, e->N, e->Np);
-  HIP_TRY(e, hipGetLastError());
-  // 3. Sigma^-1 = U U^T (lower triangle) into dW
-  {
-    const int owned = shard < nt ? (nt - shard + nshards - 1) / nshards : 0;
-    GemmArgs g{};
-    g.C = e->dW + (int64_t)shard * TILE;
-    g.ldc = e->Np;
-    g.A = e->dA;
-    g.lda = e->ld;
-    g.B = e->dA + (int64_t)shard * TILE;
-    g.ldb = e->ld;
-    g.mt = nt;
-    g.nt = owned;
-    g.k = (int)e->Np;
-    g.klo_n = 1;
-    g.krow_off = shard * TILE;
-    g.tri = 1;
-    g.tri_off = shard * TILE;
-    g.nblk_stride = nshards;
-    g.alpha = 1.0;
-    g.beta = 0.0;
-    if ((rc = launch_gemm(e, g, 4))) return rc;
-  }
-  // 4. fused trace reductions, one pass per covariance term (additive models have several); term
-  //    t accumulates into region t of dgpart: [ls.. | eta | tau | c.. ] at 0, its tables from 64
+  const int owned = shard < nt ? (nt - shard + nshards - 1) / nshards : 0;
+  GemmArgs g{};
+  g.C = packed ? Z : Z + (int64_t)shard * TILE;
+  g.ldc = ldz;
+  g.A = e->dA;
+  g.lda = e->ld;
+  g.B = e->dA + (int64_t)shard * TILE;
+  g.ldb = e->ld;
+  g.mt = nt;
+  g.nt = owned;
+  g.k = (int)e->Np;
+  g.klo_n = 1;
+  g.krow_off = shard * TILE;
+  g.tri = 1;
+  g.tri_off = shard * TILE;
+  g.nblk_stride = nshards;
+  g.cblk_stride = packed ? 1 : 0;
+  g.alpha = 1.0;
+  g.beta = 0.0;
+  return launch_gemm(e, g, 4);
+}
+
+int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t ldz, bool packed,
+                std::vector<double>& h) {
+  const gmb_kernel_spec& s = e->spec;
+  const int nt = (int)(e->Np / TILE);
+  int rc;
   HIP_TRY(e, hipMemsetAsync(e->dgpart, 0, GACC_DOUBLES * sizeof(double), e->stream));
   const int n_ls = s.ard ? s.n_cont : 1;
   int nblocks = 0;
@@ -1191,8 +1167,9 @@ int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& 
     GradArgs a{};
     a.p = tr.cp;
     a.pts = train_set(e);
-    a.Z = e->dW;
-    a.ldz = e->Np;
+    a.Z = Z;
+    a.ldz = ldz;
+    a.z_packed = packed ? 1 : 0;
     a.alpha = e->dalpha;
     a.tiles = nt;
     a.ard = s.ard;
@@ -1217,18 +1194,68 @@ int grad_accumulate(gmb_engine* e, int shard, int nshards, std::vector<double>& 
     if (rc) return rc;
     if (t == 0) {  // diagonal terms (sigma, noise table) with the global term's categories in place
       const double sigma = e->theta[n_ls + 1];
-      hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, e->dW, e->Np, e->dalpha,
-                         train_set(e), tr.cp, sigma, e->dgpart + off, shard, nshards);
+      hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, Z, ldz, e->dalpha, train_set(e),
+                         tr.cp, sigma, e->dgpart + off, shard, nshards, packed ? 1 : 0);
       HIP_TRY(e, hipGetLastError());
     }
   }
   if (e->terms.size() > 1 &&
       (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
     return rc;
-  tg.stop();
   h.assign(GACC_DOUBLES, 0.0);
   HIP_TRY(e, hipMemcpyAsync(h.data(), e->dgpart, GACC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
                             e->stream));
+  return GMB_OK;
+}
+
+// Single-GPU gradient: W = L^-1 and U = L^-T by recursive block inversion, alpha = W^T v, Sigma^-1 = U U^T
+// into dW, reductions.  The factor is consumed.
+int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (e->factor_consumed)
+    return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
+  int rc;
+  gmb_timings& tm = e->tm;
+  tm.grad_ms = tm.grad_gemm_ms = tm.grad_gemm_flops = 0.0;
+  if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
+  if ((rc = grad_workspace(e))) return rc;
+  PhaseTimer tg(e);
+  const int nt = (int)(e->Np / TILE);
+  // 0. inverses of all diagonal factor blocks, one workgroup each (kept off the Cholesky's chain)
+  {
+    InvArgs ia;
+    ia.L = e->dA;
+    ia.lda = e->ld;
+    ia.blk_stride = (int64_t)TILE * (e->ld + 1);
+    ia.dinv16 = e->dDinv16;
+    ia.invL = nullptr;
+    ia.n = e->N;
+    ia.W = e->dW;
+    ia.ldw = e->Np;
+    ia.U = e->dA;
+    ia.ldu = e->ld;
+    hipLaunchKernelGGL(leaf_invert_kernel, dim3(nt), dim3(256), 0, e->stream, ia);
+    HIP_TRY(e, hipGetLastError());
+  }
+  // 1. W = L^-1 (dW, lower) and U = L^-T (factor buffer, upper); the factor is consumed from here on
+  e->factor_consumed = true;
+  e->sync_next = 0;
+  if (e->par_inverse) {
+    if ((rc = winv_levels(e, nt))) return rc;
+  } else if ((rc = winv_cols(e, 0, nt))) {
+    return rc;
+  }
+  // 2. alpha = W^T v = Sigma^-1 y   (before Sigma^-1 overwrites W)
+  hipLaunchKernelGGL(wt_v_kernel, dim3((unsigned)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->dW, e->Np,
+                     e->dv, e->N, e->dalpha);
+  if (e->Np > e->N)
+    hipLaunchKernelGGL(reset_pad_cols_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, e->stream,
+                       e->dA, e->ld, e->N, e->Np);
+  HIP_TRY(e, hipGetLastError());
+  // 3. Sigma^-1 = U U^T (lower triangle) into dW;  4. fused trace reductions
+  if ((rc = grad_sigma_inv_rows(e, 0, 1, e->dW, e->Np, false))) return rc;
+  if ((rc = grad_reduce(e, 0, 1, e->dW, e->Np, false, h))) return rc;
+  tg.stop();
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   tm.grad_ms = tg.ms();
   ev_collect(e);
@@ -1471,7 +1498,7 @@ void gmb_destroy(gmb_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (int a = 0; a < 3; ++a)
     if (e->aux[a]) (void)hipStreamSynchronize(e->aux[a]);
-  void* ptrs[] = {e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
+  void* ptrs[] = {e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv, e->dV, e->dXs, e->txs, e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart};
   for (void* p : ptrs)
@@ -1703,82 +1730,10 @@ int gmb_nlml(gmb_engine* e, double* nlml, double* grad) {
   *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
   if (grad) {
     std::vector<double> h;
-    if ((rc = grad_accumulate(e, 0, 1, h))) return rc;
+    if ((rc = grad_accumulate(e, h))) return rc;
     return grad_chain_rule(e, h, grad);
   }
   return GMB_OK;
-}
-
-int32_t gmb_grad_acc_size(void) { return (int32_t)GACC_DOUBLES; }
-
-int gmb_nlml_shard(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc) {
-  int rc = require_ready(e, true);
-  if (rc) return rc;
-  if (!acc || nacc < (int32_t)GACC_DOUBLES || nshards < 1 || shard < 0 || shard >= nshards)
-    return fail(e, GMB_EINVAL, "bad gradient shard arguments");
-  std::vector<double> h;
-  if ((rc = grad_accumulate(e, shard, nshards, h))) return rc;
-  std::memcpy(acc, h.data(), GACC_DOUBLES * sizeof(double));
-  return GMB_OK;
-}
-
-// Block rows first, first + stride, ... of U = L^-T into V (device; V[t*128 + i + c*ldv], c < Np):
-// the predict solve V <- V L^-T applied to the matching rows of the identity, and this rank's
-// share alpha_i = sum_k U[i][k] v[k] of alpha = Sigma^-1 y.
-int gmb_inv_rows(gmb_engine* e, int32_t first, int32_t stride, double* V, int64_t ldv, double* alpha_rows) {
-  int rc = require_ready(e, true);
-  if (rc) return rc;
-  const int nt = (int)(e->Np / TILE);
-  if (!V || !alpha_rows || stride < 1 || first < 0 || first >= stride) return fail(e, GMB_EINVAL, "bad inverse-rows arguments");
-  const int owned = first < nt ? (nt - first + stride - 1) / stride : 0;
-  if (ldv < (int64_t)owned * TILE) return fail(e, GMB_EINVAL, "ldv too small for the owned rows");
-  if (owned == 0) return GMB_OK;
-  if (e->factor_consumed) return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
-  HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipMemsetAsync(V, 0, (size_t)ldv * e->Np * sizeof(double), e->stream));
-  hipLaunchKernelGGL(identity_rows_kernel, dim3(owned), dim3(TILE), 0, e->stream, V, ldv, first, stride);
-  HIP_TRY(e, hipGetLastError());
-  e->cur = e->stream;
-  if ((rc = trsm_cols(e, V, ldv, owned, 0, nt, 4, 6, first, stride))) return rc;
-  hipLaunchKernelGGL(urows_v_kernel, dim3(owned * 2), dim3(256), 0, e->stream, V, ldv, e->dv, e->N, alpha_rows);
-  HIP_TRY(e, hipGetLastError());
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  ev_collect(e);
-  return GMB_OK;
-}
-
-// Where the multi-GPU driver assembles U (upper triangle of the factor buffer, leading dimension ld)
-// and alpha (Np doubles) before gmb_nlml_shard_u.
-int gmb_grad_buffers(gmb_engine* e, void** alpha) {
-  int rc = require_ready(e, false);
-  if (rc) return rc;
-  HIP_TRY(e, hipSetDevice(e->device));
-  if (e->cap_pts_alpha < e->Np) {
-    if ((rc = alloc(e, &e->dalpha, e->Np))) return rc;
-    e->cap_pts_alpha = e->Np;
-  }
-  if (alpha) *alpha = e->dalpha;
-  return GMB_OK;
-}
-
-int gmb_nlml_shard_u(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc) {
-  int rc = require_ready(e, true);
-  if (rc) return rc;
-  if (!acc || nacc < (int32_t)GACC_DOUBLES || nshards < 1 || shard < 0 || shard >= nshards)
-    return fail(e, GMB_EINVAL, "bad gradient shard arguments");
-  std::vector<double> h;
-  if ((rc = grad_accumulate(e, shard, nshards, h, true))) return rc;
-  std::memcpy(acc, h.data(), GACC_DOUBLES * sizeof(double));
-  return GMB_OK;
-}
-
-int gmb_nlml_from_acc(gmb_engine* e, const double* acc, int32_t nacc, double* nlml, double* grad) {
-  int rc = require_ready(e, false);
-  if (rc) return rc;
-  if (!acc || !nlml || !grad || nacc < (int32_t)GACC_DOUBLES) return fail(e, GMB_EINVAL, "bad accumulator arguments");
-  *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
-  std::vector<double> h(acc, acc + GACC_DOUBLES);
-  return grad_chain_rule(e, h, grad);
 }
 
 int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_t with_noise,
@@ -2077,137 +2032,6 @@ int gmb_blk_gemm_nt(gmb_engine* e, double* C, int64_t ldc, const double* A, int6
   return launch_gemm(e, g, 0);
 }
 
-int gmb_blk_gemm_strided(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                         int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, int32_t tri,
-                         int64_t tri_off, int32_t nblk_stride) {
-  if (!e || !C || !A || !B) return fail(e, GMB_EINVAL, "null gemm operand");
-  if (m % TILE || n % TILE || k % KT || m < 0 || n < 0 || k < 0 || nblk_stride < 1)
-    return fail(e, GMB_EINVAL, "gemm sizes must be multiples of 128 (m, n) and 16 (k)");
-  HIP_TRY(e, hipSetDevice(e->device));
-  GemmArgs g{};
-  g.C = C;
-  g.ldc = ldc;
-  g.A = A;
-  g.lda = lda;
-  g.B = B;
-  g.ldb = ldb;
-  g.mt = (int)(m / TILE);
-  g.nt = (int)(n / TILE);
-  g.k = (int)k;
-  g.alpha = alpha;
-  g.beta = beta;
-  g.tri = tri;
-  g.tri_off = (int)tri_off;
-  g.nblk_stride = nblk_stride;
-  return launch_gemm(e, g, 0);
-}
-
-int gmb_blk_pack(gmb_engine* e, double* mat, int64_t ld, int64_t stride_blocks, int32_t count, double* packed,
-                 int64_t ldp, int32_t to_packed) {
-  if (!e || !mat || !packed || count < 0 || stride_blocks < 1 || ldp < (int64_t)count * TILE)
-    return fail(e, GMB_EINVAL, "bad pack arguments");
-  if (count == 0) return GMB_OK;
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipLaunchKernelGGL(pack_blocks_kernel, dim3(count, TILE / 2), dim3(256), 0, e->stream, mat, ld, stride_blocks,
-                     count, packed, ldp, to_packed);
-  HIP_TRY(e, hipGetLastError());
-  return GMB_OK;
-}
-
-int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_t* Np, void** dinv16, void** scal,
-                       void** info) {
-  int rc = require_ready(e, false);
-  if (rc) return rc;
-  if (A) *A = e->dA;
-  if (ld) *ld = e->ld;
-  if (Nr) *Nr = e->Nr;
-  if (Np) *Np = e->Np;
-  if (dinv16) *dinv16 = e->dDinv16;
-  if (scal) *scal = e->dscal;
-  if (info) *info = e->dinfo;
-  return GMB_OK;
-}
-
-int gmb_local_logdet_info(gmb_engine* e, double* logdet, int64_t* info) {
-  int rc = require_ready(e, false);
-  if (rc) return rc;
-  if (!logdet || !info) return fail(e, GMB_EINVAL, "null output");
-  HIP_TRY(e, hipSetDevice(e->device));
-  int32_t i32 = 0;
-  HIP_TRY(e, hipMemcpyAsync(logdet, e->dscal, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(&i32, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  *info = i32;
-  return GMB_OK;
-}
-
-int gmb_begin_external_factorization(gmb_engine* e) {
-  int rc = require_ready(e, false);
-  if (rc) return rc;
-  HIP_TRY(e, hipSetDevice(e->device));
-  e->factored = false;
-  e->factor_consumed = false;
-  e->notpd = -1;
-  HIP_TRY(e, hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream));
-  HIP_TRY(e, hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream));
-  return GMB_OK;
-}
-
-int gmb_finish_external_factorization(gmb_engine* e, double logdet, int64_t info) {
-  int rc = require_ready(e, false);
-  if (rc) return rc;
-  HIP_TRY(e, hipSetDevice(e->device));
-  if (info != 0) {
-    e->notpd = info - 1;
-    return fail(e, GMB_ENOTPD, "covariance matrix is not positive definite at row %lld", (long long)e->notpd);
-  }
-  HIP_TRY(e, hipMemsetAsync(e->dscal + 1, 0, sizeof(double), e->stream));
-  hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
-                     e->dscal + 1);
-  HIP_TRY(e, hipGetLastError());
-  double vn = 0.0;
-  HIP_TRY(e, hipMemcpyAsync(&vn, e->dscal + 1, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  ev_collect(e);
-  e->logdet = logdet;
-  e->vnorm2 = vn;
-  if (!std::isfinite(logdet) || !std::isfinite(vn)) {
-    e->notpd = 0;
-    return fail(e, GMB_ENOTPD, "factorisation produced non-finite values");
-  }
-  e->factored = true;
-  return GMB_OK;
-}
-
-int gmb_blk_kbuild(gmb_engine* e, double* out, int64_t ldo, int64_t i0, int64_t ni, int64_t j0, int64_t nj) {
-  int rc = require_ready(e, false);
-  if (rc) return rc;
-  if (!out || i0 % TILE || j0 % TILE || ni % TILE || nj % TILE || i0 < 0 || j0 < 0 || i0 + ni > e->Nr ||
-      j0 + nj > e->Np || ldo < ni)
-    return fail(e, GMB_EINVAL, "kbuild window must be 128-aligned and inside the padded matrix");
-  HIP_TRY(e, hipSetDevice(e->device));
-  CovTileArgs a{};
-  a.p = e->cp;
-  a.rows = train_set(e);
-  a.cols = train_set(e);
-  a.out = out;
-  a.ldo = ldo;
-  a.i0 = i0;
-  a.j0 = j0;
-  a.ti = (int)(ni / TILE);
-  a.tj = (int)(nj / TILE);
-  a.mode = COV_TRAIN;
-  a.lower_only = 1;
-  a.y = e->dy;
-  if ((rc = launch_cov(e, a))) return rc;
-  for (size_t t = 1; t < e->terms.size(); ++t) {  // additive models: accumulating passes
-    if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[t].pa))) return rc;
-    a.p = e->terms[t].cp;
-    a.accumulate = 1;
-    if ((rc = launch_cov(e, a))) return rc;
-  }
-  if (e->terms.size() > 1) return prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa);
-  return GMB_OK;
-}
-
 }  // extern "C"
+
+#include "dist_driver.hpp"

@@ -57,6 +57,10 @@ struct GemmArgs {
   // memory (1 = contiguous).  This is how one rank of the block-cyclic row partition updates
   // only the block rows it owns: noff(tn) = ((tn*BN)/128)*nblk_stride*128 + (tn*BN)%128.
   int32_t nblk_stride;
+  // block stride of the n index in C when it differs from the one in B (0 = the same): one rank's block
+  // rows of Sigma^-1 = U U^T read the strided rows of U out of the full-size factor buffer and write a
+  // PACKED result (cblk_stride = 1)
+  int32_t cblk_stride;
   // per-tile contraction range: k_lo = klo_m*tm*BM + klo_n*R(tn), k_hi = khi_n ? min(k, R(tn)+BN) : k,
   // R(tn) = noff(tn) + krow_off = the tile's first row in the coordinates of the contraction index
   // (krow_off = 0 and noff = tn*BN for a contiguous n range; a rank of the block-cyclic partition
@@ -206,7 +210,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
   const bool prefetch_c = PREFETCH_C && g.beta != 0.0;
   if constexpr (PREFETCH_C) {
     if (prefetch_c) {
-      const double* __restrict__ Cp = g.C + noff + wn * (16 * WTN) + r16;
+      const double* __restrict__ Cp = g.C + (g.cblk_stride > 0 ? gemm_noff(tn, BN, g.cblk_stride) : noff) + wn * (16 * WTN) + r16;
       const int64_t mp = (int64_t)tm * BM + wm * (16 * WTM) + kq;
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
@@ -262,7 +266,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
   }
 
   // epilogue.  v_mfma_f64_16x16x4_f64 D layout: n = lane & 15, m = (lane >> 4) + 4 * reg.
-  double* __restrict__ Cg = g.C + noff + wn * (16 * WTN) + r16;
+  double* __restrict__ Cg = g.C + (g.cblk_stride > 0 ? gemm_noff(tn, BN, g.cblk_stride) : noff) + wn * (16 * WTN) + r16;
   const int64_t m0 = (int64_t)tm * BM + wm * (16 * WTM) + kq;
   if (g.beta == 0.0) {
 #pragma unroll

@@ -39,6 +39,8 @@ struct GradArgs {
   // shard of the lower triangle this launch reduces: block rows row_first, row_first + row_stride, ...
   // (0, 1 = everything; a rank of the multi-GPU gradient passes (rank, world))
   int32_t row_first, row_stride;
+  // z_packed: Z holds ONLY the owned block rows, packed (row block t of Z = block row row_first + t*row_stride)
+  int32_t z_packed;
 };
 
 constexpr int GRAD_MAX_LDS_ACC = 16 + 2 + MAX_LIN + MAX_TABS * 64;  // tables up to 8 levels in LDS
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
   for (int k = 0; k < NC; ++k) g_ls[k] = 0.0;
   double g_eta = 0.0, g_tau = 0.0;
 
-  const double* zp = a.Z + gi + (gj0 + jh * (TILE / 2)) * a.ldz;
+  const int64_t zrow = a.z_packed ? (int64_t)((tix - a.row_first) / a.row_stride) * TILE + il : gi;
+  const double* zp = a.Z + zrow + (gj0 + jh * (TILE / 2)) * a.ldz;
   // Fast path (almost every tile): stationary term only, tile strictly below the diagonal, every
   // row and column real -- each entry stands for (i,j) and (j,i), no per-entry conditionals.
   const bool fast = p.n_lin == 0 && p.n_tab == 0 && tix > tjx && gi0 + TILE <= a.pts.n && gj0 + TILE <= a.pts.n;
@@ -223,13 +226,14 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
 __global__ __launch_bounds__(256) void grad_diag_kernel(const double* Z, int64_t ldz,
                                                         const double* alpha, PointSet pts,
                                                         CovParams p, double sigma, double* out, int row_first,
-                                                        int row_stride) {
+                                                        int row_stride, int z_packed = 0) {
   __shared__ double red[4];
   double gs = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pts.n; i += (int64_t)gridDim.x * 256) {
     if ((int)((i >> 7) % row_stride) != row_first) continue;  // block rows of this shard only
     const double a = alpha[i];
-    const double m = 0.5 * (Z[i + i * ldz] - a * a);
+    const int64_t zr = z_packed ? (((i >> 7) - row_first) / row_stride) * TILE + (i & 127) : i;
+    const double m = 0.5 * (Z[zr + i * ldz] - a * a);
     double mult = 1.0;
     if (p.noise_tab >= 0) {
       const int c = pts.cat[(int64_t)p.noise_tab * pts.npad + i];
@@ -317,23 +321,44 @@ __global__ void reset_pad_cols_kernel(double* U, int64_t ld, int64_t n, int64_t 
   for (int64_t k = n; k < npad; ++k) U[i + k * ld] = (i == k) ? 1.0 : 0.0;
 }
 
-// Gather / scatter `count` 128 x 128 blocks between a strided set of block rows of a column-major
-// matrix (rows first_row + t*stride_blocks*128, 128 columns starting at `mat`) and a packed
-// (count*128) x 128 column-major buffer.  Used around the panel all-gather of the multi-GPU
-// Cholesky (each rank owns every G-th block row).
-__global__ __launch_bounds__(256) void pack_blocks_kernel(const double* __restrict__ mat, int64_t ld,
-                                                          int64_t stride_blocks, int count,
-                                                          double* __restrict__ packed, int64_t ldp,
-                                                          int to_packed) {
-  const int t = blockIdx.x;                // block index
-  const int c = blockIdx.y * 2 + (threadIdx.x >> 7);  // column 0..127 (2 per workgroup)
-  const int r = threadIdx.x & 127;
-  const int64_t mi = (int64_t)t * stride_blocks * 128 + r + (int64_t)c * ld;
-  const int64_t pi = (int64_t)t * 128 + r + (int64_t)c * ldp;
-  if (t < count) {
-    if (to_packed) packed[pi] = mat[mi];
-    else const_cast<double*>(mat)[mi] = packed[pi];
+// Gather (to_packed) / scatter block rows between a column-major matrix and a packed buffer -- the send and
+// receive sides of the all-gathers of the multi-GPU path (dist_driver.hpp), where rank q owns the block rows
+// b = q (mod G):
+//   packed[seg*seg_elems + (t*128 + r) + c*ldp]  <->  mat[(first(seg) + t*stride)*128 + r + c*ld],
+//   t < count(seg), r < 128, c < ncols.
+// One segment (nseg = 1: this rank packing its own rows; first / count given) or, for the receive side,
+// nseg = G segments in one launch: segment q holds the block rows of [lo, hi) that rank q owns, i.e.
+// first(q) = lo + ((q - lo) mod G), count(q) = ceil((hi - first(q)) / G).  16 bytes per lane.
+struct PackArgs {
+  double* mat;
+  int64_t ld;
+  double* packed;
+  int64_t ldp;        // leading dimension of one packed segment (rows)
+  int64_t seg_elems;  // doubles between consecutive segments
+  int32_t ncols;
+  int32_t to_packed;
+  int32_t nseg;       // 1: (first, count) below; > 1: per-rank ownership of [lo, hi)
+  int32_t first, count, stride;
+  int32_t lo, hi;
+};
+__global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
+  const int seg = blockIdx.z;
+  int first = a.first, count = a.count;
+  if (a.nseg > 1) {
+    const int G = a.stride;
+    first = a.lo + (((seg - a.lo) % G) + G) % G;
+    count = first < a.hi ? (a.hi - first + G - 1) / G : 0;
   }
+  const int t = blockIdx.x;
+  if (t >= count) return;
+  const int c = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (c >= a.ncols) return;
+  const int r = (threadIdx.x & 63) * 2;
+  double* m = a.mat + ((int64_t)first + (int64_t)t * a.stride) * 128 + r + (int64_t)c * a.ld;
+  double* q = a.packed + (int64_t)seg * a.seg_elems + (int64_t)t * 128 + r + (int64_t)c * a.ldp;
+  typedef double pk_d2 __attribute__((ext_vector_type(2)));
+  if (a.to_packed) *reinterpret_cast<pk_d2*>(q) = *reinterpret_cast<const pk_d2*>(m);
+  else *reinterpret_cast<pk_d2*>(m) = *reinterpret_cast<const pk_d2*>(q);
 }
 
 // alpha = W^T v with W = L^-1 lower triangular, column-major: alpha_j = sum_{k>=j} W[k + j*ld] v_k

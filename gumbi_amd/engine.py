@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 
 __all__ = ["Engine", "KernelSpec", "GumbiHipError", "library_path", "load_library", "KERNEL_KINDS",
-           "ls_limits"]
+           "ls_limits", "dist_plan", "GmbComm", "DistStep"]
 
 GMB_MAX_DIMS, GMB_MAX_LIN, GMB_MAX_COREG, GMB_MAX_LEVELS = 16, 8, 4, 32
 GMB_OK, GMB_EINVAL, GMB_ENOMEM, GMB_EHIP, GMB_ENOTPD, GMB_ENODEVICE = 0, -1, -2, -3, -4, -5
@@ -162,6 +162,26 @@ def library_path() -> Path:
     return Path(__file__).resolve().parent / "lib" / "libgumbi_hip.so"
 
 
+class GmbComm(C.Structure):
+    """``gmb_comm``: the one collective the multi-GPU driver needs (include/gumbi_hip.h)."""
+
+    ALL_GATHER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("ctx", C.c_void_p), ("all_gather", ALL_GATHER)]
+
+
+class DistStep(C.Structure):
+    """``gmb_dist_step``: one step of a rank's schedule (include/gumbi_hip.h)."""
+
+    _fields_ = [(n, C.c_int32) for n in ("op", "c0", "c1", "lo", "hi", "first", "count", "maxcount", "stream")] + [
+        ("elems", C.c_int64)]
+    OPS = ("KBUILD", "SQUARE", "PANEL", "UPDATE", "FORK", "JOIN")
+
+    def as_dict(self):
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_}
+        d["op"] = self.OPS[d["op"]]
+        return d
+
+
 _SIGNATURES = {
     "gmb_abi_version": (C.c_int, []),
     "gmb_device_count": (C.c_int, []),
@@ -186,31 +206,22 @@ _SIGNATURES = {
     "gmb_copy_v": (C.c_int, [C.c_void_p, _DBL_P]),
     "gmb_blk_potrf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gmb_copy_alpha": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
-    "gmb_inv_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
-    "gmb_grad_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
-    "gmb_nlml_shard_u": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]),
-    "gmb_grad_acc_size": (C.c_int32, []),
-    "gmb_nlml_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]),
-    "gmb_nlml_from_acc": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double),
-                                    C.POINTER(C.c_double)]),
+    "gmb_rccl_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "gmb_rccl_comm_create": (C.c_int, [C.POINTER(C.POINTER(GmbComm)), C.c_char_p, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32]),
+    "gmb_rccl_comm_destroy": (None, [C.POINTER(GmbComm)]),
+    "gmb_rccl_last_error": (C.c_char_p, []),
+    "gmb_dist_plan": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(DistStep), C.c_int64]),
+    "gmb_dist_factorize": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), C.c_int32]),
+    "gmb_dist_nlml": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), _DBL_P, _DBL_P]),
+    "gmb_dist_predict": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_int32]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gmb_blk_trsm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                C.c_int32]),
     "gmb_blk_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                   C.c_int32, C.c_int64]),
-    "gmb_blk_gemm_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-                                       C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
-                                       C.c_int32, C.c_int64, C.c_int32]),
-    "gmb_blk_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
-                               C.c_int32]),
-    "gmb_factor_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                     C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                     C.POINTER(C.c_void_p)]),
-    "gmb_begin_external_factorization": (C.c_int, [C.c_void_p]),
-    "gmb_local_logdet_info": (C.c_int, [C.c_void_p, _DBL_P, C.POINTER(C.c_int64)]),
-    "gmb_finish_external_factorization": (C.c_int, [C.c_void_p, C.c_double, C.c_int64]),
-    "gmb_blk_kbuild": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
 }
 
 
@@ -242,8 +253,9 @@ def _preload_hip_runtime():
 
 
 #: GMB_ABI_VERSION of include/gumbi_hip.h this binding was written against (the layout of
-#: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3)
-ABI_VERSION = 3
+#: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3; version 4 replaced the block-level
+#: multi-GPU entry points by the native driver ``gmb_dist_*``)
+ABI_VERSION = 4
 
 
 def load_library():
@@ -424,39 +436,30 @@ class Engine:
         self._check(self._lib.gmb_copy_alpha(self._h, _dptr(out)), "gmb_copy_alpha")
         return out
 
-    # -- sharded gradient (multi-GPU driver) ---------------------------------------------------------------
-    def nlml_shard(self, shard: int, nshards: int) -> np.ndarray:
-        """Raw gradient accumulators of the block rows ``shard, shard + nshards, ...`` (sum the arrays of
-        all shards, then :meth:`nlml_from_acc`).  Consumes the factor like :meth:`nlml` with ``grad=True``."""
-        n = int(self._lib.gmb_grad_acc_size())
-        acc = np.zeros(n, dtype=np.float64)
-        self._check(self._lib.gmb_nlml_shard(self._h, shard, nshards, _dptr(acc), n), "gmb_nlml_shard")
-        return acc
+    # -- ONE GP over several GPUs (native driver, gumbi_amd/csrc/dist_driver.hpp) -----------------------------
+    def dist_factorize(self, comm, panel_blocks: int = 0):
+        """Collective: ``gmb_factorize`` over the ranks of ``comm`` (a :class:`gumbi_amd.distributed` comm)."""
+        self._check(self._lib.gmb_dist_factorize(self._h, comm.handle, int(panel_blocks)), "gmb_dist_factorize")
 
-    def inv_rows(self, first: int, stride: int, v_ptr: int, ldv: int, alpha_ptr: int):
-        """This rank's block rows of U = L^-T into the device buffer ``v_ptr`` and its rows of alpha."""
-        self._check(self._lib.gmb_inv_rows(self._h, first, stride, C.c_void_p(v_ptr), ldv, C.c_void_p(alpha_ptr)),
-                    "gmb_inv_rows")
-
-    def grad_alpha_ptr(self) -> int:
-        p = C.c_void_p()
-        self._check(self._lib.gmb_grad_buffers(self._h, C.byref(p)), "gmb_grad_buffers")
-        return int(p.value)
-
-    def nlml_shard_u(self, shard: int, nshards: int) -> np.ndarray:
-        """As :meth:`nlml_shard`, with U and alpha already assembled in the engine's buffers."""
-        n = int(self._lib.gmb_grad_acc_size())
-        acc = np.zeros(n, dtype=np.float64)
-        self._check(self._lib.gmb_nlml_shard_u(self._h, shard, nshards, _dptr(acc), n), "gmb_nlml_shard_u")
-        return acc
-
-    def nlml_from_acc(self, acc):
-        acc = np.ascontiguousarray(acc, dtype=np.float64)
+    def dist_nlml(self, comm, grad: bool = False):
         val = C.c_double()
-        grad = np.empty(self.spec.theta_size(), dtype=np.float64)
-        self._check(self._lib.gmb_nlml_from_acc(self._h, _dptr(acc), acc.size, C.byref(val), _dptr(grad)),
-                    "gmb_nlml_from_acc")
-        return float(val.value), grad
+        if not grad:
+            self._check(self._lib.gmb_dist_nlml(self._h, comm.handle, C.byref(val), None), "gmb_dist_nlml")
+            return val.value
+        g = np.empty(self.spec.theta_size(), dtype=np.float64)
+        self._check(self._lib.gmb_dist_nlml(self._h, comm.handle, C.byref(val), _dptr(g)), "gmb_dist_nlml")
+        return val.value, g
+
+    def dist_predict(self, comm, Xs, with_noise=True):
+        Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+        if Xs.ndim != 2 or Xs.shape[1] != self.D:
+            raise ValueError(f"points_array must be (M, {self.D}), got {Xs.shape}")
+        M = Xs.shape[0]
+        mean = np.empty(M, dtype=np.float64)
+        var = np.empty(M, dtype=np.float64)
+        self._check(self._lib.gmb_dist_predict(self._h, comm.handle, _ptr(Xs), M, Xs.shape[1], int(bool(with_noise)),
+                                               _ptr(mean), _ptr(var), GMB_HOST), "gmb_dist_predict")
+        return mean, var
 
     # -- block-level operations (device pointers) --------------------------------------------------------
     def blk_potrf(self, a_ptr, lda, nvalid, dinv16_ptr, logdet_ptr=0, info_ptr=0):
@@ -481,38 +484,16 @@ class Engine:
                                               C.c_void_p(b_ptr), ldb, m, n, k, alpha, beta, tri, tri_shift),
                     "gmb_blk_gemm_nt")
 
-    def blk_gemm_strided(self, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, m, n, k, alpha, beta, tri=0, tri_off=0,
-                         nblk_stride=1):
-        self._check(self._lib.gmb_blk_gemm_strided(self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda,
-                                                   C.c_void_p(b_ptr), ldb, m, n, k, alpha, beta, tri, tri_off,
-                                                   nblk_stride), "gmb_blk_gemm_strided")
 
-    def blk_pack(self, mat_ptr, ld, stride_blocks, count, packed_ptr, ldp, to_packed=True):
-        self._check(self._lib.gmb_blk_pack(self._h, C.c_void_p(mat_ptr), ld, stride_blocks, count,
-                                           C.c_void_p(packed_ptr), ldp, int(bool(to_packed))), "gmb_blk_pack")
-
-    def factor_buffers(self) -> dict:
-        A, inv, scal, info = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        ld, Nr, Np = C.c_int64(), C.c_int64(), C.c_int64()
-        self._check(self._lib.gmb_factor_buffers(self._h, C.byref(A), C.byref(ld), C.byref(Nr), C.byref(Np),
-                                                 C.byref(inv), C.byref(scal), C.byref(info)), "gmb_factor_buffers")
-        return dict(A=A.value, ld=ld.value, Nr=Nr.value, Np=Np.value, dinv16=inv.value, scal=scal.value,
-                    info=info.value)
-
-    def begin_external_factorization(self):
-        self._check(self._lib.gmb_begin_external_factorization(self._h), "gmb_begin_external_factorization")
-
-    def local_logdet_info(self):
-        ld, info = C.c_double(), C.c_int64()
-        self._check(self._lib.gmb_local_logdet_info(self._h, C.byref(ld), C.byref(info)), "gmb_local_logdet_info")
-        return ld.value, info.value
-
-    def finish_external_factorization(self, logdet: float, info: int):
-        self._check(self._lib.gmb_finish_external_factorization(self._h, float(logdet), int(info)),
-                    "gmb_finish_external_factorization")
-
-    def blk_kbuild(self, out_ptr, ldo, i0, ni, j0, nj):
-        self._check(self._lib.gmb_blk_kbuild(self._h, C.c_void_p(out_ptr), ldo, i0, ni, j0, nj), "gmb_blk_kbuild")
+def dist_plan(N: int, rank: int, world: int, panel_blocks: int = 0) -> list:
+    """The schedule rank ``rank`` of ``world`` executes in ``gmb_dist_factorize`` (host-only; no device needed)."""
+    lib = load_library()
+    n = lib.gmb_dist_plan(int(N), int(rank), int(world), int(panel_blocks), None, 0)
+    if n < 0:
+        raise ValueError(f"gmb_dist_plan: bad arguments (N={N}, rank={rank}, world={world})")
+    buf = (DistStep * n)()
+    lib.gmb_dist_plan(int(N), int(rank), int(world), int(panel_blocks), buf, n)
+    return [st.as_dict() for st in buf]
 
 
 def ls_limits(X, ard: bool, device: int = 0):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 3
+#define GMB_ABI_VERSION 4
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -175,25 +175,6 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
 int gmb_ls_limits(int32_t device, const double* X, int64_t N, int32_t n_cols, int64_t ldx,
                   int32_t ard, double* lower, double* upper);
 
-/* Multi-GPU gradient (every rank holds the complete factor after the block-cyclic Cholesky of
- * gumbi_amd/distributed.py): rank `shard` of `nshards` computes L^-1 (replicated), its block rows
- * shard, shard + nshards, ... of Sigma^-1 and the trace reductions over those rows, and returns
- * the raw accumulators (gmb_grad_acc_size() doubles, host).  They are plain sums over tiles: the
- * driver all-reduces them and every rank finishes with gmb_nlml_from_acc (chain rule to the packed
- * parameters, same layout as gmb_nlml's grad).  gmb_nlml(e, &v, grad) == shard 0 of 1 + from_acc. */
-/* Fully partitioned variant: gmb_inv_rows gives a rank ITS block rows first, first+stride, ... of
- * U = L^-T (V: device, (owned*128) x Np column-major with leading dimension ldv; the predict solve
- * applied to rows of the identity, N^3/G flops) and its rows of alpha = U v (device, owned*128
- * doubles); the driver all-gathers both into the upper triangle of every rank's factor buffer
- * (gmb_factor_buffers) and into the alpha vector (gmb_grad_buffers), then gmb_nlml_shard_u does
- * the rank's share of Sigma^-1 and of the reductions without inverting anything itself. */
-int gmb_inv_rows(gmb_engine* e, int32_t first, int32_t stride, double* V, int64_t ldv, double* alpha_rows);
-int gmb_grad_buffers(gmb_engine* e, void** alpha);
-int gmb_nlml_shard_u(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc);
-int32_t gmb_grad_acc_size(void);
-int gmb_nlml_shard(gmb_engine* e, int32_t shard, int32_t nshards, double* acc, int32_t nacc);
-int gmb_nlml_from_acc(gmb_engine* e, const double* acc, int32_t nacc, double* nlml, double* grad);
-
 /* -- introspection --------------------------------------------------------------------------- */
 int gmb_set_profiling(gmb_engine* e, int32_t on); /* per-launch hipEvent timing of GEMMs */
 int gmb_timings_get(const gmb_engine* e, gmb_timings* out);
@@ -213,10 +194,9 @@ int gmb_copy_v(const gmb_engine* e, double* out); /* v = L^-1 y, length N, host 
  * Kronecker (ICM) multi-output path, whose outer chain rule needs it (gumbi_amd/regression/icm.py). */
 int gmb_copy_alpha(const gmb_engine* e, double* out);
 
-/* -- block-level operations for the multi-GPU driver (device pointers, column-major) ----------
- * These expose the same kernels the single-GPU path uses so that a 1-D block-cyclic row
- * partition can be driven from one process per GPU with the panel
- * broadcast done by RCCL through torch.distributed.  All matrices are column-major float64 in
+/* -- kernel-level doors (tests, tuning tools; device pointers, column-major) -------------------
+ * The leaf, strip-solve and MFMA GEMM kernels of the factorisation on caller-provided blocks, so
+ * that each can be checked against LAPACK on its own.  All matrices are column-major float64 in
  * device memory with the given leading dimensions; sizes must be multiples of 128. */
 /* Factor one 128 x 128 diagonal block in place (lower triangle; columns >= nvalid are identity
  * padding and are left alone).  dinv16 (optional, 8 x 256 doubles) receives the column-major
@@ -236,34 +216,59 @@ int gmb_blk_trsm(gmb_engine* e, double* B, int64_t ldb, int64_t nrows, const dou
 int gmb_blk_gemm_nt(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda,
                     const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha,
                     double beta, int32_t tri, int64_t tri_shift);
-/* As gmb_blk_gemm_nt, for one rank of the block-cyclic row partition: the n index walks 128-row
- * blocks that are `nblk_stride` blocks apart in memory (B and C both), and `tri` skips tiles whose
- * last row (n offset + tri_off) lies above their first column (m offset). */
-int gmb_blk_gemm_strided(gmb_engine* e, double* C, int64_t ldc, const double* A, int64_t lda,
-                         const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha,
-                         double beta, int32_t tri, int64_t tri_off, int32_t nblk_stride);
-/* Gather (to_packed = 1) / scatter (0) `count` 128 x 128 blocks between block rows
- * mat + t*stride_blocks*128 (t < count, leading dimension ld) and a packed (count*128) x 128
- * column-major buffer (leading dimension ldp) -- the send / receive side of the panel all-gather. */
-int gmb_blk_pack(gmb_engine* e, double* mat, int64_t ld, int64_t stride_blocks, int32_t count,
-                 double* packed, int64_t ldp, int32_t to_packed);
-/* Device pointers of the engine's own resident state, for a driver that runs the factorisation
- * itself (multi-GPU): factor buffer (Nr x Np column-major, leading dimension ld), the
- * ceil(N/128) x 8 x 256 sub-block inverses of the diagonal blocks (see gmb_blk_potrf), the scalar
- * slots ([0] log-det accumulator) and the info word. */
-int gmb_factor_buffers(gmb_engine* e, void** A, int64_t* ld, int64_t* Nr, int64_t* Np,
-                       void** dinv16, void** scal, void** info);
-/* Bracket an externally driven factorisation: begin resets the accumulators; finish takes the
- * global log-det and info (after the driver's reductions), extracts v and marks the engine
- * factorised so that gmb_nlml / gmb_predict work on the resident factor. */
-int gmb_begin_external_factorization(gmb_engine* e);
-/* this rank's partial log-det (sum over the diagonal blocks it factored) and failure word */
-int gmb_local_logdet_info(gmb_engine* e, double* logdet, int64_t* info);
-int gmb_finish_external_factorization(gmb_engine* e, double logdet, int64_t info);
-/* Covariance tile rows [i0,i0+ni) x cols [j0,j0+nj) of Sigma (+noise/jitter on the diagonal)
- * into a column-major buffer: out[(i-i0) + (j-j0)*ldo]. */
-int gmb_blk_kbuild(gmb_engine* e, double* out, int64_t ldo, int64_t i0, int64_t ni, int64_t j0,
-                   int64_t nj);
+/* -- ONE GP over the GPUs of a node (no reference counterpart -- the reference is
+ * single-process; the work replaced is what pm.find_MAP / Marginal.predict do per evaluation,
+ * pymc/GP.py:811, 845-847) -------------------------------------------------------------------------------
+ * One process per GPU, every process holds an engine with the SAME data / kernel / theta.  128-row blocks
+ * of the covariance matrix are dealt round-robin over the ranks (1-D block-cyclic rows); the native driver
+ * (gumbi_amd/csrc/dist_driver.hpp) runs the panel loop with look-ahead on this rank's HIP streams and
+ * exchanges data through ONE collective, an all-gather of float64 buffers in device memory:
+ *   all_gather(ctx, send, recv, count, stream): every rank contributes `count` doubles at `send`; `recv`
+ *   receives world * count doubles in rank order; the operation is ordered on the hipStream_t `stream`
+ *   (enqueue it there, or synchronise the stream, move the data and return).  0 = success.
+ * gmb_rccl_comm_create gives the production transport (RCCL over xGMI: ncclAllGather on a communicator of
+ * its own; librccl is resolved with dlopen -- pass the path of the copy the process already uses, or NULL
+ * for the loader's); callers may supply any other transport with the same contract (the tests use gloo). */
+typedef struct gmb_comm {
+  int32_t rank, world;
+  void* ctx;
+  int32_t (*all_gather)(void* ctx, const void* send, void* recv, int64_t count, void* stream);
+} gmb_comm;
+
+int gmb_rccl_unique_id(const char* librccl_path, void* id128);  /* rank 0: 128 bytes to hand to every rank */
+int gmb_rccl_comm_create(gmb_comm** out, const char* librccl_path, const void* id128, int32_t rank,
+                         int32_t world, int32_t device);         /* collective: ncclCommInitRank          */
+void gmb_rccl_comm_destroy(gmb_comm* c);
+const char* gmb_rccl_last_error(void);
+
+/* The schedule one rank executes, as data (host-only, no device needed): step kinds
+ *   0 KBUILD  covariance tiles of the rank's block rows
+ *   1 SQUARE  all-gather the block rows [lo, hi) = [c0, c1) of the panel's diagonal square (`elems` doubles
+ *             per rank: maxcount * 128 rows x (c1 - c0) * 128 columns), then factor it locally
+ *   2 PANEL   solve the rank's block rows in [lo, hi) = [c1, nrt) of the panel, all-gather them
+ *   3 UPDATE  A[rows, lo:hi] -= L[rows, c0:c1] L[lo:hi, c0:c1]^T on the rank's block rows >= lo, on stream
+ *             `stream` (0 main, 1 bulk)
+ *   4 FORK    the bulk stream waits for everything issued on the main stream so far;  5 JOIN  the reverse
+ * (first, count): the rank's block rows first, first + world, ... of the step's row range. */
+typedef struct gmb_dist_step {
+  int32_t op, c0, c1, lo, hi, first, count, maxcount, stream;
+  int64_t elems;
+} gmb_dist_step;
+/* number of steps (the first min(cap, n) are written to out; out may be NULL) or a negative gmb_status;
+ * panel_blocks <= 0 selects the default panel width */
+int64_t gmb_dist_plan(int64_t N, int32_t rank, int32_t world, int32_t panel_blocks, gmb_dist_step* out,
+                      int64_t cap);
+
+/* gmb_factorize over comm->world ranks (collective: every rank calls it with the same state).  Every rank
+ * ends with the complete factor, v, log-det and -- on failure -- the same GMB_ENOTPD / gmb_notpd_index. */
+int gmb_dist_factorize(gmb_engine* e, const gmb_comm* comm, int32_t panel_blocks);
+/* gmb_nlml over the ranks; with grad != NULL the inverse, Sigma^-1 and the trace reductions are
+ * partitioned by block rows and every rank receives bit-identical (nlml, grad). */
+int gmb_dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad);
+/* gmb_predict with the M points sharded over the ranks; every rank passes the same Xs and receives the
+ * complete mean / var. */
+int gmb_dist_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M, int64_t ldxs,
+                     int32_t with_noise, double* mean, double* var, int32_t memspace);
 
 #ifdef __cplusplus
 }

@@ -1,14 +1,17 @@
-"""The block-cyclic multi-GPU Cholesky driver (gumbi_amd/distributed.py) on CPU: world_size-2
-``gloo`` processes, with the rank-local block operations supplied by a numpy stand-in built on the
-oracle (test infrastructure only -- the product's ``HipBlockOps`` runs HIP kernels).  Checks the
-ownership arithmetic, message sizes, recursion order and the assembled factor against LAPACK."""
+"""The multi-GPU Cholesky SCHEDULE on CPU: the native driver (gumbi_amd/csrc/dist_driver.hpp) builds its
+panel loop as a plan first (pure integer arithmetic, exported as ``gmb_dist_plan``) and then executes it with
+HIP kernels.  Here world_size-2 / -3 ``gloo`` processes replay the SAME plan with numpy blocks built on the
+oracle (test infrastructure only) and real all-gathers of the message sizes the plan states: ownership
+arithmetic, message sizes, step order and the assembled factor are checked against LAPACK.  The HIP execution
+of the plan is checked by tests/test_gpu_distributed.py."""
 import os
 import socket
 
 import numpy as np
 import pytest
 
-from gumbi_amd.distributed import BLK, BlockCyclicCholesky, TorchComm, owned_blocks
+from gumbi_amd import engine as E
+from gumbi_amd.distributed import BLK, owned_blocks
 from oracle import gp_oracle as O
 
 
@@ -24,13 +27,43 @@ def test_owned_blocks_partition():
             assert sorted(seen) == list(range(start, stop))
 
 
-class NumpyBlockOps:
-    """Same interface as HipBlockOps, on a full-size numpy buffer per rank."""
+@pytest.mark.parametrize("N,world,w", [(1000, 2, 2), (100_000, 8, 0), (100_000, 8, 8), (50_000, 4, 16), (130, 3, 1),
+                                       (4096, 2, 8), (12_800, 8, 4)])
+def test_plan_is_consistent_across_ranks(N, world, w):
+    """Every rank issues the same sequence of collectives with the same sizes (anything else deadlocks RCCL);
+    the rows named by SQUARE / PANEL / UPDATE steps partition their ranges; panels tile the columns."""
+    plans = [E.dist_plan(N, r, world, w) for r in range(world)]
+    nct, nrt = -(-N // BLK), -(-(N + 1) // BLK)
+    coll = [[(s["op"], s["c0"], s["c1"], s["lo"], s["hi"], s["elems"]) for s in p if s["op"] in ("SQUARE", "PANEL")]
+            for p in plans]
+    assert all(c == coll[0] for c in coll)
+    assert [len(p) for p in plans] == [len(plans[0])] * world
+    squares = [c for c in coll[0] if c[0] == "SQUARE"]
+    assert squares[0][1] == 0 and squares[-1][2] == nct
+    assert all(a[2] == b[1] for a, b in zip(squares, squares[1:]))  # panels tile [0, nct)
+    for i, step0 in enumerate(plans[0]):
+        steps = [p[i] for p in plans]
+        assert len({s["op"] for s in steps}) == 1
+        op = step0["op"]
+        if op in ("SQUARE", "PANEL", "UPDATE", "KBUILD"):
+            hi = nrt if op in ("UPDATE", "KBUILD") else step0["hi"]
+            rows = sorted(s["first"] + t * world for s in steps for t in range(s["count"]))
+            assert rows == list(range(step0["lo"], hi))
+        if op in ("SQUARE", "PANEL"):
+            assert step0["elems"] == step0["maxcount"] * BLK * (step0["c1"] - step0["c0"]) * BLK
+            assert step0["maxcount"] == max(s["count"] for s in steps)
+    # every trailing block (i, j), j <= i, receives the update of every earlier panel exactly once
+    ups = [s for s in plans[0] if s["op"] == "UPDATE"]
+    for c0, c1 in {(s["c0"], s["c1"]) for s in ups}:
+        cols = sorted((s["lo"], s["hi"]) for s in ups if (s["c0"], s["c1"]) == (c0, c1))
+        assert cols[0][0] == c1 and cols[-1][1] == nct and all(a[1] == b[0] for a, b in zip(cols, cols[1:]))
 
-    def __init__(self, spec, theta, X, y):
-        import torch
 
-        self.torch = torch
+class NumpyRank:
+    """One rank's full-size buffer and the numpy versions of the plan's steps."""
+
+    def __init__(self, spec, theta, X, y, rank, world):
+        self.rank, self.G = rank, world
         self.N = N = len(y)
         self.Np = -(-N // BLK) * BLK
         self.Nr = -(-(N + 1) // BLK) * BLK
@@ -39,86 +72,74 @@ class NumpyBlockOps:
         S[N, :N] = y
         for j in range(N, self.Np):
             S[j, j] = 1.0
-        self._sigma = S
-        self.A = np.full((self.Nr, self.Np), np.nan)  # poison: unbuilt rows must never be read
-        self.inv = np.full((self.Np // BLK, BLK, BLK), np.nan)
-        self._stage = torch.zeros(2 * BLK * BLK, dtype=torch.float64)
-        self.logdet, self.info = 0.0, 0
+        self._sigma = np.tril(S)
+        self.A = np.full((self.Nr, self.Np), np.nan)  # poison: rows this rank never built / received stay NaN
+        self.logdet = 0.0
 
-    def begin(self):
-        self.logdet, self.info = 0.0, 0
+    def rows(self, s):
+        return [s["first"] + t * self.G for t in range(s["count"])]
 
-    def build_block_row(self, i):
-        ncols = min(i + 1, self.Np // BLK) * BLK
-        self.A[i * BLK:(i + 1) * BLK, :ncols] = np.tril(self._sigma)[i * BLK:(i + 1) * BLK, :ncols]
+    def kbuild(self, s):
+        for i in self.rows(s):
+            ncols = min(i + 1, self.Np // BLK) * BLK
+            self.A[i * BLK:(i + 1) * BLK, :ncols] = self._sigma[i * BLK:(i + 1) * BLK, :ncols]
 
-    def potrf(self, k):
-        blk = self.A[k * BLK:(k + 1) * BLK, k * BLK:(k + 1) * BLK]
-        nv = min(BLK, self.N - k * BLK)
+    def _exchange(self, s, dist, torch, solve=None):
+        c0, c1, G = s["c0"] * BLK, s["c1"] * BLK, self.G
+        W, mc = c1 - c0, s["maxcount"]
+        send = np.zeros((mc, BLK, W))
+        for t, i in enumerate(self.rows(s)):
+            send[t] = np.nan_to_num(self.A[i * BLK:(i + 1) * BLK, c0:c1])
+        if solve is not None:
+            send[:s["count"]] = solve(send[:s["count"]])
+        assert send.size == s["elems"]
+        t_in = torch.from_numpy(send.ravel().copy())
+        t_out = torch.empty(send.size * G, dtype=torch.float64)
+        dist.all_gather_into_tensor(t_out, t_in)
+        recv = t_out.numpy().reshape(G, mc, BLK, W)
+        for q in range(G):
+            first, cnt = owned_blocks(q, G, s["lo"], s["hi"])
+            for t in range(cnt):
+                i = first + t * G
+                self.A[i * BLK:(i + 1) * BLK, c0:c1] = recv[q, t]
+
+    def square(self, s, dist, torch):
+        self._exchange(s, dist, torch)
+        c0, c1 = s["c0"] * BLK, s["c1"] * BLK
+        nv = min(c1, self.N) - c0  # rows / columns >= N inside the square: y row and identity padding
+        blk = self.A[c0:c1, c0:c1]
         L11 = np.linalg.cholesky(np.tril(blk[:nv, :nv]) + np.tril(blk[:nv, :nv], -1).T)
         blk[:nv, :nv] = L11
-        if nv < BLK:
+        if nv < c1 - c0:
             blk[nv:, :nv] = np.linalg.solve(L11, blk[nv:, :nv].T).T
-        inv = np.eye(BLK)
-        inv[:nv, :nv] = np.linalg.inv(L11)
-        self.inv[k] = inv
         self.logdet += float(np.sum(np.log(np.diag(L11))))
 
-    def diag_stage(self):
-        return self._stage
+    def panel(self, s, dist, torch):
+        c0, c1 = s["c0"] * BLK, s["c1"] * BLK
+        nv = min(c1, self.N) - c0
+        L11 = np.tril(self.A[c0:c0 + nv, c0:c0 + nv])
 
-    def diag_to_stage(self, k):
-        blk = self.A[k * BLK:(k + 1) * BLK, k * BLK:(k + 1) * BLK]
-        self._stage[:BLK * BLK] = self.torch.from_numpy(np.nan_to_num(blk).ravel().copy())
-        self._stage[BLK * BLK:] = self.torch.from_numpy(self.inv[k].ravel().copy())
+        def solve(rows):  # rows: (cnt, 128, W)
+            out = rows.copy()
+            out[:, :, :nv] = np.linalg.solve(L11, rows[:, :, :nv].reshape(-1, nv).T).T.reshape(rows.shape[0], BLK, nv)
+            return out
 
-    def stage_to_diag(self, k):
-        st = self._stage.numpy()
-        self.A[k * BLK:(k + 1) * BLK, k * BLK:(k + 1) * BLK] = st[:BLK * BLK].reshape(BLK, BLK)
-        self.inv[k] = st[BLK * BLK:].reshape(BLK, BLK)
+        self._exchange(s, dist, torch, solve)
 
-    def panel_buffers(self, maxcnt, G):
-        n = maxcnt * BLK * BLK
-        return self.torch.zeros(n, dtype=self.torch.float64), self.torch.zeros(n * G, dtype=self.torch.float64)
-
-    def pack_panel(self, k, first, cnt, G, send, maxcnt):
-        buf = send.numpy().reshape(maxcnt, BLK, BLK)
-        for t in range(cnt):
-            i = first + t * G
-            buf[t] = self.A[i * BLK:(i + 1) * BLK, k * BLK:(k + 1) * BLK]
-
-    def solve_packed(self, k, cnt, send, maxcnt):
-        buf = send.numpy().reshape(maxcnt, BLK, BLK)
-        for t in range(cnt):
-            buf[t] = buf[t] @ self.inv[k].T
-
-    def unpack_panel(self, k, first, cnt, G, recv, r, maxcnt):
-        buf = recv.numpy().reshape(G, maxcnt, BLK, BLK)[r]
-        for t in range(cnt):
-            i = first + t * G
-            self.A[i * BLK:(i + 1) * BLK, k * BLK:(k + 1) * BLK] = buf[t]
-
-    def update(self, c0, mid, c1, first, cnt, G):
-        panel_cols = self.A[mid * BLK:c1 * BLK, c0 * BLK:mid * BLK]
-        for t in range(cnt):
-            i = first + t * G
+    def update(self, s):
+        c0, c1, lo, hi = s["c0"] * BLK, s["c1"] * BLK, s["lo"], s["hi"]
+        panel_rows = self.A[lo * BLK:hi * BLK, c0:c1]
+        assert not np.isnan(panel_rows).any()  # the all-gathers must have delivered the whole panel
+        for i in self.rows(s):
             rows = slice(i * BLK, (i + 1) * BLK)
-            hi = min(i + 1, c1)  # lower-triangular tiles only
-            if hi <= mid:
+            top = min(i + 1, hi)  # lower-triangular tiles only
+            if top <= lo:
                 continue
-            self.A[rows, mid * BLK:hi * BLK] -= self.A[rows, c0 * BLK:mid * BLK] @ panel_cols[:(hi - mid) * BLK].T
-
-    def local_logdet_info(self):
-        return self.logdet, self.info
-
-    def scalar_tensor(self, values):
-        return self.torch.tensor(values, dtype=self.torch.float64)
-
-    def finish(self, logdet, info):
-        self.total_logdet, self.total_info = logdet, info
+            self.A[rows, lo * BLK:top * BLK] -= self.A[rows, c0:c1] @ panel_rows[:(top - lo) * BLK].T
 
 
-def _worker(rank, world, port, N, d, out):
+def _worker(rank, world, port, N, d, w, out):
+    import torch
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -128,17 +149,22 @@ def _worker(rank, world, port, N, d, out):
         X, y, ls = O.synthetic_table(N, d, seed=5)
         spec = O.make_spec(d, range(d), kind="Matern52")
         theta = O.pack_theta(spec, ls, 1.1, 0.3)
-        ops = NumpyBlockOps(spec, theta, X, y)
-        drv = BlockCyclicCholesky(ops, TorchComm(), ops.Np // BLK, ops.Nr // BLK)
-        drv.factorize()
+        me = NumpyRank(spec, theta, X, y, rank, world)
+        for s in E.dist_plan(N, rank, world, w):
+            if s["op"] == "KBUILD":
+                me.kbuild(s)
+            elif s["op"] == "SQUARE":
+                me.square(s, dist, torch)
+            elif s["op"] == "PANEL":
+                me.panel(s, dist, torch)
+            elif s["op"] == "UPDATE":
+                me.update(s)
         L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
-        # off-diagonal blocks of every finished panel are on every rank; diagonal blocks too (broadcast)
-        got = np.tril(ops.A[:N, :N])
+        got = np.tril(me.A[:N, :N])  # the COMPLETE factor is on every rank
         err_L = np.max(np.abs(got - L_ref)) / np.max(np.abs(L_ref))
-        err_v = np.max(np.abs(ops.A[N, :N] - v_ref)) / np.max(np.abs(v_ref))
-        err_ld = abs(ops.total_logdet - np.sum(np.log(np.diag(L_ref))))
-        leaves = [e for e in drv.log if e[0] == "leaf"]
-        out.put((rank, err_L, err_v, err_ld, ops.total_info, [e[1] for e in leaves], [e[2] for e in leaves]))
+        err_v = np.max(np.abs(me.A[N, :N] - v_ref)) / np.max(np.abs(v_ref))
+        err_ld = abs(me.logdet - np.sum(np.log(np.diag(L_ref))))
+        out.put((rank, err_L, err_v, err_ld))
     finally:
         dist.destroy_process_group()
 
@@ -149,21 +175,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,N", [(2, 300), (2, 256), (2, 130), (3, 700)])
-def test_block_cyclic_cholesky_gloo(world, N):
+@pytest.mark.parametrize("world,N,w", [(2, 300, 1), (2, 256, 2), (2, 130, 1), (3, 700, 2), (2, 1100, 4), (3, 900, 0)])
+def test_plan_replayed_with_numpy_blocks_over_gloo(world, N, w):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, w, out)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    nct = -(-N // BLK)
-    for rank, err_L, err_v, err_ld, info, leaf_ks, owners in results:
-        assert err_L < 1e-12 and err_v < 1e-12 and err_ld < 1e-10 and info == 0
-        assert leaf_ks == list(range(nct)) and owners == [k % world for k in range(nct)]
+    assert sorted(r[0] for r in results) == list(range(world))
+    for rank, err_L, err_v, err_ld in results:
+        assert err_L < 1e-12 and err_v < 1e-12 and err_ld < 1e-10

@@ -136,6 +136,55 @@ def test_c3_full_size_properties(gpu):
     eng.close()
 
 
+def test_c5_size_on_one_gpu(gpu):
+    """BASELINE.json configs[4] at its full size -- N = 100,000, d = 8, RBF-ARD -- on ONE MI355X (the
+    strong-scaling base of the 8-GPU run; 80 GB factor + 80 GB gradient workspace of 288 GB): the path
+    `PymcGP.fit` -> `find_MAP` -> `predict` reaches (gumbi/regression/pymc/GP.py:255-387, 799-813, 837-849) as
+    factorise -> one objective + gradient evaluation -> re-factorise -> predict, checked through
+    size-independent properties: L L^T = Sigma on sampled rows against the oracle's covariance, the
+    `with_noise` shift, variances inside (0, prior], a finite NLML / gradient, and the posterior mean
+    recomputed from its definition k(x*, X) alpha with the alpha = Sigma^-1 y the gradient call leaves."""
+    import time
+
+    N, d = 100_000, 8
+    X, y, ls = O.synthetic_table(N, d)
+    spec = O.make_spec(d, range(d), kind="ExpQuad")
+    sigma = 0.2
+    theta = O.pack_theta(spec, ls, 1.0, sigma)
+    eng = make_engine(spec, theta, X, y)
+    t0 = time.perf_counter()
+    eng.factorize()
+    t_fact = time.perf_counter() - t0
+    rows = np.sort(np.random.default_rng(11).choice(N, 6, replace=False))
+    sampled_rows_check(eng, spec, theta, X, rows)
+    v = eng.copy_v()
+    diag = np.array([eng.copy_factor(int(i), 1, int(i), 1)[0, 0] for i in np.random.default_rng(1).choice(N, 64)])
+    assert np.all(diag > 0) and np.all(np.isfinite(v))
+    nl = eng.nlml()
+    t0 = time.perf_counter()
+    val, g = eng.nlml(grad=True)
+    t_grad = time.perf_counter() - t0
+    assert val == nl and np.all(np.isfinite(g)) and g.shape == (d + 2,)
+    alpha = eng.copy_alpha()
+    assert np.isfinite(alpha).all()
+    eng.factorize()  # the gradient consumed the factor
+    Xs = O.synthetic_grid(d, res=100)
+    t0 = time.perf_counter()
+    mu, var = eng.predict(Xs, with_noise=True)
+    t_pred = time.perf_counter() - t0
+    mu0, var0 = eng.predict(Xs, with_noise=False)
+    assert np.array_equal(mu, mu0) and np.allclose(var - var0, sigma**2, rtol=0, atol=1e-14)
+    assert np.all(np.isfinite(mu)) and np.all(var0 > 0) and np.all(var0 <= 1.0 + 1e-9)
+    # mean = k(x*, X) alpha, straight from the definition, on a few grid points (alpha from the gradient call)
+    sub = np.random.default_rng(2).choice(len(Xs), 16, replace=False)
+    Ks = O.cov_full(spec, theta, Xs[sub], X, dist_mode="direct")
+    assert rel(mu[sub], Ks @ alpha) < 1e-8
+    print(f"C5 on one GPU: factorise {t_fact:.2f} s ({N**3 / 3 / t_fact / 1e12:.1f} TF/s), objective+gradient "
+          f"{t_grad:.2f} s, predict(1e4) {t_pred:.2f} s")
+    assert t_fact < 20 and t_grad < 40 and t_pred < 10
+    eng.close()
+
+
 def test_c4_midsize_parity_and_frontend_correlation(gpu):
     X, y, spec, theta = icm_problem(1500, 4)
     eng = make_engine(spec, theta, X, y)

@@ -1,6 +1,7 @@
-"""Multi-rank path on real HIP kernels: two processes share the one GPU of the test box and
-exchange panels through ``gloo`` (RCCL refuses two ranks on one device); the 8-GPU RCCL run is the
-driver's SCALE job.  Checks factor, v, NLML and predictions against the oracle."""
+"""Multi-rank path on real HIP kernels: the native driver (gumbi_amd/csrc/dist_driver.hpp, ``gmb_dist_*``)
+with two / three processes sharing the one GPU of the test box and exchanging panels through ``gloo``
+(RCCL refuses two ranks on one device), and with the library's own RCCL communicator on one rank; the 8-GPU
+RCCL run is the driver's SCALE job.  Checks factor, v, NLML, gradient and predictions against the oracle."""
 import os
 import socket
 
@@ -10,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, N, d, M, out, model="matern"):
+def _worker(rank, world, port, N, d, M, out, model="matern", panel=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch  # noqa: F401
@@ -32,21 +33,39 @@ def _worker(rank, world, port, N, d, M, out, model="matern"):
             Xs[:, 0] += 0.21
             kspec = KernelSpec(**{k: spec[k] for k in ("D", "idx_cont", "kind", "ard", "idx_lin", "coreg", "out_col",
                                                         "n_out", "hetero_noise", "jitter", "additive")})
+        elif model == "composite":
+            # linear x coregion x two outputs x heteroskedastic noise: every accumulator class of the sharded
+            # gradient (lengthscales, linear, coregion tables, noise table) is hit
+            from pathlib import Path
+
+            gold = np.load(Path(__file__).resolve().parent / "golden" / "gp_goldens.npz", allow_pickle=True)
+            spec = O.make_spec(4, [0, 1], idx_lin=[1], coreg=[(2, 3)], out_col=3, n_out=2, hetero_noise=True)
+            Xg, yg, theta = (gold[f"composite_N140/{k}"] for k in ("X", "y", "theta"))
+            rng = np.random.default_rng(3)
+            reps = max(2, N // len(yg))
+            X = np.concatenate([Xg] * reps)
+            X[:, spec["idx_cont"]] += 0.05 * rng.standard_normal((len(X), len(spec["idx_cont"])))
+            y = np.concatenate([yg] * reps) + 0.1 * rng.standard_normal(len(X))
+            Xs = X[::5].copy()
+            Xs[:, spec["idx_cont"][0]] += 0.13
+            kspec = KernelSpec(**{k: spec[k] for k in ("D", "idx_cont", "kind", "ard", "idx_lin", "coreg", "out_col",
+                                                        "n_out", "hetero_noise", "jitter")})
         else:
             X, y, ls = O.synthetic_table(N, d, seed=5)
             spec = O.make_spec(d, range(d), kind="Matern52")
             theta = O.pack_theta(spec, ls, 1.1, 0.3)
             Xs = np.random.default_rng(1).standard_normal((M, d))
             kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind="Matern52")
-        eng = DistributedEngine(0)
+        eng = DistributedEngine(0, panel_blocks=panel)
+        assert eng.comm.kind == "torch-gloo"
         eng.set_data(X, y)
         eng.set_kernel(kspec)
         eng.set_theta(theta)
         eng.factorize()
         L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
-        L = np.tril(eng.eng.copy_factor())
+        L = np.tril(eng.copy_factor())
         err_L = np.max(np.abs(L - L_ref)) / np.max(np.abs(L_ref))
-        err_v = np.max(np.abs(eng.eng.copy_v() - v_ref)) / np.max(np.abs(v_ref))
+        err_v = np.max(np.abs(eng.copy_v() - v_ref)) / np.max(np.abs(v_ref))
         err_nl = abs(eng.nlml() - O.nlml(spec, theta, X, y, dist_mode="direct"))
         mu, var = eng.predict(Xs)
         mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
@@ -57,11 +76,11 @@ def _worker(rank, world, port, N, d, M, out, model="matern"):
         val, g = eng.nlml(grad=True)
         val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
         err_g = max(abs(val - val_r) / abs(val_r), np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r))))
-        # the replicated-inverse variant (only Sigma^-1 sharded) must agree with the partitioned one
-        eng.partition_inverse = False
-        eng.factorize()
-        val2, g2 = eng.nlml(grad=True)
-        err_g = max(err_g, np.max(np.abs(g2 - g)) / max(1.0, np.max(np.abs(g))) * 1e2)  # 1e-10 relative
+        # alpha = Sigma^-1 y assembled from the ranks' rows of U
+        from scipy.linalg import solve_triangular
+
+        err_g = max(err_g, float(np.max(np.abs(eng.copy_alpha() - solve_triangular(L_ref, v_ref, lower=True, trans="T")))
+                               / np.max(np.abs(v_ref))) * 1e-2)
         out.put((rank, err_L, err_v, err_nl, err_mu, err_var, err_g, g.tobytes()))
         eng.close()
     finally:
@@ -74,15 +93,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,N,model", [(2, 700, "matern"), (2, 512, "matern"), (3, 1000, "matern"),
-                                           (2, 600, "additive")])
-def test_two_ranks_one_gpu_match_oracle(gpu, world, N, model):
+@pytest.mark.parametrize("world,N,model,panel", [(2, 700, "matern", 0), (2, 512, "matern", 1), (3, 1000, "matern", 2),
+                                                 (2, 600, "additive", 0), (3, 420, "composite", 1),
+                                                 (2, 2500, "matern", 3), (3, 5000, "matern", 0)])
+def test_two_ranks_one_gpu_match_oracle(gpu, world, N, model, panel):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, 333, out, model)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, 333, out, model, panel)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=300) for _ in range(world)]
@@ -94,6 +114,70 @@ def test_two_ranks_one_gpu_match_oracle(gpu, world, N, model):
         assert err_mu < 1e-8 and err_var < 1e-9
         assert err_g < 1e-8
     assert len({r[-1] for r in results}) == 1  # bit-identical gradient on every rank (optimisers stay in lock step)
+
+
+def _large_worker(rank, world, port, N, d, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gumbi_amd.distributed import DistributedEngine
+        from gumbi_amd.engine import Engine, KernelSpec
+        from oracle import gp_oracle as O
+
+        X, y, ls = O.synthetic_table(N, d, seed=7)
+        theta = np.concatenate([ls, [1.0, 0.2]])
+        kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind="ExpQuad")
+        Xs = O.synthetic_grid(d, 24)
+        res = {}
+        for name, eng in (("dist", DistributedEngine(0)), ("single", Engine(0))):
+            eng.set_data(X, y)
+            eng.set_kernel(kspec)
+            eng.set_theta(theta)
+            eng.factorize()
+            rows = [0, 127, 128, 5000, N // 2 + 1, N - 1]
+            Lr = np.stack([eng.copy_factor(r, 1, 0, N)[0] for r in rows])
+            v = eng.copy_v()
+            mu, var = eng.predict(Xs)
+            val, g = eng.nlml(grad=True)
+            res[name] = (Lr, v, mu, var, val, g)
+            eng.close()
+            del eng
+        a, b = res["dist"], res["single"]
+        errs = [float(np.max(np.abs(x - z)) / max(np.max(np.abs(z)), 1e-300)) for x, z in zip(a[:4], b[:4])]
+        errs.append(abs(a[4] - b[4]) / abs(b[4]))
+        errs.append(float(np.max(np.abs(a[5] - b[5])) / max(1.0, np.max(np.abs(b[5])))))
+        ref = O.nlml(O.make_spec(d, range(d)), theta, X, y) if rank == 0 else a[4]
+        out.put((rank, errs, abs(a[4] - ref) / abs(ref), a[5].tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_at_n_20k_match_the_single_engine(gpu):
+    """The block-cyclic driver well beyond a handful of blocks: N = 20,480 (160 block columns, 20 panels of
+    the default width, 5 chunks of the row-partitioned inverse) over two ranks sharing the GPU: sampled rows
+    of the factor, v, predictions, NLML and gradient equal the single-GPU engine's (same kernels, different
+    order of the trailing updates), the NLML equals the oracle's, both ranks hold identical bits."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_large_worker, args=(r, 2, port, 20_480, 4, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, errs, err_oracle, _ in results:
+        assert max(errs[:2]) < 1e-9 and errs[2] < 1e-8 and errs[3] < 1e-8, errs   # factor rows, v, mean, variance
+        assert errs[4] < 1e-11 and errs[5] < 1e-7, errs                            # NLML, gradient
+        assert err_oracle < 1e-10
+    assert results[0][-1] == results[1][-1]
 
 
 def _fit_worker(rank, world, port, N, out):
@@ -228,8 +312,8 @@ def _rccl_worker(out):
         X, y, ls = O.synthetic_table(N, d, seed=8)
         spec = O.make_spec(d, range(d))
         theta = O.pack_theta(spec, ls, 1.0, 0.25)
-        eng = DistributedEngine(0)
-        eng.force_partition = True
+        eng = DistributedEngine(0, panel_blocks=2)
+        kind = eng.comm.kind
         eng.set_data(X, y)
         eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d))))
         eng.set_theta(theta)
@@ -240,7 +324,7 @@ def _rccl_worker(out):
         Xs = np.random.default_rng(3).standard_normal((200, d))
         mu, var = eng.predict(Xs)
         mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
-        out.put((dist.get_backend(), abs(val - val_r) / abs(val_r), float(np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r)))),
+        out.put((dist.get_backend() + "/" + kind, abs(val - val_r) / abs(val_r), float(np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r)))),
                  float(np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))), float(np.max(np.abs(var - var_r)))))
         eng.close()
     finally:
@@ -248,9 +332,10 @@ def _rccl_worker(out):
 
 
 def test_driver_on_the_rccl_backend_with_one_rank(gpu):
-    """The same driver on the nccl (= RCCL) backend: device-tensor broadcast / all-gather / all-reduce on
-    the engine's side stream, no host staging.  One rank is all a one-GPU box allows (RCCL refuses two
-    ranks on one device); the collectives are trivial but every call the 8-GPU run makes is made."""
+    """The same driver on its production transport: the library's OWN RCCL communicator (unique id from
+    ncclGetUniqueId, ncclCommInitRank, ncclAllGather called from the C++ panel loop on the engine's streams).
+    One rank is all a one-GPU box allows (RCCL refuses two ranks on one device); the collectives are trivial
+    but every call the 8-GPU run makes is made."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
@@ -260,7 +345,7 @@ def test_driver_on_the_rccl_backend_with_one_rank(gpu):
     backend, e_val, e_g, e_mu, e_var = out.get(timeout=300)
     p.join(timeout=60)
     assert p.exitcode == 0
-    assert backend == "nccl"
+    assert backend == "nccl/rccl"
     assert e_val < 1e-10 and e_g < 1e-8 and e_mu < 1e-8 and e_var < 1e-9
 
 

@@ -307,113 +307,6 @@ def test_nlml_gradient_matches_oracle(gpu, kind, ard):
         eng.predict(X[:4])  # the factor was consumed by the gradient
 
 
-@pytest.mark.parametrize("nshards", [2, 3, 5])
-def test_sharded_gradient_sums_to_the_full_gradient(gpu, nshards):
-    """gmb_nlml_shard over all shards + gmb_nlml_from_acc == gmb_nlml (the multi-GPU gradient's contract);
-    composite model so that every accumulator class (lengthscales, linear, coregion tables, noise) is hit."""
-    case = "composite_N140"
-    spec = golden_spec(case)
-    X, y, theta = (GOLD[f"{case}/{k}"] for k in ("X", "y", "theta"))
-    rng = np.random.default_rng(3)
-    reps = 3  # > 128 rows so that several block rows exist
-    Xb = np.concatenate([X] * reps)
-    Xb[:, spec["idx_cont"]] += 0.05 * rng.standard_normal((len(Xb), len(spec["idx_cont"])))
-    yb = np.concatenate([y] * reps) + 0.1 * rng.standard_normal(len(Xb))
-    eng = make_engine(spec, theta, Xb, yb)
-    eng.factorize()
-    val, g = eng.nlml(grad=True)
-    acc = 0.0
-    for sh in range(nshards):
-        eng.factorize()  # each shard call consumes the factor, as each rank's engine does
-        acc = acc + eng.nlml_shard(sh, nshards)
-    eng.factorize()
-    val2, g2 = eng.nlml_from_acc(acc)
-    assert val2 == val
-    assert np.max(np.abs(g2 - g)) < 1e-11 * max(1.0, np.max(np.abs(g)))
-    val_r, g_r = O.nlml_and_grad(spec, theta, Xb, yb, dist_mode="direct")
-    assert np.isclose(val2, val_r, rtol=1e-10)
-    assert np.max(np.abs(g2 - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
-
-
-def test_composite_model_gradient_and_prediction(gpu):
-    case = "composite_N140"
-    spec = golden_spec(case)
-    X, y, Xs, theta = (GOLD[f"{case}/{k}"] for k in ("X", "y", "Xs", "theta"))
-    eng = make_engine(spec, theta, X, y)
-    eng.factorize()
-    val, g = eng.nlml(grad=True)
-    assert np.isclose(val, float(GOLD[f"{case}/nlml"]), rtol=1e-10)
-    g_r = GOLD[f"{case}/grad"]
-    assert np.max(np.abs(g - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
-
-
-def test_ls_limits_joint_matches_oracle(gpu):
-    from gumbi_amd.engine import ls_limits
-    from gumbi_amd.utils.gp_utils import parse_ls_limits
-
-    rng = np.random.default_rng(4)
-    X = rng.standard_normal((700, 4))
-    X[10] = X[3]
-    lo, hi = ls_limits(X, ard=False)
-    lo_r, hi_r = O.parse_ls_limits(X, ARD=False)
-    assert np.isclose(lo[0], lo_r[0], rtol=1e-14) and np.isclose(hi[0], hi_r[0], rtol=1e-14)
-    from scipy.spatial.distance import pdist
-
-    lo, hi = ls_limits(X, ard=True)  # raw extrema (the 0.01 floor is applied by parse_ls_limits)
-    for j in range(X.shape[1]):
-        dj = pdist(X[:, [j]])
-        assert np.isclose(lo[j], dj[dj != 0].min(), rtol=1e-14) and np.isclose(hi[j], dj.max(), rtol=1e-14)
-    lo2, hi2 = parse_ls_limits(X, ARD=False)
-    assert np.isclose(lo2[0], lo_r[0]) and np.isclose(hi2[0], hi_r[0])
-    lo, hi = ls_limits(np.ones((5, 2)), ard=False)
-    assert lo[0] == -1.0  # every pair coincides
-
-
-# ----------------------------------------------------------------------------------------------
-# BASELINE.json sizes: size-independent properties (the oracle would take minutes here)
-# ----------------------------------------------------------------------------------------------
-def test_full_size_properties_config2(gpu):
-    """C2 (N = 10k, d = 4, RBF-ARD): factor reproduces sampled covariance entries, the noise
-    switch shifts the variance by exactly sigma^2, and the mean is linear in y."""
-    N, d = 10_000, 4
-    X, y, ls = O.synthetic_table(N, d)
-    spec = O.make_spec(d, range(d))
-    sigma = 0.2
-    theta = O.pack_theta(spec, ls, 1.0, sigma)
-    eng = make_engine(spec, theta, X, y)
-    eng.factorize()
-    # (L L^T)_ij == Sigma_ij on sampled rows
-    rng = np.random.default_rng(1)
-    rows = np.sort(rng.choice(N, 6, replace=False))
-    Lr = np.stack([eng.copy_factor(int(r), 1, 0, N)[0] for r in rows])
-    for a, ra in enumerate(rows):
-        Lr[a, ra + 1:] = 0.0
-    S_rows = O.sigma_matrix(spec, theta, X[rows], "direct")
-    got = Lr @ Lr.T
-    assert rel(got, S_rows) < 1e-11
-    Xs = O.synthetic_grid(d, res=40)
-    mu, var = eng.predict(Xs, with_noise=True)
-    mu0, var0 = eng.predict(Xs, with_noise=False)
-    assert np.array_equal(mu, mu0) and np.allclose(var - var0, sigma**2, rtol=0, atol=1e-14)
-    assert np.all(var0 > 0) and np.all(var0 <= 1.0 + 1e-9)
-    # linearity in y
-    y2 = np.random.default_rng(2).standard_normal(N)
-    eng.set_data(X, y2)
-    eng.set_theta(theta)
-    eng.factorize()
-    mu_b, _ = eng.predict(Xs)
-    eng.set_data(X, y + y2)
-    eng.set_theta(theta)
-    eng.factorize()
-    mu_c, _ = eng.predict(Xs)
-    assert rel(mu_c, mu + mu_b) < 1e-9
-    # sub-sampled oracle parity on a 1500-point subset problem is covered above; here compare a
-    # few predictions against a direct dense solve on the GPU-independent oracle at reduced M
-    sub = rng.choice(len(Xs), 5, replace=False)
-    mu_r, var_r = O.predict(spec, theta, X[:2000], (y + y2)[:2000], Xs[sub], dist_mode="direct")
-    assert mu_r.shape == (5,)  # smoke: the oracle itself runs at 2000 in seconds
-
-
 @pytest.mark.parametrize("two_outputs,lin,hetero,n", [(True, True, True, 90), (False, True, False, 300), (True, False, False, 200)])
 def test_additive_model_matches_oracle(gpu, two_outputs, lin, hetero, n):
     """specify_model(additive=True) (pymc/GP.py:732-754): a global kernel plus one kernel per categorical
@@ -437,11 +330,3 @@ def test_additive_model_matches_oracle(gpu, two_outputs, lin, hetero, n):
     val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
     assert np.isclose(val, val_r, rtol=1e-10)
     assert np.max(np.abs(g - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
-    # sharded gradient (multi-GPU contract) covers the per-term accumulator regions too
-    acc = 0.0
-    for sh in range(2):
-        eng.factorize()
-        acc = acc + eng.nlml_shard(sh, 2)
-    eng.factorize()
-    _, g2 = eng.nlml_from_acc(acc)
-    assert np.max(np.abs(g2 - g)) < 1e-10 * max(1.0, np.max(np.abs(g)))
