@@ -1,30 +1,31 @@
 #!/usr/bin/env python
 """Headline benchmark: GP fit + predict on synthetic N x d fp64 tables (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1] [--map-evals E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1|c5] [--map-evals E]
 
-A *step* is one pass of the hot path the reference reaches through ``gp.fit()`` +
-``gp.predict_grid()``, with the inputs already resident in HBM:
+One GPU (default; BASELINE.json configs[2] = C3, the largest single-GPU configuration: N = 50k, d = 8,
+Matern-5/2 ARD, M = 10^4 grid).  A *step* is one pass of the hot path the reference reaches through
+``gp.fit()`` + ``gp.predict_grid()``, inputs already resident in HBM:
 
-    find_MAP  -- L-BFGS-B on -(log-lik + log-priors + log-Jacobians); every objective / gradient
-                 evaluation = covariance build -> Cholesky -> v = L^-1 y, log-det ->
-                 L^-1, Sigma^-1, fused trace reductions                  (all in libgumbi_hip.so)
-    refactor at the MAP, predict mean / variance on the M-point grid     (libgumbi_hip.so)
+    find_MAP  -- L-BFGS-B on -(log-lik + log-priors); every objective / gradient evaluation = covariance
+                 build -> Cholesky -> v = L^-1 y, log-det -> L^-T, Sigma^-1, fused trace reductions
+    refactor at the MAP, predict mean / variance on the M-point grid                (all in libgumbi_hip.so)
 
-The default workload is BASELINE.json configs[1]: N = 10k, d = 4, RBF-ARD, fp64, M = 10^4 grid
-(100 x 100 over dims 0,1; other dims pinned at 0).  ``value`` = algorithmic GFLOP/s of the whole
-step; ``ms_per_step`` is the fit + predict wall time.  One JSON line is printed by rank 0.
+``value`` = algorithmic GFLOP/s of the whole step; ``ms_per_step`` = fit + predict wall time.  The same JSON
+line carries: ``roofline`` (the Cholesky's trailing-update SYRK/GEMM launches alone -- the kernel the north
+star's MFMA target is stated on -- from per-launch HIP events of one extra step, plus the same figure over
+every GEMM launch), ``kbuild`` (HBM GB/s of the covariance build), ``phases``, ``end_to_end`` (the user-level
+``DataSet -> GP.fit() -> prepare_grid() -> predict_grid()`` wall time, host transfers included),
+``c5_single_gpu`` (the N = 100k problem of the multi-GPU runs on this one GPU: their strong-scaling base) and
+``cpu_baseline`` (the oracle on a bounded sample on the host cores).
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) the timed
-workload shards by independent GPs: every rank runs the same MAP fit + prediction on its own GPU
-(the cross-validation / per-category refit pattern, SURVEY.md section 8e last row) -- weak
-scaling, no data-path collective; the barrier / max-over-ranks timing contract is kept.
-In the same invocation, OUTSIDE the timed steps, the block-cyclic multi-GPU Cholesky
-(gumbi_amd/distributed.py: diagonal-block broadcast + panel all-gather on RCCL) factors ONE large
-covariance matrix (N = 40,960, d = 8, RBF-ARD, fixed hyper-parameters) across all ranks and
-predicts a 10^4 grid sharded over the ranks; its wall time and rate are reported under
-"distributed" in the same JSON line (at --gpus 1 the same problem runs on the single-GPU engine,
-which gives the strong-scaling baseline).  GUMBI_BENCH_NO_DIST=1 skips that section.
+Several GPUs (``--gpus N``, launched by torch.distributed.run, one rank per GPU): ONE GP -- BASELINE.json
+configs[4] = C5, N = 100k, d = 8, RBF-ARD -- factored block-cyclically over all ranks by the native driver
+(gumbi_amd/csrc/dist_driver.hpp; all-gathers on RCCL over xGMI), hyper-parameters fixed.  A step = one MAP
+objective + gradient evaluation (factorise + row-partitioned gradient) + re-factorisation (``fit`` at fixed
+theta) + prediction of the 10^4 grid sharded over the ranks; the three parts are reported separately under
+``phases``; ``scaling`` is "strong" (the same problem at every N; ``python bench.py --config c5`` is its N = 1
+point).  The barrier / max-over-ranks timing contract is the same.
 """
 import argparse
 import json
@@ -47,7 +48,13 @@ CONFIGS = {
     "c1": dict(N=392, d=1, kernel="ExpQuad", res=100, label="C1-like synthetic N=392 d=1 RBF"),
     "c2": dict(N=10_000, d=4, kernel="ExpQuad", res=100, label="synthetic N=10k d=4 RBF-ARD fp64, M=10^4 grid"),
     "c3": dict(N=50_000, d=8, kernel="Matern52", res=100, label="synthetic N=50k d=8 Matern-5/2 ARD fp64, M=10^4 grid"),
+    "c5": dict(N=100_000, d=8, kernel="ExpQuad", res=100,
+               label="synthetic N=100k d=8 RBF-ARD fp64, fixed theta, M=10^4 grid, ONE GP block-cyclic over the GPUs"),
 }
+# test hook: shrink the one-GP problem (the contract tests run it on a shared GPU in seconds)
+if os.environ.get("GUMBI_BENCH_DIST_N"):
+    CONFIGS["c5"]["N"] = int(os.environ["GUMBI_BENCH_DIST_N"])
+    CONFIGS["c5"]["label"] = CONFIGS["c5"]["label"].replace("N=100k", f"N={CONFIGS['c5']['N']}")
 
 
 def synthetic_table(N, d, seed=2021, sigma=0.2):
@@ -71,8 +78,7 @@ def synthetic_grid(d, res=100, lim=2.4):
     return Xs
 
 
-def build_gp(cfg, device):
-    """Front-end objects exactly as a Gumbi user builds them (DataSet -> GP -> build_model)."""
+def make_dataset(cfg):
     import pandas as pd
 
     import gumbi_amd as gmb
@@ -81,7 +87,14 @@ def build_gp(cfg, device):
     cols = [f"x{k}" for k in range(cfg["d"])]
     df = pd.DataFrame(X, columns=cols)
     df["y"] = y
-    ds = gmb.DataSet(df, outputs=["y"])
+    return gmb.DataSet(df, outputs=["y"]), cols
+
+
+def build_gp(cfg, device):
+    """Front-end objects exactly as a Gumbi user builds them (DataSet -> GP -> build_model)."""
+    import gumbi_amd as gmb
+
+    ds, cols = make_dataset(cfg)
     gp = gmb.GP(ds, outputs=["y"], device=device)
     gp.specify_model(continuous_dims=cols)
     gp.build_model(continuous_kernel=cfg["kernel"])
@@ -95,11 +108,11 @@ def step_flops(N, M, n_eval):
     return n_eval * n3 + n3 / 3.0 + float(N) ** 2 * M + 4.0 * N * M
 
 
-def pmc_traffic(config):
-    """HBM bytes per GEMM launch from the committed rocprofv3 PMC summary of this same bench command
-    (profiles/*_pmc_bench_<config>_summary.csv, made by tools/gpu_pmc_bench.sh: separate --pmc
-    passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950, WRITE_SIZE as counted).  None when no summary is committed."""
+def pmc_traffic(config, kernel_filter):
+    """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC summary of this same bench
+    command (profiles/*_pmc_bench_<config>_summary.csv, made by tools/gpu_pmc_bench.sh: separate --pmc passes
+    for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
+    WRITE_SIZE as counted).  None when no summary is committed."""
     import csv
     import glob
 
@@ -109,7 +122,7 @@ def pmc_traffic(config):
     launches, gbytes = 0, 0.0
     with open(files[-1]) as fh:
         for row in csv.DictReader(fh):
-            if "gemm_f64" in row["Kernel"]:
+            if kernel_filter in row["Kernel"]:
                 launches += int(row["Launches"])
                 gbytes += float(row["FetchGB(x2 corrected)"]) + float(row["WriteGB(raw)"])
     if launches == 0:
@@ -166,136 +179,97 @@ def cpu_baseline(cfg, target_seconds=20.0):
     }
 
 
-DIST_N, DIST_D = int(os.environ.get("GUMBI_BENCH_DIST_N", "40960")), 8  # the env override is for the tests
+def roofline_block(tm, config):
+    """``roofline`` from the engine's per-launch HIP events (gmb_timings, cumulative since profiling was
+    switched on): the trailing-update launches of the Cholesky alone, and every GEMM launch beside it."""
+    chol_tf = tm["total_chol_gemm_flops"] / max(tm["total_chol_gemm_ms"], 1e-9) / 1e9
+    all_tf = tm["total_gemm_flops"] / max(tm["total_gemm_ms"], 1e-9) / 1e9
+    n_chol = max(int(tm["total_chol_gemm_launches"]), 1)
+    out = {
+        "bound": "mfma",
+        "kernel": "gemm_f64_kernel, the Cholesky's trailing-update launches (v_mfma_f64_16x16x4_f64 SYRK/GEMM)",
+        "achieved": round(chol_tf, 3),
+        "peak": FP64_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(chol_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+        "traffic": None,
+        "measured_over": "one extra step of the same workload after the timed region (per-launch HIP events on the "
+                         "launch's own stream)",
+        "launches": int(tm["total_chol_gemm_launches"]),
+        "avg_launch_ms": round(tm["total_chol_gemm_ms"] / n_chol, 5),
+        "flops_per_launch": round(tm["total_chol_gemm_flops"] / n_chol, 1),
+        # launches of the look-ahead schedule's two streams overlap: the same flops over the WALL time with at
+        # least one of these launches in flight (union of the launch intervals)
+        "achieved_over_wall_time": round(tm["total_chol_gemm_flops"] / max(tm.get("total_chol_gemm_wall_ms", 0.0), 1e-9) / 1e9, 3),
+        "all_gemm_launches": {  # trailing updates + triangular solves + inverse + Sigma^-1 + predict
+            "achieved": round(all_tf, 3),
+            "frac": round(all_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+            "launches": int(tm["total_gemm_launches"]),
+            "avg_launch_ms": round(tm["total_gemm_ms"] / max(tm["total_gemm_launches"], 1), 5),
+            "flops_per_launch": round(tm["total_gemm_flops"] / max(tm["total_gemm_launches"], 1), 1),
+            "achieved_over_wall_time": round(tm["total_gemm_flops"] / max(tm.get("total_gemm_wall_ms", 0.0), 1e-9) / 1e9, 3),
+        },
+    }
+    if tm.get("masked_gemm_flops", 0.0) > 0.0:
+        # trailing updates of the masked look-ahead schedule run on masked_cus of the chip's compute units BY
+        # DESIGN (the rest serves the concurrent panel chain): their share and rate are reported separately
+        ncu = 256
+        mtf = tm["masked_gemm_flops"] / max(tm["masked_gemm_ms"], 1e-9) / 1e9
+        out["cu_masked_launches"] = {
+            "compute_units": int(tm["masked_cus"]), "of": ncu,
+            "flops_share": round(tm["masked_gemm_flops"] / tm["total_gemm_flops"], 4),
+            "achieved": round(mtf, 3),
+            "frac_of_their_share_of_peak": round(mtf / (FP64_MFMA_PEAK_TFLOPS * tm["masked_cus"] / ncu), 4),
+        }
+    pt = pmc_traffic(config, "gemm_f64")
+    if pt is not None:
+        out["traffic"] = round(pt["bytes_per_launch"], 1)
+        out["traffic_unit"] = "HBM bytes per gemm_f64 launch (2*FETCH_SIZE + WRITE_SIZE)"
+        out["traffic_source"] = pt["source"]
+    return out
 
 
-def distributed_section(world, local_rank, dist):
-    """Fixed-theta fit (K-build + Cholesky + v + NLML), a sharded grid prediction and one MAP
-    objective+gradient evaluation of ONE N = 40,960 GP over all ranks; max-over-ranks wall time."""
-    import torch
+def kbuild_block(tm):
+    kb_gbs = tm["total_kbuild_bytes"] / max(tm["total_kbuild_ms"], 1e-9) / 1e6
+    return {"bound": "hbm", "kernel": "cov_tile_kernel (lower-triangle covariance build)", "achieved": round(kb_gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb_gbs / HBM_PEAK_GBS, 4),
+            "launches": int(tm["total_kbuild_launches"]),
+            "bytes_per_launch": round(tm["total_kbuild_bytes"] / max(tm["total_kbuild_launches"], 1), 1)}
 
-    from gumbi_amd import engine as E
 
-    N, d = DIST_N, DIST_D
-    X, y, ls = synthetic_table(N, d)
-    Xs = synthetic_grid(d, 100)
-    theta = np.concatenate([ls, [1.0, 0.2]])
-    spec = E.KernelSpec(D=d, idx_cont=list(range(d)), kind="ExpQuad")
-    if world == 1:
-        eng = E.Engine(local_rank)
-        predict = lambda: eng.predict(Xs)  # noqa: E731
-    else:
-        from gumbi_amd.distributed import DistributedEngine
+class Clock:
+    """barrier + device synchronisation on both sides of a timed region; max over ranks."""
 
-        eng = DistributedEngine(local_rank)
-        predict = lambda: eng.predict(Xs)  # noqa: E731
-    eng.set_data(X, y)
-    eng.set_kernel(spec)
-    eng.set_theta(theta)
+    def __init__(self, dist, dev):
+        self.dist, self.dev = dist, dev
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
+    def sync(self):
+        import torch
+
+        if self.dist is not None:
+            self.dist.barrier()
         torch.cuda.synchronize()
 
-    eng.factorize()  # warm-up (allocations, code objects, RCCL channels)
-    eng.nlml(grad=True)  # ... including the gradient's N^2 workspace
-    sync()
-    t0 = time.perf_counter()
-    eng.factorize()
-    nlml = eng.nlml()
-    sync()
-    t1 = time.perf_counter()
-    mu, var = predict()
-    sync()
-    t2 = time.perf_counter()
-    # one MAP objective + gradient evaluation of the same GP (what find_MAP repeats): factorisation,
-    # replicated L^-1, sharded Sigma^-1 + trace reductions, all-reduce of the accumulators
-    eng.factorize()
-    val, grad = eng.nlml(grad=True)
-    sync()
-    t3 = time.perf_counter()
-    on_dev = dist is None or dist.get_backend() == "nccl"
-    times = torch.tensor([t1 - t0, t2 - t1, t3 - t2], dtype=torch.float64,
-                         device=torch.device("cuda", local_rank) if on_dev else "cpu")
-    if dist is not None:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    fit_s, pred_s, eval_s = (float(v) for v in times.cpu())
-    eng.close()
-    flops_fit = float(N) ** 3 / 3.0
-    flops_pred = float(N) ** 2 * len(Xs)
-    return {
-        "workload": f"ONE GP, N={N}, d={d}, RBF-ARD fp64, fixed theta; block-cyclic rows over {world} GPU(s)",
-        "fit_fixed_theta_s": round(fit_s, 4),
-        "predict_s": round(pred_s, 4),
-        "fit_tflops": round(flops_fit / fit_s / 1e12, 2),
-        "predict_tflops": round(flops_pred / pred_s / 1e12, 2),
-        "map_eval_s": round(eval_s, 4),
-        "map_eval_tflops": round(float(N) ** 3 / eval_s / 1e12, 2),
-        "grad_finite": bool(np.all(np.isfinite(grad))),
-        "nlml": float(nlml),
-        "results_finite": bool(np.all(np.isfinite(mu)) and np.all(var > 0)),
-    }
+    def max_over_ranks(self, values):
+        import torch
+
+        if self.dist is None:
+            return [float(v) for v in values]
+        on_dev = self.dist.get_backend() == "nccl"
+        t = torch.tensor(list(values), dtype=torch.float64, device=self.dev if on_dev else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
 
 
-def run_with_deadline(fn, seconds):
-    """fn() on a helper thread; (result, finished).  A collective that never completes (a peer
-    died, a link is down) must not take the headline line with it: the caller prints what it has
-    and leaves with os._exit."""
-    import threading
-
-    box = {}
-
-    def target():
-        try:
-            box["value"] = fn()
-        except Exception as err:  # never lose the headline line to the side measurement
-            box["value"] = {"error": f"{type(err).__name__}: {err}"[:300]}
-
-    th = threading.Thread(target=target, daemon=True)
-    th.start()
-    th.join(seconds)
-    if th.is_alive():
-        return {"error": f"no result after {seconds:.0f} s (collective did not complete)"}, False
-    return box["value"], True
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--map-evals", type=int, default=0,
-                    help="cap on L-BFGS objective evaluations per fit (0 = run to convergence, cap 200)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    cfg = CONFIGS[args.config]
-
-    dist = None
+# -----------------------------------------------------------------------------------------------------
+# workload A: MAP fit + grid prediction of one table on ONE GPU (C1 / C2 / C3)
+# -----------------------------------------------------------------------------------------------------
+def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clock):
     import torch
 
-    if os.environ.get("GUMBI_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0  # test hook: several ranks share GPU 0 (needs GUMBI_BENCH_BACKEND=gloo)
-    if world > 1:
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        backend = os.environ.get("GUMBI_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    from gumbi_amd import engine
-
-    if engine.device_count() < 1:
-        raise SystemExit("bench.py needs an MI355X: libgumbi_hip has no CPU fallback")
+    t_build = time.perf_counter()
     gp = build_gp(cfg, device=local_rank)
+    t_build = time.perf_counter() - t_build
     eng = gp.engine
     Xs = synthetic_grid(cfg["d"], cfg["res"])
     M = len(Xs)
@@ -304,28 +278,22 @@ def main():
     mean_dev = torch.empty(M, dtype=torch.float64, device=dev)
     var_dev = torch.empty(M, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
-    maxeval = args.map_evals if args.map_evals > 0 else 200
+    maxeval = map_evals if map_evals > 0 else 200
 
     def one_step():
         gp.find_MAP(maxeval=maxeval)
         eng.predict_device(xs_dev.data_ptr(), M, cfg["d"], mean_dev.data_ptr(), var_dev.data_ptr(), True)
         return gp.n_eval
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
-    barrier()
+    clock.sync()
     t0 = time.perf_counter()
-    n_evals = [one_step() for _ in range(args.steps)]
-    barrier()
+    n_evals = [one_step() for _ in range(steps)]
+    clock.sync()
     elapsed = time.perf_counter() - t0
-    # Roofline pass: ONE more step of the same workload with a HIP event pair around every GEMM
-    # launch (on the stream it is launched on).  Kept out of the timed region above: ~900 event
-    # pairs per MAP evaluation cost 3.5 ms of host time per evaluation (+13 % on the step).
+    # Roofline pass: ONE more step of the same workload with a HIP event pair around every GEMM launch (on
+    # the stream it is launched on).  Kept out of the timed region: event pairs cost host time per launch.
     eng.set_profiling(True)  # resets the totals
     one_step()
     torch.cuda.synchronize()
@@ -349,6 +317,7 @@ def main():
         eng.nlml(grad=True)
 
     phases = {
+        "specify_plus_build_model_s": round(t_build, 3),  # DataSet -> specify_model -> build_model (ls priors, H2D copy)
         "factorize_ms": wall_ms(eng.factorize),          # K-build + Cholesky + L^-1 y + log-det
         "factorize_plus_gradient_ms": wall_ms(fact_then_grad),  # one MAP objective evaluation
     }
@@ -356,108 +325,264 @@ def main():
     phases["predict_ms"] = wall_ms(lambda: eng.predict_device(xs_dev.data_ptr(), M, cfg["d"], mean_dev.data_ptr(),
                                                                 var_dev.data_ptr(), True))
     phases["ls_limits_ms"] = wall_ms(lambda: gp._prepare_lengthscales(gp.model.X, ARD=True))
+    N = cfg["N"]
+    phases["rates_tflops"] = {
+        "factorize": round(N**3 / 3.0 / phases["factorize_ms"] / 1e9, 2),
+        "map_evaluation": round(float(N) ** 3 / phases["factorize_plus_gradient_ms"] / 1e9, 2),
+        "predict": round(float(N) ** 2 * M / phases["predict_ms"] / 1e9, 2),
+    }
     phases["profiled_last_evaluation_ms"] = {k: round(tm[k], 3) for k in
                                              ("kbuild_ms", "chol_ms", "chol_leaf_ms", "chol_trsm_ms", "chol_gemm_ms",
                                               "grad_ms", "grad_gemm_ms", "predict_ms", "predict_gemm_ms")}
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     mean_host = mean_dev.cpu().numpy()
     var_host = var_dev.cpu().numpy()
     finite = bool(np.all(np.isfinite(mean_host)) and np.all(var_host > 0))
-    # the headline engine's streams go away before the distributed section creates its own: more
-    # than four live HIP streams per process slow every kernel down on this stack
+    # the engine's streams go away before any other section creates its own: more than four live HIP
+    # streams per process slow every kernel down on this stack
     eng.close()
     gp.engine = None
+    return dict(elapsed=elapsed, n_evals=n_evals, M=M, tm=tm, phases=phases, finite=finite,
+                flops=sum(step_flops(N, M, n) for n in n_evals))
 
-    dist_info, healthy = None, True
-    if os.environ.get("GUMBI_BENCH_NO_DIST") != "1" and args.config == "c2":
+
+def end_to_end_fit(cfg, local_rank, map_evals):
+    """The user-level call sequence of the reference (DataSet -> GP.fit -> prepare_grid -> predict_grid), wall
+    clock, once: host-side plumbing, lengthscale priors, host -> device copies and result wrapping included."""
+    import gumbi_amd as gmb
+
+    t0 = time.perf_counter()
+    ds, cols = make_dataset(cfg)
+    t1 = time.perf_counter()
+    gp = gmb.GP(ds, outputs=["y"], device=local_rank)
+    gp.fit(continuous_dims=cols, continuous_kernel=cfg["kernel"], MAP_kwargs={"maxeval": map_evals if map_evals > 0 else 200})
+    t2 = time.perf_counter()
+    if cfg["d"] > 2:
+        gp.prepare_grid(at=gp.parray(**{c: 0.0 for c in cols[2:]}, stdzd=True), resolution=cfg["res"])
+    else:
+        gp.prepare_grid(resolution=cfg["res"])
+    pred = gp.predict_grid()
+    t3 = time.perf_counter()
+    ok = bool(np.all(np.isfinite(np.asarray(pred.μ))))
+    gp.engine.close()
+    gp.engine = None
+    return {"dataset_s": round(t1 - t0, 3), "fit_s": round(t2 - t1, 3), "prepare_and_predict_grid_s": round(t3 - t2, 3),
+            "total_s": round(t3 - t0, 3), "map_evals": int(gp.n_eval), "results_finite": ok,
+            "note": "gp.fit() = specify_model + build_model + find_MAP, host <-> device transfers included"}
+
+
+# -----------------------------------------------------------------------------------------------------
+# workload B: ONE GP at fixed hyper-parameters over `world` GPUs (C5)
+# -----------------------------------------------------------------------------------------------------
+def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock):
+    import torch
+
+    from gumbi_amd import engine as E
+
+    N, d = cfg["N"], cfg["d"]
+    X, y, ls = synthetic_table(N, d)
+    Xs = synthetic_grid(d, cfg["res"])
+    M = len(Xs)
+    theta = np.concatenate([ls, [1.0, 0.2]])
+    spec = E.KernelSpec(D=d, idx_cont=list(range(d)), kind=cfg["kernel"])
+    if world == 1:
+        eng = E.Engine(local_rank)
+        transport = "single engine"
+    else:
+        from gumbi_amd.distributed import DistributedEngine
+
+        eng = DistributedEngine(local_rank)
+        transport = eng.comm.kind
+    eng.set_data(X, y)
+    eng.set_kernel(spec)
+    eng.set_theta(theta)
+    part = {"map_eval": 0.0, "fit_fixed_theta": 0.0, "predict": 0.0}
+    last = {}
+
+    def one_step(record=False):
+        t0 = time.perf_counter()
+        eng.factorize()
+        val, grad = eng.nlml(grad=True)      # one MAP objective + gradient evaluation
+        t1 = time.perf_counter()
+        eng.factorize()                      # fit at fixed theta: K-build + Cholesky + v + log-det
+        nl = eng.nlml()
+        t2 = time.perf_counter()
+        mu, var = eng.predict(Xs)            # 10^4-point grid (sharded over the ranks)
+        t3 = time.perf_counter()
+        if record:
+            part["map_eval"] += t1 - t0
+            part["fit_fixed_theta"] += t2 - t1
+            part["predict"] += t3 - t2
+        last.update(val=val, grad=grad, nl=nl, mu=mu, var=var)
+
+    for _ in range(warmup):
+        one_step()
+    clock.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(record=True)
+    clock.sync()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(True)
+    one_step()
+    torch.cuda.synchronize()
+    tm = eng.timings()
+    eng.set_profiling(False)
+    eng.close()
+    per = clock.max_over_ranks([part["map_eval"] / steps, part["fit_fixed_theta"] / steps, part["predict"] / steps])
+    n3 = float(N) ** 3
+    phases = {
+        "map_eval_s": round(per[0], 4), "fit_fixed_theta_s": round(per[1], 4), "predict_s": round(per[2], 4),
+        "rates_tflops_whole_job": {"map_eval": round(n3 / per[0] / 1e12, 2), "fit_fixed_theta": round(n3 / 3.0 / per[1] / 1e12, 2),
+                                   "predict": round(float(N) ** 2 * M / per[2] / 1e12, 2)},
+        "profiled_last_step_ms_rank0": {k: round(tm[k], 3) for k in ("kbuild_ms", "chol_ms", "chol_gemm_ms", "grad_ms",
+                                                                      "grad_gemm_ms", "predict_ms")},
+        "nlml": float(last["nl"]),
+    }
+    finite = bool(np.all(np.isfinite(last["mu"])) and np.all(last["var"] > 0) and np.all(np.isfinite(last["grad"])))
+    return dict(elapsed=elapsed, M=M, tm=tm, phases=phases, finite=finite, transport=transport,
+                flops=steps * step_flops(N, M, 1))
+
+
+def run_with_deadline(fn, seconds):
+    """fn() on a helper thread; (result, finished).  A collective that never completes (a peer died, a
+    link is down) must not hang the run for ever: the caller prints what it has and leaves with os._exit."""
+    import threading
+
+    box = {}
+
+    def target():
+        try:
+            box["value"] = fn()
+        except Exception as err:
+            import traceback
+
+            box["value"] = {"error": f"{type(err).__name__}: {err}"[:400], "traceback": traceback.format_exc()[-1500:]}
+
+    th = threading.Thread(target=target, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": f"no result after {seconds:.0f} s (collective did not complete)"}, False
+    return box["value"], True
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: c3 on one GPU, c5 (ONE GP over all ranks) on several")
+    ap.add_argument("--map-evals", type=int, default=0,
+                    help="cap on L-BFGS objective evaluations per fit (0 = run to convergence, cap 200)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    config_name = args.config or ("c3" if world == 1 else "c5")
+    cfg = CONFIGS[config_name]
+    if world > 1 and config_name != "c5":
+        raise SystemExit("several GPUs run the one-GP workload: --config c5")
+
+    dist = None
+    import torch
+
+    if os.environ.get("GUMBI_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0  # test hook: several ranks share GPU 0 (needs GUMBI_BENCH_BACKEND=gloo)
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        backend = os.environ.get("GUMBI_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    from gumbi_amd import engine
+
+    if engine.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libgumbi_hip has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    clock = Clock(dist, dev)
+    healthy = True
+
+    if config_name == "c5":
         def section():
             torch.cuda.set_device(local_rank)  # the current device is per-thread state
-            return distributed_section(world, local_rank, dist)
+            return one_gp_workload(cfg, world, local_rank, dist, args.steps, args.warmup, clock)
 
-        dist_info, healthy = run_with_deadline(section, float(os.environ.get("GUMBI_BENCH_DIST_DEADLINE", "300")))
+        res, healthy = run_with_deadline(section, float(os.environ.get("GUMBI_BENCH_DEADLINE", "1500")))
+    else:
+        res = map_fit_workload(cfg, config_name, local_rank, args.steps, args.warmup, args.map_evals, clock)
 
-    flops_total = sum(step_flops(cfg["N"], M, n) for n in n_evals) * world
-
-    if rank == 0:
-        gemm_tf = tm["total_gemm_flops"] / max(tm["total_gemm_ms"], 1e-9) / 1e9
-        kb_gbs = tm["total_kbuild_bytes"] / max(tm["total_kbuild_ms"], 1e-9) / 1e6
-        out = {
-            "metric": "fit+predict achieved GFLOP/s (fp64 exact GP: MAP fit + grid prediction)",
-            "value": round(flops_total / elapsed / 1e9, 2),
-            "unit": "GFLOP/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": cfg["label"],
-                "N": cfg["N"], "d": cfg["d"], "kernel": cfg["kernel"], "M": M,
-                "map_evals_per_step": n_evals,
-                "parallelism": "1 GPU" if world == 1 else f"{world} independent GPs, one per GPU (no data-path collective)",
-            },
-            "fit_predict_seconds": round(elapsed / args.steps, 4),
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "gemm_f64_kernel (v_mfma_f64_16x16x4_f64 SYRK/GEMM: Cholesky trailing update, "
-                          "triangular solves, inverse)",
-                "achieved": round(gemm_tf, 3),
-                "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(gemm_tf / FP64_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
-                "measured_over": "one extra step of the same workload after the timed region (per-launch HIP events)",
-                "launches": int(tm["total_gemm_launches"]),
-                "avg_launch_ms": round(tm["total_gemm_ms"] / max(tm["total_gemm_launches"], 1), 5),
-                "flops_per_launch": round(tm["total_gemm_flops"] / max(tm["total_gemm_launches"], 1), 1),
-                # launches of the look-ahead schedule's two streams overlap: the same flops over the WALL time
-                # with at least one GEMM launch in flight (union of the launch intervals)
-                "achieved_over_wall_time": round(tm["total_gemm_flops"] / max(tm.get("total_gemm_wall_ms", 0.0), 1e-9) / 1e9, 3),
-            },
-            "kbuild": {
-                "bound": "hbm", "achieved": round(kb_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(kb_gbs / HBM_PEAK_GBS, 4), "launches": int(tm["total_kbuild_launches"]),
-            },
-            "results_finite": finite,
-            "phases": phases,
-        }
-        if tm.get("masked_gemm_flops", 0.0) > 0.0:
-            # trailing updates of the masked look-ahead schedule run on masked_cus of the chip's compute
-            # units BY DESIGN (the rest serves the concurrent panel chain): their share and rate are
-            # reported separately; `achieved` / `frac` above stay the plain all-launch figures
-            ncu = 256
-            mtf = tm["masked_gemm_flops"] / max(tm["masked_gemm_ms"], 1e-9) / 1e9
-            utf = (tm["total_gemm_flops"] - tm["masked_gemm_flops"]) / max(tm["total_gemm_ms"] - tm["masked_gemm_ms"], 1e-9) / 1e9
-            out["roofline"]["cu_masked_launches"] = {
-                "compute_units": int(tm["masked_cus"]), "of": ncu,
-                "flops_share": round(tm["masked_gemm_flops"] / tm["total_gemm_flops"], 4),
-                "achieved": round(mtf, 3),
-                "frac_of_their_share_of_peak": round(mtf / (FP64_MFMA_PEAK_TFLOPS * tm["masked_cus"] / ncu), 4),
-                "unmasked_achieved": round(utf, 3),
+    out = None
+    if "error" in res:
+        if rank == 0:
+            out = {"metric": "fit+predict achieved GFLOP/s (fp64 exact GP)", "value": None, "unit": "GFLOP/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": cfg["label"]}, "error": res}
+    else:
+        (elapsed,) = clock.max_over_ranks([res["elapsed"]]) if healthy else (res["elapsed"],)
+        if rank == 0:
+            tm = res["tm"]
+            out = {
+                "metric": "fit+predict achieved GFLOP/s (fp64 exact GP: MAP fit + grid prediction)" if config_name != "c5"
+                          else "fit+predict achieved GFLOP/s (fp64 exact GP: one MAP evaluation + fit at fixed theta + grid prediction)",
+                "value": round(res["flops"] / elapsed / 1e9, 2),
+                "unit": "GFLOP/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                "higher_is_better": True,
+                "scaling": "strong" if config_name == "c5" else "weak",
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic",
+                "config": {
+                    "workload": cfg["label"],
+                    "N": cfg["N"], "d": cfg["d"], "kernel": cfg["kernel"], "M": res["M"],
+                    "parallelism": "1 GPU" if world == 1 else
+                                   f"ONE GP, 128-row blocks dealt block-cyclically over {world} GPUs; panel all-gathers: {res['transport']}",
+                },
+                "fit_predict_seconds": round(elapsed / args.steps, 4),
+                "roofline": roofline_block(tm, config_name),
+                "kbuild": kbuild_block(tm),
+                "results_finite": res["finite"],
+                "phases": res["phases"],
             }
-        pt = pmc_traffic(args.config)
-        if pt is not None:
-            out["roofline"]["traffic"] = round(pt["bytes_per_launch"], 1)
-            out["roofline"]["traffic_unit"] = "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)"
-            out["roofline"]["traffic_source"] = pt["source"]
-        try:
-            tf, cyc = engine.mfma_f64_peak(local_rank)
-            out["roofline"]["mfma_only_microbench_tflops"] = round(tf, 2)  # sustained ceiling under DVFS
-        except Exception:
-            pass
-        if dist_info is not None:
-            out["distributed"] = dist_info
-        if not args.no_cpu_baseline and world == 1 and os.environ.get("GUMBI_BENCH_NO_CPU") != "1":
+            if "n_evals" in res:
+                out["config"]["map_evals_per_step"] = res["n_evals"]
+            try:
+                tf, cyc = engine.mfma_f64_peak(local_rank)
+                out["roofline"]["mfma_only_microbench_tflops"] = round(tf, 2)  # sustained ceiling under DVFS
+            except Exception:
+                pass
+
+    # side sections of the one-GPU run (outside the timed steps)
+    if world == 1 and out is not None and "error" not in out and config_name != "c5":
+        if os.environ.get("GUMBI_BENCH_NO_E2E") != "1":
+            try:
+                out["end_to_end"] = end_to_end_fit(cfg, local_rank, args.map_evals)
+            except Exception as err:
+                out["end_to_end"] = {"error": f"{type(err).__name__}: {err}"[:300]}
+        if os.environ.get("GUMBI_BENCH_NO_DIST") != "1":
+            def c5_side():
+                torch.cuda.set_device(local_rank)
+                r = one_gp_workload(CONFIGS["c5"], 1, local_rank, None, 2, 1, clock)
+                return {"workload": CONFIGS["c5"]["label"], "note": "strong-scaling base of the multi-GPU runs (python bench.py --config c5)",
+                        "value": round(r["flops"] / r["elapsed"] / 1e9, 2), "unit": "GFLOP/s", "steps": 2, "warmup": 1,
+                        "ms_per_step": round(1e3 * r["elapsed"] / 2, 3), "phases": r["phases"], "results_finite": r["finite"],
+                        "trailing_update_tflops": roofline_block(r["tm"], "c5")["achieved"]}
+
+            out["c5_single_gpu"], _ = run_with_deadline(c5_side, 900.0)
+        if not args.no_cpu_baseline and os.environ.get("GUMBI_BENCH_NO_CPU") != "1":
             out["cpu_baseline"] = cpu_baseline(cfg)
+    if rank == 0 and out is not None:
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if dist is not None:
         def leave():
@@ -470,7 +595,7 @@ def main():
         if not healthy:
             sys.stderr.write(f"[bench rank {rank}] leaving without the final barrier\n")
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(0 if out is None or "error" not in out else 1)
 
 
 if __name__ == "__main__":

@@ -106,14 +106,15 @@ int dist_pack(gmb_engine* e, hipStream_t st, double* mat, int64_t ld, double* pa
   a.seg_elems = seg_elems;
   a.ncols = ncols;
   a.to_packed = to_packed ? 1 : 0;
-  a.nseg = nseg;
+  a.nseg = nseg > 0 ? nseg : 1;
+  a.by_rank = nseg > 0 ? 1 : 0;  // nseg = 0: this rank's own rows (first, count); nseg = G: the receive side
   a.first = first;
   a.count = count;
   a.stride = stride;
   a.lo = lo;
   a.hi = hi;
-  if (nseg == 1 && count <= 0) return GMB_OK;
-  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)(nseg == 1 ? count : maxcount), (unsigned)((ncols + 3) / 4), (unsigned)nseg),
+  if (!a.by_rank && count <= 0) return GMB_OK;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)(a.by_rank ? maxcount : count), (unsigned)((ncols + 3) / 4), (unsigned)a.nseg),
                      dim3(256), 0, st, a);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -192,7 +193,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       case DIST_SQUARE: {
         double* cols = e->dA + (int64_t)s.c0 * TILE * e->ld;  // column block c0 of the factor buffer
         const int64_t ldp = (int64_t)s.maxcount * TILE;
-        if ((rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, true, 1, s.first, s.count, G, 0, 0, s.maxcount))) break;
+        if ((rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, true, 0, s.first, s.count, G, 0, 0, s.maxcount))) break;
         if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems))) break;
         if ((rc = dist_pack(e, mainS, cols, e->ld, e->drecv, ldp, s.elems, (int)W, false, G, 0, 0, G, s.lo, s.hi, s.maxcount))) break;
         e->cur = mainS;
@@ -202,7 +203,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       case DIST_PANEL: {
         double* cols = e->dA + (int64_t)s.c0 * TILE * e->ld;
         const int64_t ldp = (int64_t)s.maxcount * TILE;
-        if ((rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, true, 1, s.first, s.count, G, 0, 0, s.maxcount))) break;
+        if ((rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, true, 0, s.first, s.count, G, 0, 0, s.maxcount))) break;
         e->cur = mainS;
         if (s.count > 0 &&
             (rc = trsm_cols(e, e->dsend - (int64_t)s.c0 * TILE * ldp, ldp, s.count, s.c0, s.c1, 2, 5)))
@@ -352,7 +353,7 @@ int dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
     // columns [k0, k1) go into the upper triangle of every rank's factor buffer
     const int ncols = (k1 - k0) * TILE;
     const int64_t ldp = (int64_t)mc * TILE, elems = ldp * ncols;
-    if ((rc = dist_pack(e, commS, V + (int64_t)k0 * TILE * ldv, ldv, e->dsend, ldp, 0, ncols, true, 1, 0, mine, 1, 0, 0, mc))) return rc;
+    if ((rc = dist_pack(e, commS, V + (int64_t)k0 * TILE * ldv, ldv, e->dsend, ldp, 0, ncols, true, 0, 0, mine, 1, 0, 0, mc))) return rc;
     if ((rc = dist_all_gather(e, comm, commS, e->dsend, e->drecv, elems))) return rc;
     if ((rc = dist_pack(e, commS, e->dA + (int64_t)k0 * TILE * e->ld, e->ld, e->drecv, ldp, elems, ncols, false, G, 0, 0, G, 0, k1, mc))) return rc;
   }

@@ -266,27 +266,31 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
   // intervals on the device timeline): launches of the two streams of the look-ahead schedules
   // overlap, so the SUM of their durations exceeds the time they cover.
   if (!e->evs.empty()) {
-    std::vector<std::pair<float, float>> iv;
-    for (auto& p : e->evs)
-      if (p.kind == 0 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
-        float ta = 0.f, tb = 0.f;
-        if (hipEventElapsedTime(&ta, e->evs[0].a, p.a) == hipSuccess && hipEventElapsedTime(&tb, e->evs[0].a, p.b) == hipSuccess)
-          iv.emplace_back(ta, tb);
+    auto interval_union = [&](auto pick) {
+      std::vector<std::pair<float, float>> iv;
+      for (auto& p : e->evs)
+        if (pick(p.kind)) {
+          float ta = 0.f, tb = 0.f;
+          if (hipEventElapsedTime(&ta, e->evs[0].a, p.a) == hipSuccess && hipEventElapsedTime(&tb, e->evs[0].a, p.b) == hipSuccess)
+            iv.emplace_back(ta, tb);
+        }
+      std::sort(iv.begin(), iv.end());
+      float cur_lo = 0.f, cur_hi = -1.f;
+      double uni = 0.0;
+      for (auto& x : iv) {
+        if (cur_hi < cur_lo || x.first > cur_hi) {
+          if (cur_hi >= cur_lo) uni += cur_hi - cur_lo;
+          cur_lo = x.first;
+          cur_hi = x.second;
+        } else if (x.second > cur_hi) {
+          cur_hi = x.second;
+        }
       }
-    std::sort(iv.begin(), iv.end());
-    float cur_lo = 0.f, cur_hi = -1.f;
-    double uni = 0.0;
-    for (auto& x : iv) {
-      if (cur_hi < cur_lo || x.first > cur_hi) {
-        if (cur_hi >= cur_lo) uni += cur_hi - cur_lo;
-        cur_lo = x.first;
-        cur_hi = x.second;
-      } else if (x.second > cur_hi) {
-        cur_hi = x.second;
-      }
-    }
-    if (cur_hi >= cur_lo) uni += cur_hi - cur_lo;
-    e->tm.total_gemm_wall_ms += uni;
+      if (cur_hi >= cur_lo) uni += cur_hi - cur_lo;
+      return uni;
+    };
+    e->tm.total_gemm_wall_ms += interval_union([](int k) { return k == 0 || k == 2 || k == 3 || k == 4; });
+    e->tm.total_chol_gemm_wall_ms += interval_union([](int k) { return k == 0; });
   }
   for (auto& p : e->evs) {
     float t = 0.f;
@@ -306,6 +310,9 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
         e->tm.chol_gemm_ms += t;
         e->tm.chol_gemm_flops += p.flops;
         e->tm.chol_gemm_launches += 1;
+        e->tm.total_chol_gemm_ms += t;
+        e->tm.total_chol_gemm_flops += p.flops;
+        e->tm.total_chol_gemm_launches += 1;
         break;
       case 1: e->tm.chol_leaf_ms += t; break;
       case 2:
@@ -1611,6 +1618,8 @@ int gmb_set_profiling(gmb_engine* e, int32_t on) {
     e->tm.total_gemm_ms = e->tm.total_gemm_flops = 0.0;
     e->tm.masked_gemm_ms = e->tm.masked_gemm_flops = 0.0;
     e->tm.total_gemm_wall_ms = 0.0;
+    e->tm.total_chol_gemm_ms = e->tm.total_chol_gemm_flops = e->tm.total_chol_gemm_wall_ms = 0.0;
+    e->tm.total_chol_gemm_launches = 0;
     e->tm.masked_cus = e->aux_shared ? e->wg_slots / 2 - e->part_cus : 0;
     e->tm.total_gemm_launches = 0;
     e->tm.total_kbuild_ms = e->tm.total_kbuild_bytes = 0.0;

@@ -326,8 +326,8 @@ __global__ void reset_pad_cols_kernel(double* U, int64_t ld, int64_t n, int64_t 
 // b = q (mod G):
 //   packed[seg*seg_elems + (t*128 + r) + c*ldp]  <->  mat[(first(seg) + t*stride)*128 + r + c*ld],
 //   t < count(seg), r < 128, c < ncols.
-// One segment (nseg = 1: this rank packing its own rows; first / count given) or, for the receive side,
-// nseg = G segments in one launch: segment q holds the block rows of [lo, hi) that rank q owns, i.e.
+// One segment (by_rank = 0: this rank packing its own rows; first / count given) or, for the receive side,
+// by_rank = 1 with nseg = G segments in one launch: segment q holds the block rows of [lo, hi) that rank q owns, i.e.
 // first(q) = lo + ((q - lo) mod G), count(q) = ceil((hi - first(q)) / G).  16 bytes per lane.
 struct PackArgs {
   double* mat;
@@ -337,14 +337,15 @@ struct PackArgs {
   int64_t seg_elems;  // doubles between consecutive segments
   int32_t ncols;
   int32_t to_packed;
-  int32_t nseg;       // 1: (first, count) below; > 1: per-rank ownership of [lo, hi)
+  int32_t nseg;       // segments in the packed buffer (grid z)
+  int32_t by_rank;    // 0: one segment, (first, count) below; 1: segment q = rank q's block rows of [lo, hi)
   int32_t first, count, stride;
   int32_t lo, hi;
 };
 __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
   const int seg = blockIdx.z;
   int first = a.first, count = a.count;
-  if (a.nseg > 1) {
+  if (a.by_rank) {
     const int G = a.stride;
     first = a.lo + (((seg - a.lo) % G) + G) % G;
     count = first < a.hi ? (a.hi - first + G - 1) / G : 0;

@@ -76,6 +76,10 @@ class Timings(C.Structure):
         ("masked_gemm_flops", C.c_double),
         ("masked_cus", C.c_int64),
         ("total_gemm_wall_ms", C.c_double),
+        ("total_chol_gemm_ms", C.c_double),
+        ("total_chol_gemm_flops", C.c_double),
+        ("total_chol_gemm_launches", C.c_int64),
+        ("total_chol_gemm_wall_ms", C.c_double),
     ]
 
     def as_dict(self):

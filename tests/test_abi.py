@@ -37,7 +37,15 @@ def test_struct_layouts_match_header():
 
     # gmb_kernel_spec: 3 + 16 + 1 + 8 + 1 + 4 + 4 + 4 int32 (= 41), 4 bytes of padding, then one double
     assert engine.C.sizeof(engine._Spec) == 41 * 4 + 4 + 8
-    assert engine.C.sizeof(engine.Timings) == 25 * 8
+    # gmb_timings: every member is 8 bytes (double / int64_t) -- count them in the header, and compare names
+    header = (ROOT / "include" / "gumbi_hip.h").read_text()
+    body = re.search(r"typedef struct gmb_timings \{(.*?)\} gmb_timings;", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:double|int64_t)\s+([a-z_0-9]+)\s*;", body)
+    assert fields == [n for n, _ in engine.Timings._fields_]
+    assert engine.C.sizeof(engine.Timings) == 8 * len(fields) == 29 * 8
+    # gmb_comm {int32 rank, world; void* ctx; fn* all_gather} and gmb_dist_step {9 x int32, pad, int64}
+    assert engine.C.sizeof(engine.GmbComm) == 24 and engine.C.sizeof(engine.DistStep) == 48
     spec = engine.KernelSpec(D=6, idx_cont=[0, 1, 2], idx_lin=[1], coreg=[(3, 4)], out_col=5, n_out=2)
     cs = spec.to_c()
     assert (cs.n_cont, cs.n_lin, cs.n_coreg, cs.out_col, cs.n_out, cs.hetero_noise) == (3, 1, 1, 5, 2, 1)

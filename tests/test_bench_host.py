@@ -55,3 +55,28 @@ def test_step_flops_counts_cholesky_inverse_and_prediction():
     final = N**3 / 3 + float(N) ** 2 * M                # re-factorisation + N^2 M solve of the grid prediction
     got = bench.step_flops(N, M, n_eval)
     assert abs(got - (n_eval * per_eval + final)) / got < 0.02
+
+
+def test_roofline_block_is_the_trailing_update_alone():
+    """``roofline`` = algorithmic flops of the Cholesky's trailing-update launches / their summed launch
+    durations (frac = achieved / peak), with the all-launch figure beside it; ``kbuild`` in GB/s."""
+    bench = load_bench()
+    tm = {"total_chol_gemm_flops": 4.0e13, "total_chol_gemm_ms": 600.0, "total_chol_gemm_launches": 400,
+          "total_chol_gemm_wall_ms": 580.0, "total_gemm_flops": 1.6e14, "total_gemm_ms": 2500.0, "total_gemm_launches": 4000,
+          "total_gemm_wall_ms": 2400.0, "masked_gemm_flops": 0.0, "total_kbuild_bytes": 1.0e10, "total_kbuild_ms": 3.0,
+          "total_kbuild_launches": 1}
+    r = bench.roofline_block(tm, "no-such-config")
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert abs(r["achieved"] - 4.0e13 / 0.6 / 1e12) < 1e-3 and abs(r["frac"] - r["achieved"] / 78.6) < 1e-4
+    assert r["launches"] == 400 and abs(r["avg_launch_ms"] - 1.5) < 1e-9 and r["flops_per_launch"] == 1.0e11
+    assert r["traffic"] is None  # no PMC summary committed for that name
+    assert abs(r["all_gemm_launches"]["achieved"] - 64.0) < 1e-9
+    k = bench.kbuild_block(tm)
+    assert k["bound"] == "hbm" and k["unit"] == "GB/s" and abs(k["achieved"] - 1.0e10 / 3.0e-3 / 1e9) < 0.1
+
+
+def test_configs_name_the_baseline_workloads():
+    bench = load_bench()
+    assert bench.CONFIGS["c3"]["N"] == 50_000 and bench.CONFIGS["c3"]["d"] == 8 and bench.CONFIGS["c3"]["kernel"] == "Matern52"
+    assert bench.CONFIGS["c2"]["N"] == 10_000 and bench.CONFIGS["c2"]["d"] == 4
+    assert bench.CONFIGS["c5"]["d"] == 8 and bench.CONFIGS["c5"]["kernel"] == "ExpQuad"

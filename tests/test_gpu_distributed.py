@@ -11,6 +11,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _collect(out, n, timeout):
+    """n results from the workers' queue; a worker that died reports its traceback instead of a result."""
+    results = []
+    for _ in range(n):
+        r = out.get(timeout=timeout)
+        if isinstance(r, tuple) and r and r[0] == "error":
+            pytest.fail("worker failed:\n" + r[1])
+        results.append(r)
+    return results
+
+
 def _worker(rank, world, port, N, d, M, out, model="matern", panel=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -83,6 +94,11 @@ def _worker(rank, world, port, N, d, M, out, model="matern", panel=0):
                                / np.max(np.abs(v_ref))) * 1e-2)
         out.put((rank, err_L, err_v, err_nl, err_mu, err_var, err_g, g.tobytes()))
         eng.close()
+    except BaseException:
+        import traceback
+
+        out.put(("error", traceback.format_exc()[-3000:]))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -105,7 +121,7 @@ def test_two_ranks_one_gpu_match_oracle(gpu, world, N, model, panel):
     procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, 333, out, model, panel)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [out.get(timeout=300) for _ in range(world)]
+    results = _collect(out, world, 300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -152,6 +168,11 @@ def _large_worker(rank, world, port, N, d, out):
         errs.append(float(np.max(np.abs(a[5] - b[5])) / max(1.0, np.max(np.abs(b[5])))))
         ref = O.nlml(O.make_spec(d, range(d)), theta, X, y) if rank == 0 else a[4]
         out.put((rank, errs, abs(a[4] - ref) / abs(ref), a[5].tobytes()))
+    except BaseException:
+        import traceback
+
+        out.put(("error", traceback.format_exc()[-3000:]))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -169,7 +190,7 @@ def test_two_ranks_one_gpu_at_n_20k_match_the_single_engine(gpu):
     procs = [ctx.Process(target=_large_worker, args=(r, 2, port, 20_480, 4, out)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [out.get(timeout=900) for _ in range(2)]
+    results = _collect(out, 2, 900)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -213,6 +234,11 @@ def _fit_worker(rank, world, port, N, out):
         th_s, mu_s, var_s, n_s = fit(None)  # the same fit on this rank's GPU alone
         out.put((rank, float(np.max(np.abs(th_d - th_s) / np.maximum(np.abs(th_s), 1e-3))),
                  float(np.max(np.abs(mu_d - mu_s))), float(np.max(np.abs(var_d - var_s))), n_d, n_s, th_d.tobytes()))
+    except BaseException:
+        import traceback
+
+        out.put(("error", traceback.format_exc()[-3000:]))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -229,7 +255,7 @@ def test_distributed_map_fit_matches_single_gpu_fit(gpu):
     procs = [ctx.Process(target=_fit_worker, args=(r, world, port, 400, out)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [out.get(timeout=300) for _ in range(world)]
+    results = _collect(out, world, 300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -259,6 +285,11 @@ def _cv_worker(rank, world, port, out):
         gp.build_model()
         res = gp.cross_validate_replicas([11, 12, 13], pct_train=0.7)
         out.put((rank, [float(r["test"]["NLPDs"].mean()) for r in res], [len(r["train"]["data"].wide) for r in res]))
+    except BaseException:
+        import traceback
+
+        out.put(("error", traceback.format_exc()[-3000:]))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -278,7 +309,7 @@ def test_cross_validation_replicas_over_ranks(gpu):
     procs = [ctx.Process(target=_cv_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [out.get(timeout=300) for _ in range(2)]
+    results = _collect(out, 2, 300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -327,6 +358,11 @@ def _rccl_worker(out):
         out.put((dist.get_backend() + "/" + kind, abs(val - val_r) / abs(val_r), float(np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r)))),
                  float(np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))), float(np.max(np.abs(var - var_r)))))
         eng.close()
+    except BaseException:
+        import traceback
+
+        out.put(("error", traceback.format_exc()[-3000:]))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -342,7 +378,7 @@ def test_driver_on_the_rccl_backend_with_one_rank(gpu):
     out = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(out,))
     p.start()
-    backend, e_val, e_g, e_mu, e_var = out.get(timeout=300)
+    (backend, e_val, e_g, e_mu, e_var), = _collect(out, 1, 300)
     p.join(timeout=60)
     assert p.exitcode == 0
     assert backend == "nccl/rccl"
@@ -352,37 +388,44 @@ def test_driver_on_the_rccl_backend_with_one_rank(gpu):
 def test_bench_contract_with_two_ranks_on_one_gpu(gpu):
     """bench.py as the driver launches it for N > 1 (``python -m torch.distributed.run --nproc-per-node N
     bench.py --gpus N ...``), with both ranks on the test box's one GPU over gloo: rank 0 prints exactly ONE
-    JSON line with the contract's keys, n_gpus = 2, the replica workload and the distributed section."""
+    JSON line with the contract's keys, n_gpus = 2, and the workload is ONE GP partitioned over the ranks."""
     import json
     import subprocess
     import sys
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, GUMBI_BENCH_SINGLE_DEVICE="1", GUMBI_BENCH_BACKEND="gloo", GUMBI_BENCH_DIST_N="2304",
+    env = dict(os.environ, GUMBI_BENCH_SINGLE_DEVICE="1", GUMBI_BENCH_BACKEND="gloo", GUMBI_BENCH_DIST_N="3000",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "1",
-           "--warmup", "0", "--map-evals", "4"]
+           "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
+    assert "error" not in d, d
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
-    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
     assert d["value"] > 0 and d["results_finite"] and "cpu_baseline" not in d
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
-    dist = d["distributed"]
-    assert "error" not in dist, dist
-    assert dist["results_finite"] and dist["grad_finite"] and "2 GPU(s)" in dist["workload"]
+    assert "ONE GP" in d["config"]["workload"] and "over 2 GPUs" in d["config"]["parallelism"]
+    assert "torch-gloo" in d["config"]["parallelism"] and d["config"]["N"] == 3000
+    ph = d["phases"]
+    assert ph["map_eval_s"] > 0 and ph["fit_fixed_theta_s"] > 0 and ph["predict_s"] > 0 and np.isfinite(ph["nlml"])
+    # whole-job value = algorithmic flops of the steps / max-over-ranks wall time
+    N, M = 3000, 10_000
+    flops = 2 * (float(N) ** 3 + float(N) ** 3 / 3 + float(N) ** 2 * M + 4.0 * N * M)
+    assert abs(d["value"] - flops / (d["ms_per_step"] * 2e-3) / 1e9) / d["value"] < 1e-3
 
 
 def test_bench_contract_single_process(gpu):
-    """``python bench.py`` (N = 1): one JSON line with the contract's keys plus ``roofline``, ``cpu_baseline``
-    (here on a shortened sample) and the per-phase timings."""
+    """``python bench.py --config c2`` (N = 1): one JSON line with the contract's keys plus ``roofline`` (the
+    trailing update alone), ``cpu_baseline`` (here on a shortened sample), the per-phase timings, the
+    end-to-end fit and the one-GP section (shrunk by the test hook)."""
     import json
     import subprocess
     import sys
@@ -390,8 +433,8 @@ def test_bench_contract_single_process(gpu):
 
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, GUMBI_BENCH_DIST_N="2304", GUMBI_BENCH_CPU_SECONDS="2")
-    out = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "1", "--warmup", "0", "--map-evals", "4"],
-                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--config", "c2", "--steps", "1", "--warmup", "0",
+                          "--map-evals", "4"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -401,8 +444,30 @@ def test_bench_contract_single_process(gpu):
     assert 1 <= d["config"]["map_evals_per_step"][0] <= 8  # scipy checks maxfun between line searches
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert 20.0 < r["achieved"] < r["peak"] and r["launches"] > 100
+    assert "trailing-update" in r["kernel"] and 15.0 < r["achieved"] < r["peak"] and r["launches"] > 50
+    assert r["all_gemm_launches"]["launches"] > r["launches"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "N=" in c["sample"]
     assert d["phases"]["factorize_ms"] > 0 and d["phases"]["predict_ms"] > 0
-    assert d["distributed"]["results_finite"] and "1 GPU(s)" in d["distributed"]["workload"]
+    assert d["kbuild"]["unit"] == "GB/s" and d["kbuild"]["achieved"] > 100
+    assert d["end_to_end"]["results_finite"] and d["end_to_end"]["total_s"] > 0
+    side = d["c5_single_gpu"]
+    assert "error" not in side, side
+    assert side["results_finite"] and side["value"] > 0 and "N=2304" in side["workload"]
+
+
+def test_bench_default_config_is_the_largest_single_gpu_one():
+    """Without --config the one-GPU headline is C3 (N = 50k, d = 8, Matern-5/2); checked on the argument
+    handling only (the full C3 run is the driver's bench job)."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_cfg", root / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["bench_cfg"] = mod
+    spec.loader.exec_module(mod)
+    src = (root / "bench.py").read_text()
+    assert 'args.config or ("c3" if world == 1 else "c5")' in src
+    assert mod.CONFIGS["c3"]["label"].startswith("synthetic N=50k d=8 Matern-5/2")
