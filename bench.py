@@ -187,7 +187,7 @@ def roofline_block(tm, config):
     n_chol = max(int(tm["total_chol_gemm_launches"]), 1)
     out = {
         "bound": "mfma",
-        "kernel": "gemm_f64_kernel, the Cholesky's trailing-update launches (v_mfma_f64_16x16x4_f64 SYRK/GEMM)",
+        "kernel": "gemm_f64_kernel, the Cholesky's bulk trailing-update launches U1 / U2 (v_mfma_f64_16x16x4_f64 SYRK/GEMM)",
         "achieved": round(chol_tf, 3),
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
@@ -201,7 +201,11 @@ def roofline_block(tm, config):
         # launches of the look-ahead schedule's two streams overlap: the same flops over the WALL time with at
         # least one of these launches in flight (union of the launch intervals)
         "achieved_over_wall_time": round(tm["total_chol_gemm_flops"] / max(tm.get("total_chol_gemm_wall_ms", 0.0), 1e-9) / 1e9, 3),
-        "all_gemm_launches": {  # trailing updates + triangular solves + inverse + Sigma^-1 + predict
+        # the small products INSIDE the panels (the latency-bound chain that runs beside U2): share of the Cholesky's flops
+        "in_panel_products": {"flops_share_of_cholesky": round(tm.get("total_chol_panel_gemm_flops", 0.0) / max(
+            tm.get("total_chol_panel_gemm_flops", 0.0) + tm["total_chol_gemm_flops"], 1.0), 4),
+            "sum_of_launch_ms": round(tm.get("total_chol_panel_gemm_ms", 0.0), 3)},
+        "all_gemm_launches": {  # trailing updates + in-panel products + triangular solves + inverse + Sigma^-1 + predict
             "achieved": round(all_tf, 3),
             "frac": round(all_tf / FP64_MFMA_PEAK_TFLOPS, 4),
             "launches": int(tm["total_gemm_launches"]),
@@ -221,10 +225,11 @@ def roofline_block(tm, config):
             "achieved": round(mtf, 3),
             "frac_of_their_share_of_peak": round(mtf / (FP64_MFMA_PEAK_TFLOPS * tm["masked_cus"] / ncu), 4),
         }
-    pt = pmc_traffic(config, "gemm_f64")
+    pt = pmc_traffic(config, "gemm_f64_kernel<2, 2, 4, 4")  # the 128 x 128 instantiation the bulk updates run
     if pt is not None:
         out["traffic"] = round(pt["bytes_per_launch"], 1)
-        out["traffic_unit"] = "HBM bytes per gemm_f64 launch (2*FETCH_SIZE + WRITE_SIZE)"
+        out["traffic_unit"] = ("HBM bytes per launch of the 128x128 gemm_f64_kernel instantiation (2*FETCH_SIZE + WRITE_SIZE; "
+                               "all its launches of one bench step, the bulk trailing updates among them)")
         out["traffic_source"] = pt["source"]
     return out
 

@@ -157,6 +157,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   hipStream_t mainS = e->stream, bulkS = e->aux[2];
   e->sync_next = 0;
   e->cur = mainS;
+  e->chol_update_kind = 0;  // chol_cols factors the panels' squares: in-panel products
   PhaseTimer tk(e);
   PhaseTimer* tc = nullptr;
   for (const gmb_dist_step& s : plan) {
@@ -230,7 +231,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
         g.tri_off = (s.first - s.lo) * TILE;
         g.nblk_stride = G;
         e->cur = s.stream ? bulkS : mainS;
-        rc = launch_gemm(e, g, 0);
+        rc = launch_gemm(e, g, 7);
         e->cur = mainS;
         break;
       }

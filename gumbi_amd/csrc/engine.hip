@@ -42,7 +42,7 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 struct EventPair {
   hipEvent_t a, b;
-  int kind;  // 0 chol gemm, 1 leaf, 2 trsm, 3 predict gemm, 4 grad gemm
+  int kind;  // 0 chol in-panel gemm, 7 chol bulk trailing update, 1 leaf, 2 trsm gemm, 5 / 6 strips, 3 predict gemm, 4 grad gemm
   double flops;
   int mt, nt, k, flags;
   bool masked = false;  // launched on the CU-masked bulk stream
@@ -154,6 +154,9 @@ struct gmb_engine {
   // level-parallel triangular inverse (independent merges dealt over stream + aux[0..2])
   hipStream_t cur = nullptr;
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  // event kind of the updates chol_cols issues: 7 (bulk trailing update) for the plain recursion over the whole
+  // matrix, 0 (in-panel product of the latency-bound chain) inside the look-ahead schedules' panels
+  int chol_update_kind = 7;
   int chol_scheme = -1;  // -1 = by size (masked bulk stream for small matrices, else 0); 0 = panel chain on the aux stream; 2 = masked bulk stream
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
   std::vector<hipEvent_t> sync_pool;
@@ -289,14 +292,14 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
       if (cur_hi >= cur_lo) uni += cur_hi - cur_lo;
       return uni;
     };
-    e->tm.total_gemm_wall_ms += interval_union([](int k) { return k == 0 || k == 2 || k == 3 || k == 4; });
-    e->tm.total_chol_gemm_wall_ms += interval_union([](int k) { return k == 0; });
+    e->tm.total_gemm_wall_ms += interval_union([](int k) { return k == 0 || k == 7 || k == 2 || k == 3 || k == 4; });
+    e->tm.total_chol_gemm_wall_ms += interval_union([](int k) { return k == 7; });
   }
   for (auto& p : e->evs) {
     float t = 0.f;
     (void)hipEventElapsedTime(&t, p.a, p.b);
     if (trace) fprintf(trace, "%d %d %d %d %d %.5f %.1f\n", p.kind, p.mt, p.nt, p.k, p.flags, t, p.flops / 1e9);
-    if (p.kind == 0 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
+    if (p.kind == 0 || p.kind == 7 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
       e->tm.total_gemm_ms += t;
       e->tm.total_gemm_flops += p.flops;
       e->tm.total_gemm_launches += 1;
@@ -307,12 +310,18 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
     }
     switch (p.kind) {
       case 0:
+      case 7:
         e->tm.chol_gemm_ms += t;
         e->tm.chol_gemm_flops += p.flops;
         e->tm.chol_gemm_launches += 1;
-        e->tm.total_chol_gemm_ms += t;
-        e->tm.total_chol_gemm_flops += p.flops;
-        e->tm.total_chol_gemm_launches += 1;
+        if (p.kind == 7) {
+          e->tm.total_chol_gemm_ms += t;
+          e->tm.total_chol_gemm_flops += p.flops;
+          e->tm.total_chol_gemm_launches += 1;
+        } else {
+          e->tm.total_chol_panel_gemm_ms += t;
+          e->tm.total_chol_panel_gemm_flops += p.flops;
+        }
         break;
       case 1: e->tm.chol_leaf_ms += t; break;
       case 2:
@@ -714,7 +723,7 @@ int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
   g.alpha = -1.0;
   g.beta = 1.0;
   g.tri = 1;
-  rc = launch_gemm(e, g, 0);
+  rc = launch_gemm(e, g, e->chol_update_kind);
   if (rc) return rc;
   return chol_cols(e, mid, c1, rend);
 }
@@ -748,6 +757,7 @@ int chol_lookahead_full(gmb_engine* e) {
   hipStream_t mainS = e->stream, auxS = e->aux[0];
   e->sync_next = 0;
   int rc;
+  e->chol_update_kind = 0;  // chol_cols below factors panels: its products belong to the chain
   e->cur = mainS;
   if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
   for (int c0 = 0; c0 < nct; c0 += w) {
@@ -768,7 +778,7 @@ int chol_lookahead_full(gmb_engine* e) {
       g.alpha = -1.0;
       g.beta = 1.0;
       g.tri = 1;
-      return launch_gemm(e, g, 0);
+      return launch_gemm(e, g, 7);
     };
     e->cur = mainS;
     if ((rc = update(n0, n1))) return rc;                 // U1
@@ -790,6 +800,7 @@ int chol_lookahead_masked(gmb_engine* e) {
   hipStream_t mainS = e->stream, bulkS = e->aux[2];
   e->sync_next = 0;
   int rc;
+  e->chol_update_kind = 0;  // chol_cols below factors panels: its products belong to the chain
   e->cur = mainS;
   if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
   for (int c0 = 0; c0 < nct; c0 += w) {
@@ -810,7 +821,7 @@ int chol_lookahead_masked(gmb_engine* e) {
       g.alpha = -1.0;
       g.beta = 1.0;
       g.tri = 1;
-      return launch_gemm(e, g, 0);
+      return launch_gemm(e, g, 7);
     };
     e->cur = mainS;
     if ((rc = order_after(e, bulkS, mainS))) return rc;   // U2(p-1) reached these columns
@@ -1620,6 +1631,7 @@ int gmb_set_profiling(gmb_engine* e, int32_t on) {
     e->tm.total_gemm_wall_ms = 0.0;
     e->tm.total_chol_gemm_ms = e->tm.total_chol_gemm_flops = e->tm.total_chol_gemm_wall_ms = 0.0;
     e->tm.total_chol_gemm_launches = 0;
+    e->tm.total_chol_panel_gemm_ms = e->tm.total_chol_panel_gemm_flops = 0.0;
     e->tm.masked_cus = e->aux_shared ? e->wg_slots / 2 - e->part_cus : 0;
     e->tm.total_gemm_launches = 0;
     e->tm.total_kbuild_ms = e->tm.total_kbuild_bytes = 0.0;
@@ -1681,6 +1693,7 @@ int gmb_factorize(gmb_engine* e) {
   tk.stop();
   // 2. Cholesky
   PhaseTimer tc(e);
+  e->chol_update_kind = 7;
   if (e->panel_auto) {
     // wider panels for larger matrices: a k = 1024 trailing update pays its C read-modify-write and
     // epilogue per 1024 of contraction; measured at N = 60k: 8 blocks 58.0, 16: 62.2, 32: 63.9 TF/s

@@ -80,6 +80,8 @@ class Timings(C.Structure):
         ("total_chol_gemm_flops", C.c_double),
         ("total_chol_gemm_launches", C.c_int64),
         ("total_chol_gemm_wall_ms", C.c_double),
+        ("total_chol_panel_gemm_ms", C.c_double),
+        ("total_chol_panel_gemm_flops", C.c_double),
     ]
 
     def as_dict(self):

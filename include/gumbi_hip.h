@@ -115,12 +115,16 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
   /* wall time with at least one GEMM launch in flight (union of the launch intervals: launches of
      the look-ahead schedules' two streams overlap, total_gemm_ms is the SUM of their durations)    */
   double total_gemm_wall_ms;
-  /* the Cholesky's trailing-update launches alone (kind of chol_gemm_*), cumulative like total_gemm_*:
-     the kernel launches the north star's MFMA-utilisation target is stated on                        */
+  /* the Cholesky's BULK trailing-update launches alone (U1 / U2 of the look-ahead schedules, every update
+     of the plain recursion, the UPDATE steps of the multi-GPU driver), cumulative like total_gemm_*: the
+     kernel launches the north star's MFMA-utilisation target is stated on.  The small in-panel products
+     of the latency-bound panel chain are counted separately (total_chol_panel_gemm_*).               */
   double total_chol_gemm_ms;
   double total_chol_gemm_flops;
   int64_t total_chol_gemm_launches;
   double total_chol_gemm_wall_ms; /* union of their launch intervals */
+  double total_chol_panel_gemm_ms;
+  double total_chol_panel_gemm_flops;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;

@@ -220,6 +220,44 @@ def test_c4_full_size_properties(gpu):
     eng.close()
 
 
+@pytest.mark.parametrize("n,d,lin", [(700, 4, False), (900, 3, True)])
+def test_kronecker_engine_matches_the_oracle_directly(gpu, n, d, lin):
+    """IcmEngine (P systems of size N, gumbi_amd/regression/icm.py) straight against the ORACLE's stacked
+    PN x PN evaluation -- not against the stacked HIP engine: NLML, every gradient entry (kernel parameters,
+    output table W / kappa, noise table), posterior mean and variance with and without noise."""
+    from gumbi_amd.engine import KernelSpec
+    from gumbi_amd.regression.icm import IcmEngine
+
+    X, y, spec, theta = icm_problem(n, d, seed=17)
+    idx_lin = [1] if lin else []
+    if lin:
+        spec = O.make_spec(d + 1, range(d), kind="ExpQuad", idx_lin=idx_lin, out_col=d, n_out=2, hetero_noise=True)
+        p = O.unpack_theta(icm_problem(n, d, seed=17)[2], theta)
+        theta = O.pack_theta(spec, p["ls"], p["eta"], p["sigma"], c=[0.3], tau=0.7, W_out=p["W_out"], kappa_out=p["kappa_out"],
+                             W_noise=p["W_noise"], kappa_noise=p["kappa_noise"])
+    ks = KernelSpec(D=d + 1, idx_cont=list(range(d)), kind="ExpQuad", idx_lin=idx_lin, out_col=d, n_out=2, hetero_noise=True)
+    kron = IcmEngine(0)
+    kron.set_data(X, y)
+    kron.set_kernel(ks)
+    rng = np.random.default_rng(4)
+    for trial in range(2):
+        th = theta.copy() if trial == 0 else theta * np.exp(rng.normal(0, 0.15, theta.size))
+        kron.set_theta(th)
+        kron.factorize()
+        val, g = kron.nlml(grad=True)
+        val_r, g_r = O.nlml_and_grad(spec, th, X, y, dist_mode="direct")
+        assert np.isclose(val, val_r, rtol=1e-10)
+        assert np.max(np.abs(g - g_r)) < 1e-7 * max(1.0, np.max(np.abs(g_r)))
+        Xs1 = rng.standard_normal((60, d))
+        Xs = np.vstack([np.column_stack([Xs1, np.full(len(Xs1), p)]) for p in range(2)])
+        kron.factorize()
+        for with_noise in (True, False):
+            mu, var = kron.predict(Xs, with_noise=with_noise)
+            mu_r, var_r = O.predict(spec, th, X, y, Xs, with_noise=with_noise, dist_mode="direct")
+            assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-9
+    kron.close()
+
+
 def test_c4_full_size_kronecker_equals_stacked(gpu):
     """C4 at full size both ways: the stacked 40k x 40k system and the Kronecker form (two 20k x 20k
     systems, gumbi_amd/regression/icm.py) give the same NLML, gradient and predictions; the
