@@ -56,7 +56,9 @@ struct CovParams {
 // x = k ln2 + r (|r| <= ln2 / 2), degree-13 Taylor polynomial (truncation 4e-18), v_ldexp_f64.
 // Within 1-2 ulp of libm's exp; about two thirds of its instructions (no overflow / NaN paths).
 __device__ __forceinline__ double exp_nonpos(double x) {
-  if (x <= -745.0) return 0.0;  // underflow (and -inf); NaN falls through and stays NaN
+  // underflow (and -inf) without a branch: clamp to where the result is the smallest subnormal (v_ldexp then
+  // rounds to 5e-324, i.e. zero for every use here); NaN compares false and stays NaN
+  x = x < -745.0 ? -745.0 : x;
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = fma(-k, 6.93147180369123816490e-01, x);
   r = fma(-k, 1.90821492927058770002e-10, r);
@@ -77,20 +79,38 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return __builtin_amdgcn_ldexp(p, (int)k);
 }
 
-// Measured: no faster than libm's exp inside the covariance kernels (they were bound by branches
-// and XCD imbalance, not by the exponential), so libm stays the default; -DGMB_FAST_EXP selects it.
-#ifdef GMB_FAST_EXP
-#define GMB_EXP(x) exp_nonpos(x)
-#else
+// The covariance build at C3 (N = 50k, d = 8, Matern-5/2) is bound by fp64 VALU issue, not by HBM: ~75
+// instructions per entry with libm's exp / sqrt (special-case handling included) against ~1.6 ms of store
+// time for the 10 GB triangle.  exp_nonpos / sqrt_pos drop the paths a stationary kernel can never take
+// (-DGMB_LIBM_EXP restores libm for A/B runs).
+#ifdef GMB_LIBM_EXP
 #define GMB_EXP(x) exp(x)
+#define GMB_SQRT(x) sqrt(x)
+#else
+#define GMB_EXP(x) exp_nonpos(x)
+#define GMB_SQRT(x) sqrt_pos(x)
 #endif
+
+// sqrt(p) for p in the normal range (here p = r^2 + 1e-12 >= 1e-12): hardware rsq estimate, one coupled
+// Goldschmidt step and one residual correction -- correctly rounded in all but ~1e-3 of cases, <= 1 ulp
+// otherwise; libm's version spends as many instructions again on scaling subnormals and on 0 / inf.
+__device__ __forceinline__ double sqrt_pos(double p) {
+  const double y = __builtin_amdgcn_rsq(p);
+  double g = p * y;
+  const double h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  const double hh = fma(h, r, h);
+  const double d = fma(-g, g, p);
+  return fma(d, hh, g);
+}
 
 template <int KIND>
 __device__ __forceinline__ double stationary(double r2) {
   if constexpr (KIND == 0) {
     return GMB_EXP(-0.5 * r2);
   } else {
-    const double r = sqrt(r2 + 1e-12);
+    const double r = GMB_SQRT(r2 + 1e-12);
     if constexpr (KIND == 1) {
       const double s5 = 2.23606797749978969641;
       return (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * GMB_EXP(-s5 * r);
@@ -111,7 +131,7 @@ __device__ __forceinline__ double stationary_dr2(double r2) {
   if constexpr (KIND == 0) {
     return -0.5 * GMB_EXP(-0.5 * r2);
   } else {
-    const double r = sqrt(r2 + 1e-12);
+    const double r = GMB_SQRT(r2 + 1e-12);
     if constexpr (KIND == 1) {
       const double s5 = 2.23606797749978969641;
       return -(5.0 / 6.0) * (1.0 + s5 * r) * GMB_EXP(-s5 * r);
@@ -277,17 +297,21 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
   const bool below = a.mode != COV_TRAIN || gj0 + TILE <= gi0;
   if (full && below && p.n_lin == 0 && p.n_tab == 0) {
     const double* xjp = &xj[0][jh * (TILE / 2)];
-#pragma unroll 8
-    for (int jj = 0; jj < TILE / 2; ++jj) {
+    auto entry = [&](int jj) {
       double r2 = 0.0;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         const double d = xi[k] - xjp[k * TILE + jj];
         r2 = fma(d, d, r2);
       }
-      const double v = p.eta2 * stationary<KIND>(r2);
-      double* o = outp + (int64_t)jj * a.ldo;
-      *o = a.accumulate ? *o + v : v;
+      return p.eta2 * stationary<KIND>(r2);
+    };
+    if (a.accumulate) {  // (tested once per tile, not once per entry)
+#pragma unroll 8
+      for (int jj = 0; jj < TILE / 2; ++jj) outp[(int64_t)jj * a.ldo] += entry(jj);
+    } else {
+#pragma unroll 8
+      for (int jj = 0; jj < TILE / 2; ++jj) outp[(int64_t)jj * a.ldo] = entry(jj);
     }
     return;
   }

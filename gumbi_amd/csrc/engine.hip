@@ -138,6 +138,7 @@ struct gmb_engine {
   const double* plan_A = nullptr;
   bool batch_inverse = true;
   bool lpt_order = true;
+  int tile_strip = 8;  // GMB_TILE_STRIP: m-tiles per strip of the L2-aware tile order (0 = row-major runs)
 
   // timing
   bool profiling = false;
@@ -407,6 +408,8 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   g.order = 0;
   if (e->lpt_order && g.nblk_stride == 1 && g.tri_off >= 0 && !g.klo_m && (g.klo_n != 0) != (g.khi_n != 0))
     g.order = g.klo_n ? 1 : 2;
+  // L2-aware rasterisation of the XCD runs for launches that are several patches large (GemmArgs::strip)
+  g.strip = (g.order == 0 && e->tile_strip > 0 && g.mt >= 2 && !in_place && !g.klo_m) ? e->tile_strip : 0;
   double flops = 0.0;
   const int nblocks = gemm_schedule(g, bm, bn, &flops);
   if (nblocks <= 0) return GMB_OK;
@@ -1442,6 +1445,8 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream) {
   }
   e->lookahead = flag("GMB_LOOKAHEAD", true);
   e->lpt_order = flag("GMB_LPT_ORDER", true);
+  const char* ts = getenv("GMB_TILE_STRIP");
+  if (ts) e->tile_strip = std::max(0, atoi(ts));
   e->batch_inverse = flag("GMB_BATCH_INVERSE", true);
   e->par_inverse = flag("GMB_PAR_INVERSE", true);
   const char* pb = getenv("GMB_PANEL_BLOCKS");
@@ -1988,6 +1993,43 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
 }
 
 // ---- block-level operations (multi-GPU driver) ---------------------------------------------
+// Host-only (no device): the tile list of one GEMM launch as the kernels enumerate it -- gemm_schedule's
+// grid, then gemm_decode_tile for every block.  out receives (block, tm, tn) triples of the blocks that
+// compute a tile; returns their number (or the negative status).  Tests check that every computed tile of
+// the (triangular, strided, strip-ordered ...) launch appears exactly once.
+int64_t gmb_debug_tile_list(int32_t mt, int32_t nt, int32_t bm, int32_t bn, int32_t k, int32_t tri, int32_t tri_off,
+                            int32_t nblk_stride, int32_t klo_n, int32_t khi_n, int32_t order, int32_t strip,
+                            int32_t* out, int64_t cap, int32_t* grid) {
+  if (mt < 1 || nt < 1 || k < KT || nblk_stride < 1 || (bm != 128 && bm != 64) || (bn != 128 && bn != 64 && bn != 32))
+    return GMB_EINVAL;
+  GemmArgs g{};
+  g.mt = mt;
+  g.nt = nt;
+  g.k = k;
+  g.tri = tri;
+  g.tri_off = tri_off;
+  g.nblk_stride = nblk_stride;
+  g.klo_n = klo_n;
+  g.khi_n = khi_n;
+  g.order = order;
+  g.strip = order == 0 ? strip : 0;
+  double flops = 0.0;
+  const int nblocks = gemm_schedule(g, bm, bn, &flops);
+  if (grid) *grid = nblocks;
+  int64_t n = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    int tm = -1, tn = -1;
+    if (!gemm_decode_tile(g, bm, bn, b, tm, tn)) continue;
+    if (out && n < cap) {
+      out[3 * n] = b;
+      out[3 * n + 1] = tm;
+      out[3 * n + 2] = tn;
+    }
+    ++n;
+  }
+  return n;
+}
+
 int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, double* dinv16,
                   double* logdet_accum, int32_t* info) {
   if (!e || !Akk || nvalid < 1 || nvalid > TILE || lda < TILE) return fail(e, GMB_EINVAL, "bad potrf block");

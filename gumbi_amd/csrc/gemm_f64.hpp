@@ -81,6 +81,13 @@ struct GemmArgs {
   // runs 1.1 ms of a 2.8 ms launch and must not start late.  Consecutive blocks land on
   // consecutive XCDs, which deals every length class evenly over the 8 XCDs.
   int32_t order;
+  // order == 0 only.  strip > 0: L2-aware rasterisation -- the tile list is enumerated strip by strip of
+  // `strip` consecutive m-tiles, inside a strip n-tile by n-tile (tm fastest).  Blocks are dispatched in list
+  // order, so the ~64 tiles resident on one XCD (32 compute units x 2 workgroups) form a strip x 64/strip
+  // patch that shares `strip` A panels and 64/strip B panels through that XCD's 4 MiB L2, instead of one A
+  // panel and 64 different B panels in the row-major order (strip == 0).  PMC at C3 (r02d): the row-major
+  // 128 x 128 launches fetched 2.5 TB/s, 13x the algorithmic operand + C traffic.
+  int32_t strip;
 };
 
 // XCD-aware tile order.  The dispatcher places block b on XCD b % 8 (observed, speed only), and
@@ -110,6 +117,89 @@ __host__ __device__ __forceinline__ int gemm_first_tn(int64_t T, int bn, int str
   return (int)(q * per + (r + bn - 1) / bn);
 }
 
+// Block index -> tile (tm, tn) of the launch's tile list; false when the block has nothing to do.  Shared by
+// the kernels and by the host-side enumeration the tests use (gmb_debug_tile_list): every computed tile must
+// come out exactly once over the grid gemm_schedule returns.
+__host__ __device__ inline bool gemm_decode_tile(const GemmArgs& g, const int BM, const int BN, const int vbid, int& tm,
+                                                 int& tn) {
+  const int xcd = vbid & 7;
+  int ci = g.xstart[xcd] + (vbid >> 3);
+  if (g.order == 0 && g.strip > 0) {
+    if (ci >= g.xstart[xcd + 1]) return false;
+    // strip-major list: strip s holds m-tiles [s*strip, min(mt, (s+1)*strip)); for n-tile tn it has the
+    // m-tiles of the strip whose first computed n-tile is <= tn (first() is non-decreasing in tm)
+    auto first_of = [&](int t) {
+      if (!g.tri) return 0;
+      const int f = gemm_first_tn((int64_t)t * BM - g.tri_off - (BN - 1), BN, g.nblk_stride);
+      return f > g.nt ? g.nt : f;
+    };
+    int t0 = 0;
+    for (;;) {  // find the strip
+      const int t1 = t0 + g.strip < g.mt ? t0 + g.strip : g.mt;
+      int cnt = 0;
+      for (int t = t0; t < t1; ++t) cnt += g.nt - first_of(t);
+      if (ci < cnt) break;
+      ci -= cnt;
+      t0 = t1;
+      if (t0 >= g.mt) return false;
+    }
+    const int t1 = t0 + g.strip < g.mt ? t0 + g.strip : g.mt, sz = t1 - t0;
+    const int f_hi = first_of(t1 - 1);
+    tn = first_of(t0);
+    int have = 1;  // m-tiles of the strip that reach n-tile tn
+    while (tn < f_hi) {  // ragged head (triangular corner of the strip)
+      while (have < sz && first_of(t0 + have) <= tn) ++have;
+      if (ci < have) break;
+      ci -= have;
+      ++tn;
+    }
+    if (tn >= f_hi) {  // rectangular body: every m-tile of the strip
+      tn += ci / sz;
+      ci -= (ci / sz) * sz;
+    }
+    tm = t0 + ci;
+    return true;
+  }
+  if (g.order == 0) {
+    if (ci >= g.xstart[xcd + 1]) return false;
+    if (!g.tri) {
+      tm = ci / g.nt;
+      tn = ci - tm * g.nt;
+      return true;
+    }
+    tm = 0;
+    for (;;) {
+      int first = gemm_first_tn((int64_t)tm * BM - g.tri_off - (BN - 1), BN, g.nblk_stride);
+      first = first > g.nt ? g.nt : first;
+      const int cnt = g.nt - first;
+      if (ci < cnt) {
+        tn = first + ci;
+        return true;
+      }
+      ci -= cnt;
+      ++tm;
+    }
+  }
+  // n-major list (nblk_stride == 1): n-tile tn holds the m-tiles [0, cnt(tn))
+  ci = vbid;
+  const int step = g.order == 1 ? 1 : -1;
+  tn = g.order == 1 ? 0 : g.nt - 1;
+  for (;;) {
+    if (tn < 0 || tn >= g.nt) return false;
+    int cnt = g.mt;
+    if (g.tri) {
+      const int lim = (tn * BN + BN - 1 + g.tri_off) / BM + 1;
+      cnt = lim < cnt ? lim : cnt;
+    }
+    if (ci < cnt) {
+      tm = ci;
+      return true;
+    }
+    ci -= cnt;
+    tn += step;
+  }
+}
+
 // __launch_bounds__(256, 2): two workgroups (= two waves per SIMD) per CU.  The 128 x 128 variant
 // then keeps its 128 accumulator registers + staging in 207 VGPRs (no AGPRs, no spills) and the
 // second workgroup's MFMAs fill the first one's barrier / staging bubbles: 39 -> 52 TF/s on the
@@ -126,51 +216,8 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
   static_assert(NA >= 1 && NB >= 1 && NA * RA == KT && NB * RB == KT, "staging must tile the k-tile");
   __shared__ double lds[2][KT * (PA + PB)];
 
-  const int xcd = vbid & 7;
-  // compact index of this block's tile within its XCD's run, then (tm, tn) by walking the rows
   int tm, tn;
-  {
-    int ci = g.xstart[xcd] + (vbid >> 3);
-    if (g.order == 0) {
-      if (ci >= g.xstart[xcd + 1]) return;
-      if (!g.tri) {
-        tm = ci / g.nt;
-        tn = ci - tm * g.nt;
-      } else {
-        tm = 0;
-        for (;;) {
-          int first = gemm_first_tn((int64_t)tm * BM - g.tri_off - (BN - 1), BN, g.nblk_stride);
-          first = first > g.nt ? g.nt : first;
-          const int cnt = g.nt - first;
-          if (ci < cnt) {
-            tn = first + ci;
-            break;
-          }
-          ci -= cnt;
-          ++tm;
-        }
-      }
-    } else {
-      // n-major list (nblk_stride == 1): n-tile tn holds the m-tiles [0, cnt(tn))
-      ci = vbid;
-      const int step = g.order == 1 ? 1 : -1;
-      tn = g.order == 1 ? 0 : g.nt - 1;
-      for (;;) {
-        if (tn < 0 || tn >= g.nt) return;
-        int cnt = g.mt;
-        if (g.tri) {
-          const int lim = (tn * BN + BN - 1 + g.tri_off) / BM + 1;
-          cnt = lim < cnt ? lim : cnt;
-        }
-        if (ci < cnt) {
-          tm = ci;
-          break;
-        }
-        ci -= cnt;
-        tn += step;
-      }
-    }
-  }
+  if (!gemm_decode_tile(g, BM, BN, vbid, tm, tn)) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -404,6 +451,45 @@ inline int gemm_schedule(GemmArgs& g, int bm, int bn, double* flops) {
       for (int tn = first_of(tm); tn < g.nt; ++tn) funits += kunits(tm, tn);
   }
   if (flops) *flops = 2.0 * bm * bn * KT * (double)funits;
+  if (g.strip > 0) {
+    // work-balanced cuts of the strip-major list: walk the strips, inside the strip that holds a cut walk its
+    // n-tiles (tile work depends on tn only: P)
+    g.xstart[0] = 0;
+    long long acc = 0, ci = 0;
+    int x = 1;
+    for (int t0 = 0; t0 < g.mt && x < 8; t0 += g.strip) {
+      const int t1 = std::min(t0 + g.strip, g.mt), sz = t1 - t0;
+      long long sw = 0, sc = 0;
+      for (int t = t0; t < t1; ++t) {
+        const int f = first_of(t);
+        sw += P[g.nt] - P[f];
+        sc += g.nt - f;
+      }
+      if ((acc + sw) * 8 >= (long long)x * total) {  // one or more cuts fall inside this strip
+        long long a2 = acc, c2 = ci;
+        int have = 1;
+        for (int tn = first_of(t0); tn < g.nt && x < 8; ++tn) {
+          while (have < sz && first_of(t0 + have) <= tn) ++have;
+          const long long w1 = P[tn + 1] - P[tn];
+          for (int q = 0; q < have && x < 8; ++q) {
+            if ((a2 + w1) * 8 >= (long long)x * total) g.xstart[x++] = (int)(c2 + 1);
+            a2 += w1;
+            ++c2;
+          }
+        }
+      }
+      acc += sw;
+      ci += sc;
+    }
+    while (x <= 8) g.xstart[x++] = (int)nact;
+    g.xstart[8] = (int)nact;
+    int longest = 0;
+    for (int i = 0; i < 8; ++i) {
+      if (g.xstart[i + 1] < g.xstart[i]) g.xstart[i + 1] = g.xstart[i];
+      longest = std::max(longest, g.xstart[i + 1] - g.xstart[i]);
+    }
+    return longest * 8;
+  }
   g.xstart[0] = 0;
   long long acc = 0, ci = 0;
   int x = 1;

@@ -222,6 +222,7 @@ _SIGNATURES = {
     "gmb_dist_nlml": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), _DBL_P, _DBL_P]),
     "gmb_dist_predict": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_int32]),
+    "gmb_debug_tile_list": (C.c_int64, [C.c_int32] * 12 + [C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32)]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gmb_blk_trsm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                C.c_int32]),
@@ -489,6 +490,20 @@ class Engine:
         self._check(self._lib.gmb_blk_gemm_nt(self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda,
                                               C.c_void_p(b_ptr), ldb, m, n, k, alpha, beta, tri, tri_shift),
                     "gmb_blk_gemm_nt")
+
+
+def gemm_tile_list(mt, nt, bm=128, bn=128, k=1024, tri=0, tri_off=0, nblk_stride=1, klo_n=0, khi_n=0, order=0, strip=0):
+    """(grid, [(block, tm, tn), ...]) of one GEMM launch as the kernel enumerates it (host-only)."""
+    lib = load_library()
+    args = [int(v) for v in (mt, nt, bm, bn, k, tri, tri_off, nblk_stride, klo_n, khi_n, order, strip)]
+    grid = C.c_int32()
+    n = lib.gmb_debug_tile_list(*args, None, 0, C.byref(grid))
+    if n < 0:
+        raise ValueError("gmb_debug_tile_list: bad arguments")
+    buf = (C.c_int32 * (3 * n))()
+    lib.gmb_debug_tile_list(*args, buf, n, C.byref(grid))
+    arr = np.frombuffer(buf, dtype=np.int32).reshape(n, 3)
+    return int(grid.value), [tuple(int(v) for v in row) for row in arr]
 
 
 def dist_plan(N: int, rank: int, world: int, panel_blocks: int = 0) -> list:

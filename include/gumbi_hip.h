@@ -208,6 +208,12 @@ int gmb_copy_alpha(const gmb_engine* e, double* out);
  * The leaf, strip-solve and MFMA GEMM kernels of the factorisation on caller-provided blocks, so
  * that each can be checked against LAPACK on its own.  All matrices are column-major float64 in
  * device memory with the given leading dimensions; sizes must be multiples of 128. */
+/* Host-only: the tile list of one MFMA GEMM launch exactly as the kernel enumerates it (XCD-balanced runs,
+ * triangular skipping, strided rows, longest-first and L2-aware strip orders); out = (block, tm, tn) triples,
+ * *grid = the launch's grid size; returns the number of triples. */
+int64_t gmb_debug_tile_list(int32_t mt, int32_t nt, int32_t bm, int32_t bn, int32_t k, int32_t tri,
+                            int32_t tri_off, int32_t nblk_stride, int32_t klo_n, int32_t khi_n, int32_t order,
+                            int32_t strip, int32_t* out, int64_t cap, int32_t* grid);
 /* Factor one 128 x 128 diagonal block in place (lower triangle; columns >= nvalid are identity
  * padding and are left alone).  dinv16 (optional, 8 x 256 doubles) receives the column-major
  * inverses of the eight 16 x 16 diagonal sub-blocks of the identity-padded factor: the operands

@@ -78,3 +78,60 @@ def test_product_package_never_imports_oracle():
     for path in (ROOT / "gumbi_amd" / "csrc").glob("*"):
         if path.suffix in (".hip", ".hpp"):
             assert "oracle/" not in path.read_text().replace("see oracle/gp_oracle.py square_dist", "")
+
+
+def _expected_tiles(mt, nt, bm, bn, tri, tri_off, stride):
+    """Tiles the launch must compute: all of them, or -- tri -- those not strictly above the diagonal: tile
+    (tm, tn) is skipped when its last row noff(tn) + bn - 1 + tri_off lies above its first column tm * bm."""
+    out = set()
+    for tm in range(mt):
+        for tn in range(nt):
+            e = tn * bn
+            noff = (e >> 7) * stride * 128 + (e & 127)
+            if not tri or noff + bn - 1 + tri_off >= tm * bm:
+                out.add((tm, tn))
+    return out
+
+
+@pytest.mark.parametrize("strip", [0, 8, 4, 3])
+def test_gemm_tile_lists_cover_every_tile_exactly_once(strip):
+    """The kernels find their tile from the block index alone (XCD-balanced runs, triangular skipping, strided
+    block rows, L2-aware strips): enumerate the launch on the host exactly as the kernel does and compare with
+    the definition -- every computed tile once, no other tile, runs balanced."""
+    from gumbi_amd import engine
+
+    rng = np.random.default_rng(7)
+    cases = [(1, 1, 128, 128, 0, 0, 1), (5, 7, 128, 128, 0, 0, 1), (16, 16, 128, 128, 1, 0, 1), (16, 40, 128, 128, 1, 8 * 128, 1),
+             (24, 367, 128, 128, 1, 0, 1), (13, 29, 64, 64, 1, 0, 1), (8, 33, 128, 64, 1, 128, 1), (9, 50, 128, 32, 1, 0, 1),
+             (40, 12, 128, 128, 1, 3 * 128, 8), (48, 13, 128, 128, 1, 5 * 128, 3), (31, 6, 64, 64, 1, 128, 2)]
+    for _ in range(12):
+        bm, bn = [(128, 128), (64, 64), (128, 64)][rng.integers(3)]
+        cases.append((int(rng.integers(1, 60)), int(rng.integers(1, 90)), bm, bn, int(rng.integers(2)),
+                      int(rng.integers(0, 6)) * 128, int(rng.integers(1, 5))))
+    for mt, nt, bm, bn, tri, tri_off, stride in cases:
+        grid, tiles = engine.gemm_tile_list(mt, nt, bm, bn, k=2048, tri=tri, tri_off=tri_off, nblk_stride=stride, strip=strip)
+        got = [(tm, tn) for _, tm, tn in tiles]
+        want = _expected_tiles(mt, nt, bm, bn, tri, tri_off, stride)
+        assert len(got) == len(set(got)), (mt, nt, bm, bn, tri, tri_off, stride)
+        assert set(got) == want, (mt, nt, bm, bn, tri, tri_off, stride, sorted(want - set(got))[:5], sorted(set(got) - want)[:5])
+        assert grid % 8 == 0 and grid >= len(got)
+        per_xcd = np.bincount([b % 8 for b, _, _ in tiles], minlength=8)
+        if len(got) >= 64:  # equal work per XCD run (uniform k here): counts within a couple of tiles
+            assert per_xcd.max() - per_xcd.min() <= max(3, strip + 1), per_xcd
+        if strip and len(got) >= 8 * 64 and tri == 0:
+            # locality: 64 consecutive tiles of one XCD's run touch few distinct A / B panels
+            run0 = [(tm, tn) for b, tm, tn in tiles if b % 8 == 0][:64]
+            assert len({tm for tm, _ in run0}) + len({tn for _, tn in run0}) <= strip + 64 // strip + 2 * 8
+
+
+def test_gemm_longest_first_orders_cover_every_tile():
+    from gumbi_amd import engine
+
+    for order in (1, 2):
+        for mt, nt, tri in [(12, 12, 1), (20, 9, 0), (7, 30, 1)]:
+            grid, tiles = engine.gemm_tile_list(mt, nt, 128, 128, k=nt * 128, tri=tri, klo_n=int(order == 1),
+                                                khi_n=int(order == 2), order=order)
+            got = [(tm, tn) for _, tm, tn in tiles]
+            # n-major lists: with tri the m-tiles of n-tile tn are [0, (tn*bn + bn - 1)/bm]
+            want = {(tm, tn) for tn in range(nt) for tm in range(mt) if not tri or tm <= (tn * 128 + 127) // 128}
+            assert len(got) == len(set(got)) and set(got) == want
