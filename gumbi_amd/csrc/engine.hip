@@ -376,10 +376,11 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
     // Tile shape by a small model: a launch of T tiles on S workgroup slots (two per compute
     // unit for every shape) takes max(1, T / S + 1/2) tile times -- full rounds plus an expected
     // half round of tail -- and a tile time is tile flops / intrinsic rate.  Intrinsic rates
-    // measured on MI355X at 8192^3 (TF/s): 128x128 69, 64x64 62, 128x64 62, 128x32 60.  Measured
-    // launch by launch on the N = 10k fit (tools/gpu_variant_compare.py): always-128x128 61.7 ms,
-    // always-64x64 52.2 ms, best shape per launch 51.0 ms.
-    static const double rate[4] = {69.0, 60.0, 61.0, 59.0};
+    // measured on MI355X on large plain products (TF/s, r02 kernels with the interleaved staging):
+    // 128x128 73, 64x64 63, 128x64 65, 128x32 60.  Measured launch by launch on the N = 10k fit
+    // (round 1, tools/gpu_variant_compare.py): always-128x128 61.7 ms, always-64x64 52.2 ms, best shape
+    // per launch 51.0 ms.
+    static const double rate[4] = {73.0, 63.0, 65.0, 60.0};
     static const int per128[4] = {1, 4, 2, 4};  // tiles per 128 x 128 block
     const double slots = (double)e->wg_slots;
     auto score = [&](int v) {  // higher is better: 1 / predicted time
@@ -1028,7 +1029,7 @@ int build_inv_plan(gmb_engine* e, const std::vector<std::vector<InvNode>>& level
   std::vector<TransposeJob> ht;
   e->inv_plan.assign(levels.size(), gmb_engine::InvLevelPlan{});
   static const int BMs[3] = {128, 64, 128}, BNs[3] = {128, 64, 64};
-  static const double rate[3] = {69.0, 60.0, 61.0};
+  static const double rate[3] = {73.0, 63.0, 65.0};
   static const int per128[3] = {1, 4, 2};
   for (size_t depth = 0; depth < levels.size(); ++depth) {
     std::vector<InvNode> nodes;
