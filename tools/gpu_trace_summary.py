@@ -4,7 +4,7 @@ from collections import defaultdict
 
 rows = [ln.split() for ln in open(sys.argv[1]) if ln.strip()]
 agg = defaultdict(lambda: [0, 0.0, 0.0])
-names = {0: "chol", 1: "leaf", 2: "trsm", 3: "pred", 4: "grad"}
+names = {0: "panel", 1: "leaf", 2: "trsm", 3: "pred", 4: "grad", 5: "strip", 6: "strip", 7: "bulk"}
 for kind, mt, nt, k, flags, ms, gf in rows:
     key = (names[int(kind)], int(mt), int(nt), int(k), int(flags))
     a = agg[key]
