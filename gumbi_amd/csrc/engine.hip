@@ -158,7 +158,7 @@ struct gmb_engine {
   // event kind of the updates chol_cols issues: 7 (bulk trailing update) for the plain recursion over the whole
   // matrix, 0 (in-panel product of the latency-bound chain) inside the look-ahead schedules' panels
   int chol_update_kind = 7;
-  int chol_scheme = -1;  // -1 = by size (masked bulk stream for small matrices, else 0); 0 = panel chain on the aux stream; 2 = masked bulk stream
+  int chol_scheme = -1;  // -1 = by size (masked look-ahead for small matrices, else the plain recursion); 0 = plain recursion; 2 = masked look-ahead
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
   std::vector<hipEvent_t> sync_pool;
   size_t sync_next = 0;
@@ -753,51 +753,13 @@ int order_after(gmb_engine* e, hipStream_t from, hipStream_t to) {
 int trsm_cols(gmb_engine* e, double* V, int64_t ldz, int ntm, int c0, int c1, int kind_gemm, int kind_strip,
               int lfirst = -1, int lstride = 0);
 
-// Full-height variant: the panel chain (leaf, strip solve and updates over ALL rows below) runs on
-// the auxiliary stream beside U2; U1 = the next panel's columns over all rows.
-int chol_lookahead_full(gmb_engine* e) {
-  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
-  const int w = e->panel_blocks;
-  hipStream_t mainS = e->stream, auxS = e->aux[0];
-  e->sync_next = 0;
-  int rc;
-  e->chol_update_kind = 0;  // chol_cols below factors panels: its products belong to the chain
-  e->cur = mainS;
-  if ((rc = chol_cols(e, 0, std::min(w, nct), nrt))) return rc;
-  for (int c0 = 0; c0 < nct; c0 += w) {
-    const int c1 = std::min(c0 + w, nct);
-    const int n0 = c1, n1 = std::min(c1 + w, nct);
-    if (n0 >= nct) break;
-    auto update = [&](int col_lo, int col_hi) {
-      GemmArgs g{};
-      g.C = e->dA + (int64_t)col_lo * TILE + (int64_t)col_lo * TILE * e->ld;
-      g.ldc = e->ld;
-      g.A = e->dA + (int64_t)col_lo * TILE + (int64_t)c0 * TILE * e->ld;
-      g.lda = e->ld;
-      g.B = g.A;
-      g.ldb = e->ld;
-      g.mt = col_hi - col_lo;
-      g.nt = nrt - col_lo;
-      g.k = (c1 - c0) * TILE;
-      g.alpha = -1.0;
-      g.beta = 1.0;
-      g.tri = 1;
-      return launch_gemm(e, g, 7);
-    };
-    e->cur = mainS;
-    if ((rc = update(n0, n1))) return rc;                 // U1
-    if ((rc = order_after(e, mainS, auxS))) return rc;
-    e->cur = auxS;
-    if ((rc = chol_cols(e, n0, n1, nrt))) return rc;      // panel p+1 (~24 small launches) beside U2
-    e->cur = mainS;
-    if (n1 < nct && (rc = update(n1, nct))) return rc;    // U2
-    if ((rc = order_after(e, auxS, mainS))) return rc;
-  }
-  e->cur = mainS;
-  return GMB_OK;
-}
-
-// Full-height chain on the MAIN stream, U2 on the CU-masked stream (scheme 2).
+// Look-ahead Cholesky for SMALL matrices (<= masked_max_blocks block columns, N <= 16k): right-looking over
+// panels; the latency-bound chain of panel p+1 (leaves, strips, in-panel products) runs on the main stream
+// beside U2(p), the bulk of the trailing update, which runs on the process-wide CU-masked stream (it leaves 4
+// compute units of every XCD to the chain).  Larger matrices use the plain recursion (chol_cols over the whole
+// matrix, one stream): there the chain is a few per cent of the work, and bulk updates that share the chip with
+// chain kernels lose more than the overlap wins -- r02: N = 50k 627 ms with look-ahead (bulk updates at 63
+// TF/s) vs 607 ms plain (70.8 TF/s); N = 100k 5.02 vs 4.75 s; N = 24k / 32k 1 % apart; N = 16k equal.
 int chol_lookahead_masked(gmb_engine* e) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
   const int w = e->panel_blocks;
@@ -1455,7 +1417,7 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream) {
     e->panel_blocks = atoi(pb);
     e->panel_auto = false;
   }
-  const char* cs = getenv("GMB_CHOL_SCHEME");  // 0 = unmasked look-ahead, 2 = masked bulk stream, default by size
+  const char* cs = getenv("GMB_CHOL_SCHEME");  // 0 = plain recursion, 2 = masked look-ahead, default by size
   if (cs) e->chol_scheme = atoi(cs);
   const char* mb = getenv("GMB_MASKED_MAX_BLOCKS");
   if (mb) e->masked_max_blocks = atoi(mb);
@@ -1707,15 +1669,9 @@ int gmb_factorize(gmb_engine* e) {
     const int nct = (int)(e->Np / TILE);
     e->panel_blocks = std::max(8, ((nct / 16 + 4) / 8) * 8);
   }
-  if (e->lookahead && e->Np / TILE > e->panel_blocks) {
-    // default (chol_scheme < 0): small matrices are chain-bound -- the masked bulk stream lets the chain run
-    // beside the trailing updates (N = 10k: 9.8 -> 9.0 ms); large ones lose more to the 12 % of compute
-    // units taken from the updates than the chain is worth (N = 30k: +5 %), they keep the full chip
-    const bool masked = e->aux_shared && (e->chol_scheme == 2 || (e->chol_scheme < 0 && e->Np / TILE <= e->masked_max_blocks));
-    if ((rc = masked ? chol_lookahead_masked(e) : chol_lookahead_full(e))) return rc;
-  } else if ((rc = chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) {
-    return rc;
-  }
+  const bool masked = e->lookahead && e->aux_shared && e->Np / TILE > e->panel_blocks &&
+                      (e->chol_scheme == 2 || (e->chol_scheme < 0 && e->Np / TILE <= e->masked_max_blocks));
+  if ((rc = masked ? chol_lookahead_masked(e) : chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) return rc;
   // 3. v = L^-1 y is row N of the factor
   hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
                      e->dscal + 1);

@@ -304,76 +304,6 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
     }
   };
 
-#if defined(GMB_GEMM_ROTATE)
-  // Experiment: the k-loop rotated by one k4 group -- the last group of a tile is issued AFTER the barrier, behind
-  // the LDS reads of the next tile's first group, so the post-barrier read latency hides under 16 MFMAs.
-  auto frag_read = [&](int st, int k4, double (&a)[WTM], double (&b)[WTN]) {
-    const double* As = &lds[st][0];
-    const double* Bs = &lds[st][KT * PA];
-#pragma unroll
-    for (int i = 0; i < WTM; ++i) a[i] = As[(k4 + kq) * PA + wm * (16 * WTM) + i * 16 + r16];
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) b[j] = Bs[(k4 + kq) * PB + wn * (16 * WTN) + j * 16 + r16];
-  };
-  auto frag_mfma = [&](const double (&a)[WTM], const double (&b)[WTN]) {
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-  };
-  if (kt0 < kt1) {
-    gload(kt0);
-    lstore(0);
-    __syncthreads();
-    int st = 0;
-    double fa[WTM], fb[WTN], na[WTM], nb[WTN];
-    frag_read(0, 0, fa, fb);
-    constexpr int NMFMA = WTM * WTN * (KT / 4 - 1), NMEM = NA + NB;  // MFMAs ahead of the barrier
-    constexpr int SLOT = NMFMA / (4 * NMEM) > 0 ? NMFMA / (4 * NMEM) : 1;
-    for (int kt = kt0; kt + 1 < kt1; ++kt) {
-      gload(kt + 1);
-#pragma unroll
-      for (int k4 = 0; k4 + 4 < KT; k4 += 4) {
-        frag_read(st, k4 + 4, na, nb);
-        frag_mfma(fa, fb);
-#pragma unroll
-        for (int i = 0; i < WTM; ++i) fa[i] = na[i];
-#pragma unroll
-        for (int jj = 0; jj < WTN; ++jj) fb[jj] = nb[jj];
-      }
-      lstore(st ^ 1);
-#pragma unroll
-      for (int q = 0; q < NMEM; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * SLOT * NMEM, 0);
-#pragma unroll
-      for (int q = 0; q < NMEM; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      }
-      __syncthreads();
-      frag_read(st ^ 1, 0, na, nb);
-      frag_mfma(fa, fb);  // last group of tile kt, behind the barrier
-#pragma unroll
-      for (int i = 0; i < WTM; ++i) fa[i] = na[i];
-#pragma unroll
-      for (int jj = 0; jj < WTN; ++jj) fb[jj] = nb[jj];
-      st ^= 1;
-    }
-#pragma unroll
-    for (int k4 = 0; k4 + 4 < KT; k4 += 4) {
-      frag_read(st, k4 + 4, na, nb);
-      frag_mfma(fa, fb);
-#pragma unroll
-      for (int i = 0; i < WTM; ++i) fa[i] = na[i];
-#pragma unroll
-      for (int jj = 0; jj < WTN; ++jj) fb[jj] = nb[jj];
-    }
-    frag_mfma(fa, fb);
-  }
-#else
   if (kt0 < kt1) {
     gload(kt0);
     lstore(0);
@@ -388,7 +318,8 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
     // for the global loads right after issuing them (63 TF/s).  Measured on one box, 8192^3 / 16384^2 x 3072:
     // 69.1 / 68.5 TF/s before, 73.4 / 73.0 TF/s with this order; N = 30k factorisation 152.3 -> 146.7 ms,
     // gradient 272.7 -> 263.5 ms (tools/gpu_ab_gemm.py; s_setprio around the MFMAs: -5 %; explicit fragment
-    // prefetch: no change).
+    // prefetch: no change; loop rotated by one k4 group so that the last 16 MFMAs of a tile sit behind the
+    // barrier and cover the next tile's first LDS reads: -1.5 %).
     constexpr int NMFMA = WTM * WTN * (KT / 4), NMEM = NA + NB;
     constexpr int SLOT = NMFMA / (4 * NMEM) > 0 ? NMFMA / (4 * NMEM) : 1;
     static_assert(2 * SLOT * NMEM <= NMFMA, "not enough MFMAs to interleave the staging with");
@@ -413,7 +344,6 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
     compute(st);
   }
 
-#endif
 
   // epilogue.  v_mfma_f64_16x16x4_f64 D layout: n = lane & 15, m = (lane >> 4) + 4 * reg.
   double* __restrict__ Cg = g.C + (g.cblk_stride > 0 ? gemm_noff(tn, BN, g.cblk_stride) : noff) + wn * (16 * WTN) + r16;

@@ -132,6 +132,76 @@ def test_two_ranks_one_gpu_match_oracle(gpu, world, N, model, panel):
     assert len({r[-1] for r in results}) == 1  # bit-identical gradient on every rank (optimisers stay in lock step)
 
 
+def _notpd_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gumbi_amd.distributed import DistributedEngine
+        from gumbi_amd.engine import Engine, KernelSpec
+        from oracle import gp_oracle as O
+
+        N, d = 900, 3
+        X, y, ls = O.synthetic_table(N, d, seed=2)
+        bad = 517  # in the fifth block row: owned by another rank than block row 0
+        X[bad, 1] = np.nan
+        theta = np.concatenate([ls, [1.0, 0.2]])
+        got = []
+        for eng in (DistributedEngine(0, panel_blocks=2), Engine(0)):
+            eng.set_data(X, y)
+            eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d))))
+            eng.set_theta(theta)
+            try:
+                eng.factorize()
+                got.append(("no error", -1))
+            except np.linalg.LinAlgError as err:
+                got.append(("LinAlgError", eng.notpd_index(), str(err)[:80]))
+            # the engine stays usable: a clean table factorises afterwards
+            X2 = X.copy()
+            X2[bad, 1] = 0.25
+            eng.set_data(X2, y)
+            eng.set_theta(theta)
+            eng.factorize()
+            got.append(round(float(eng.nlml()), 6))
+            eng.close()
+        out.put((rank, got))
+    except BaseException:
+        import traceback
+
+        out.put(("error", traceback.format_exc()[-3000:]))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_not_positive_definite_is_reported_identically_on_every_rank(gpu):
+    """A NaN input makes the covariance non-factorisable at its row: every rank of the multi-GPU driver must
+    return the SAME failure (GMB_ENOTPD -> LinAlgError, same global row index as the single engine -- the
+    diagonal squares are factored redundantly, so no rank can run ahead into a collective the others skip),
+    and the engines must remain usable afterwards."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_notpd_worker, args=(r, 3, port, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = _collect(out, 3, 300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got in results:
+        dist_err, dist_nl, single_err, single_nl = got
+        assert dist_err[0] == "LinAlgError" and single_err[0] == "LinAlgError", got
+        assert dist_err[1] == single_err[1] == 517, got
+        assert dist_nl == single_nl
+    assert len({str(g) for _, g in results}) == 1
+
+
 def _large_worker(rank, world, port, N, d, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
