@@ -226,6 +226,8 @@ def _large_worker(rank, world, port, N, d, out):
             eng.factorize()
             rows = [0, 127, 128, 5000, N // 2 + 1, N - 1]
             Lr = np.stack([eng.copy_factor(r, 1, 0, N)[0] for r in rows])
+            for a, r in enumerate(rows):
+                Lr[a, r + 1:] = 0.0  # above the diagonal the buffer holds scratch (schedule-dependent)
             v = eng.copy_v()
             mu, var = eng.predict(Xs)
             val, g = eng.nlml(grad=True)
