@@ -86,4 +86,24 @@ for w in widths:
     print(f"  rank {rank} of {G}, panel_blocks={w}: {t * 1e3:.1f} ms = {single / G / t:.2f} of ideal "
           f"({N**3 / 3 / G / t / 1e12:.1f} TF/s per GPU); {comm.calls} all-gathers, {comm.bytes / 1e9:.1f} GB received "
           f"(= {comm.bytes / 1e9 / 300:.3f} s at 300 GB/s if not hidden)", flush=True)
+# gradient: every rank holds the complete factor after the factorisation, so a single-engine factorisation puts this
+# GPU in exactly that state; the row-partitioned gradient then runs as rank `rank` of G (the other ranks' rows of U
+# arrive as copies of this rank's -- garbage values, real timing)
+eng.factorize()
+t0 = time.perf_counter()
+eng.nlml(grad=True)
+single_g = time.perf_counter() - t0
+comm = FakeComm(rank, G)
+times = []
+for rep in range(2):
+    eng.factorize()
+    comm.bytes = comm.calls = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.dist_nlml(comm, grad=True)
+    torch.cuda.synchronize()
+    times.append(time.perf_counter() - t0)
+t = min(times)
+print(f"  gradient: single engine {single_g * 1e3:.1f} ms; rank {rank} of {G}: {t * 1e3:.1f} ms = {single_g / G / t:.2f} of ideal; "
+      f"{comm.calls} all-gathers, {comm.bytes / 1e9:.1f} GB received (= {comm.bytes / 1e9 / 300:.3f} s at 300 GB/s if not hidden)", flush=True)
 eng.close()
