@@ -16,7 +16,8 @@ for N, d in [tuple(int(v) for v in t.split('x')) for t in os.environ.get('AB_SIZ
         t0 = time.perf_counter(); e.factorize(); t1 = time.perf_counter(); e.predict(Xs); t2 = time.perf_counter()
         e.factorize(); t3 = time.perf_counter(); e.nlml(grad=True); t4 = time.perf_counter()
         best = [min(best[0], t1 - t0), min(best[1], t2 - t1), min(best[2], t4 - t3)]
-    print('N=%d: factorize %.2f ms (%.1f TF/s)  predict %.2f ms (%.1f TF/s)  grad %.2f ms (%.1f TF/s)' % (N, best[0]*1e3, N**3/3/best[0]/1e12, best[1]*1e3, N*N*len(Xs)/best[1]/1e12, best[2]*1e3, 2*N**3/3/best[2]/1e12))
+    e.factorize(); nl = e.nlml()
+    print('N=%d: factorize %.2f ms (%.1f TF/s)  predict %.2f ms (%.1f TF/s)  grad %.2f ms (%.1f TF/s)  nlml %.12g' % (N, best[0]*1e3, N**3/3/best[0]/1e12, best[1]*1e3, N*N*len(Xs)/best[1]/1e12, best[2]*1e3, 2*N**3/3/best[2]/1e12, nl))
     e.close()
 '''
 for setting in sys.argv[1:]:
