@@ -28,7 +28,7 @@ def test_owned_blocks_partition():
 
 
 @pytest.mark.parametrize("N,world,w", [(1000, 2, 2), (100_000, 8, 0), (100_000, 8, 8), (50_000, 4, 16), (130, 3, 1),
-                                       (4096, 2, 8), (12_800, 8, 4)])
+                                       (4096, 2, 8), (12_800, 8, 4), (100, 3, 0), (128, 2, 1), (1, 2, 0), (127, 8, 3)])
 def test_plan_is_consistent_across_ranks(N, world, w):
     """Every rank issues the same sequence of collectives with the same sizes (anything else deadlocks RCCL);
     the rows named by SQUARE / PANEL / UPDATE steps partition their ranges; panels tile the columns."""
@@ -175,7 +175,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,N,w", [(2, 300, 1), (2, 256, 2), (2, 130, 1), (3, 700, 2), (2, 1100, 4), (3, 900, 0)])
+@pytest.mark.parametrize("world,N,w", [(2, 300, 1), (2, 256, 2), (2, 130, 1), (3, 700, 2), (2, 1100, 4), (3, 900, 0),
+                                       (3, 100, 0), (2, 128, 1), (4, 130, 2), (3, 384, 8)])
 def test_plan_replayed_with_numpy_blocks_over_gloo(world, N, w):
     import torch.multiprocessing as mp
 

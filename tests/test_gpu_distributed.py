@@ -111,7 +111,8 @@ def _free_port():
 
 @pytest.mark.parametrize("world,N,model,panel", [(2, 700, "matern", 0), (2, 512, "matern", 1), (3, 1000, "matern", 2),
                                                  (2, 600, "additive", 0), (3, 420, "composite", 1),
-                                                 (2, 2500, "matern", 3), (3, 5000, "matern", 0)])
+                                                 (2, 2500, "matern", 3), (3, 5000, "matern", 0),
+                                                 (3, 100, "matern", 0), (2, 128, "matern", 1), (4, 130, "matern", 2)])
 def test_two_ranks_one_gpu_match_oracle(gpu, world, N, model, panel):
     import torch.multiprocessing as mp
 
