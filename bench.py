@@ -101,11 +101,12 @@ def build_gp(cfg, device):
     return gp
 
 
-def step_flops(N, M, n_eval):
+def step_flops(N, M, n_eval, n_refactor=1):
     """Algorithmic flops of one step: per evaluation N^3/3 (Cholesky) +
-    2N^3/3 (inverse + Sigma^-1); final Cholesky N^3/3; predict N^2 M + 4 N M."""
+    2N^3/3 (inverse + Sigma^-1); N^3/3 per re-factorisation at the MAP (none when the optimiser's last
+    evaluation was at the MAP: its factorisation is still resident); predict N^2 M + 4 N M."""
     n3 = float(N) ** 3
-    return n_eval * n3 + n3 / 3.0 + float(N) ** 2 * M + 4.0 * N * M
+    return n_eval * n3 + n_refactor * n3 / 3.0 + float(N) ** 2 * M + 4.0 * N * M
 
 
 def pmc_traffic(config, kernel_filter):
@@ -288,13 +289,14 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
     def one_step():
         gp.find_MAP(maxeval=maxeval)
         eng.predict_device(xs_dev.data_ptr(), M, cfg["d"], mean_dev.data_ptr(), var_dev.data_ptr(), True)
-        return gp.n_eval
+        return gp.n_eval, gp.n_refactor
 
     for _ in range(warmup):
         one_step()
     clock.sync()
     t0 = time.perf_counter()
-    n_evals = [one_step() for _ in range(steps)]
+    counts = [one_step() for _ in range(steps)]
+    n_evals = [c[0] for c in counts]
     clock.sync()
     elapsed = time.perf_counter() - t0
     # Roofline pass: ONE more step of the same workload with a HIP event pair around every GEMM launch (on
@@ -346,8 +348,8 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
     # streams per process slow every kernel down on this stack
     eng.close()
     gp.engine = None
-    return dict(elapsed=elapsed, n_evals=n_evals, M=M, tm=tm, phases=phases, finite=finite,
-                flops=sum(step_flops(N, M, n) for n in n_evals))
+    return dict(elapsed=elapsed, n_evals=n_evals, n_refactor=[c[1] for c in counts], M=M, tm=tm, phases=phases, finite=finite,
+                flops=sum(step_flops(N, M, n, r) for n, r in counts))
 
 
 def end_to_end_fit(cfg, local_rank, map_evals):
@@ -562,6 +564,7 @@ def main():
             }
             if "n_evals" in res:
                 out["config"]["map_evals_per_step"] = res["n_evals"]
+                out["config"]["refactorizations_at_the_map_per_step"] = res["n_refactor"]
             try:
                 tf, cyc = engine.mfma_f64_peak(local_rank)
                 out["roofline"]["mfma_only_microbench_tflops"] = round(tf, 2)  # sustained ceiling under DVFS

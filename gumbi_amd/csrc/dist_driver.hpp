@@ -141,6 +141,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   const int G = comm->world, rank = comm->rank;
   e->factored = false;
   e->factor_consumed = false;
+  e->have_alpha = false;
   e->notpd = -1;
   gmb_timings& tm = e->tm;
   tm.kbuild_ms = tm.chol_ms = tm.chol_gemm_ms = tm.chol_gemm_flops = 0.0;
@@ -387,6 +388,7 @@ int dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
   HIP_TRY(e, hipStreamSynchronize(mainS));
   tm.grad_ms = tg.ms();
   ev_collect(e);
+  e->have_alpha = true;
   h.assign(GACC_DOUBLES, 0.0);
   for (int q = 0; q < G; ++q)
     for (int i = 0; i < GACC_DOUBLES; ++i) h[i] += all[(size_t)q * GACC_DOUBLES + i];

@@ -95,7 +95,10 @@ struct gmb_engine {
   int32_t* dinfo = nullptr;
   double* dv = nullptr;
   bool factored = false;
-  bool factor_consumed = false;  // Sigma^-1 has overwritten the factor (gradient call)
+  bool factor_consumed = false;  // U = L^-T sits in the factor buffer's diagonal tiles (multi-GPU gradient; or a failed one)
+  bool have_alpha = false;       // dalpha holds Sigma^-1 y of the current factorisation
+  double* dDiagSave = nullptr;   // the factor's diagonal blocks while the gradient keeps U in their place
+  int64_t cap_diag = 0;
   int64_t notpd = -1;
   double logdet = 0.0, vnorm2 = 0.0;
 
@@ -1203,8 +1206,11 @@ int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
   tm.grad_ms = tm.grad_gemm_ms = tm.grad_gemm_flops = 0.0;
   if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
   if ((rc = grad_workspace(e))) return rc;
-  PhaseTimer tg(e);
   const int nt = (int)(e->Np / TILE);
+  if ((rc = ensure(e, &e->dDiagSave, &e->cap_diag, (int64_t)nt * TILE * TILE))) return rc;
+  PhaseTimer tg(e);
+  // the diagonal blocks of L are put back at the end: U takes their place in between
+  hipLaunchKernelGGL(diag_blocks_copy_kernel, dim3(nt), dim3(256), 0, e->stream, e->dA, e->ld, e->dDiagSave, 1);
   // 0. inverses of all diagonal factor blocks, one workgroup each (kept off the Cholesky's chain)
   {
     InvArgs ia;
@@ -1236,13 +1242,18 @@ int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
     hipLaunchKernelGGL(reset_pad_cols_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, e->stream,
                        e->dA, e->ld, e->N, e->Np);
   HIP_TRY(e, hipGetLastError());
-  // 3. Sigma^-1 = U U^T (lower triangle) into dW;  4. fused trace reductions
+  // 3. Sigma^-1 = U U^T (lower triangle) into dW -- the last reader of U: the factor's diagonal blocks go back
   if ((rc = grad_sigma_inv_rows(e, 0, 1, e->dW, e->Np, false))) return rc;
+  hipLaunchKernelGGL(diag_blocks_copy_kernel, dim3(nt), dim3(256), 0, e->stream, e->dA, e->ld, e->dDiagSave, 0);
+  HIP_TRY(e, hipGetLastError());
+  // 4. fused trace reductions
   if ((rc = grad_reduce(e, 0, 1, e->dW, e->Np, false, h))) return rc;
   tg.stop();
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   tm.grad_ms = tg.ms();
   ev_collect(e);
+  e->factor_consumed = false;  // lower triangle = L again (the upper triangle keeps U: scratch as far as L goes)
+  e->have_alpha = true;
   return GMB_OK;
 }
 
@@ -1484,7 +1495,7 @@ void gmb_destroy(gmb_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (int a = 0; a < 3; ++a)
     if (e->aux[a]) (void)hipStreamSynchronize(e->aux[a]);
-  void* ptrs[] = {e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
+  void* ptrs[] = {e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv, e->dV, e->dXs, e->txs, e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart};
   for (void* p : ptrs)
@@ -1616,12 +1627,15 @@ int gmb_timings_get(const gmb_engine* e, gmb_timings* out) {
 
 int64_t gmb_notpd_index(const gmb_engine* e) { return e ? e->notpd : -1; }
 
+int gmb_factor_valid(const gmb_engine* e) { return (e && e->N > 0 && e->have_theta && e->factored && !e->factor_consumed) ? 1 : 0; }
+
 int gmb_factorize(gmb_engine* e) {
   int rc = require_ready(e, false);
   if (rc) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
   e->factored = false;
   e->factor_consumed = false;
+  e->have_alpha = false;
   e->notpd = -1;
   gmb_timings& tm = e->tm;
   tm.kbuild_ms = tm.chol_ms = tm.chol_gemm_ms = tm.chol_gemm_flops = 0.0;
@@ -1850,7 +1864,7 @@ int gmb_copy_alpha(const gmb_engine* ce, double* out) {
   int rc = require_ready(e, false);
   if (rc) return rc;
   if (!out) return fail(e, GMB_EINVAL, "null output");
-  if (!e->factor_consumed || !e->dalpha)
+  if (!e->have_alpha || !e->dalpha)
     return fail(e, GMB_EINVAL, "alpha exists only after a gradient evaluation (gmb_nlml with grad)");
   HIP_TRY(e, hipMemcpy(out, e->dalpha, e->N * sizeof(double), hipMemcpyDeviceToHost));
   return GMB_OK;

@@ -362,6 +362,24 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
   else *reinterpret_cast<pk_d2*>(m) = *reinterpret_cast<const pk_d2*>(q);
 }
 
+// Save (to_save) / restore the 128 x 128 diagonal blocks of the factor buffer: the gradient keeps U = L^-T in the
+// upper triangle AND the diagonal tiles of that buffer, so putting the diagonal blocks of L back afterwards
+// leaves the factorisation intact (the strictly lower blocks are never touched) -- predict() after a
+// gradient evaluation needs no re-factorisation.
+__global__ __launch_bounds__(256) void diag_blocks_copy_kernel(double* __restrict__ A, int64_t ld,
+                                                               double* __restrict__ save, int to_save) {
+  double* blk = A + (int64_t)blockIdx.x * 128 * (ld + 1);
+  double* sv = save + (int64_t)blockIdx.x * 128 * 128;
+  typedef double dg_d2 __attribute__((ext_vector_type(2)));
+  const int r = (threadIdx.x & 63) * 2, c0 = threadIdx.x >> 6;
+  for (int c = c0; c < 128; c += 4) {
+    dg_d2* m = reinterpret_cast<dg_d2*>(blk + r + (int64_t)c * ld);
+    dg_d2* q = reinterpret_cast<dg_d2*>(sv + r + c * 128);
+    if (to_save) *q = *m;
+    else *m = *q;
+  }
+}
+
 // alpha = W^T v with W = L^-1 lower triangular, column-major: alpha_j = sum_{k>=j} W[k + j*ld] v_k
 __global__ __launch_bounds__(256) void wt_v_kernel(const double* W, int64_t ld, const double* v,
                                                    int64_t n, double* alpha) {

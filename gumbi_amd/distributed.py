@@ -263,6 +263,9 @@ class DistributedEngine:
     def notpd_index(self):
         return self.eng.notpd_index()
 
+    def factor_is_current(self):
+        return self.eng.factor_is_current()  # False after a gradient: U = L^-T sits in the factor buffer
+
     def copy_factor(self, *args, **kwargs):
         return self.eng.copy_factor(*args, **kwargs)
 

@@ -201,6 +201,7 @@ _SIGNATURES = {
     "gmb_set_theta": (C.c_int, [C.c_void_p, _DBL_P, C.c_int32]),
     "gmb_factorize": (C.c_int, [C.c_void_p]),
     "gmb_notpd_index": (C.c_int64, [C.c_void_p]),
+    "gmb_factor_valid": (C.c_int, [C.c_void_p]),
     "gmb_nlml": (C.c_int, [C.c_void_p, _DBL_P, _DBL_P]),
     "gmb_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                               C.c_void_p, C.c_int32]),
@@ -385,6 +386,11 @@ class Engine:
 
     def notpd_index(self) -> int:
         return int(self._lib.gmb_notpd_index(self._h))
+
+    def factor_is_current(self) -> bool:
+        """True while a usable factorisation of the current (data, kernel, theta) is resident -- also after
+        ``nlml(grad=True)``: ``predict`` may follow without another ``factorize``."""
+        return bool(self._lib.gmb_factor_valid(self._h))
 
     def nlml(self, grad: bool = False):
         val = C.c_double()

@@ -102,6 +102,8 @@ class HipGP(Regressor):
         }
         self.nlml_trace = []
         self._rejected = 0
+        self._last_eval_theta = None
+        self.n_refactor = 0
         self._theta_fitted = None
 
     # ------------------------------------------------------------------------------------------
@@ -338,6 +340,7 @@ class HipGP(Regressor):
             self._rejected += 1
             return _REJECTED, np.zeros_like(u)
         self.nlml_trace.append(float(nlml))
+        self._last_eval_theta = theta.copy()
         return float(f), g
 
     # -- fitting -----------------------------------------------------------------------------------------------------------
@@ -357,6 +360,7 @@ class HipGP(Regressor):
             theta0 = self._theta_from_dict(start, theta0)
         self.nlml_trace = []
         self._rejected = 0
+        self._last_eval_theta = None
         if theta is not None:
             th = self._theta_from_dict(theta, theta0) if isinstance(theta, dict) else np.asarray(theta, float)
             self.n_eval = 0
@@ -378,9 +382,17 @@ class HipGP(Regressor):
             elif not res.success and res.status != 1:  # status 1 = evaluation budget (maxeval) reached
                 warnings.warn(f"find_MAP: L-BFGS-B stopped without converging ({res.message})", RuntimeWarning,
                               stacklevel=2)
-        # leave the engine factorised at the MAP so predict() reuses the resident factor
-        self.engine.set_theta(th)
-        self.engine.factorize()
+        # leave the engine factorised at the MAP so predict() reuses the resident factor.  When the optimiser's
+        # last evaluation was AT the MAP (the usual L-BFGS-B ending) that factorisation is still resident -- the
+        # gradient puts the factor back together -- and nothing is recomputed (the reference factorises again
+        # in every predict call, pymc/GP.py:845-847)
+        current = getattr(self.engine, "factor_is_current", lambda: False)
+        if self._last_eval_theta is not None and np.array_equal(th, self._last_eval_theta) and current():
+            self.n_refactor = 0
+        else:
+            self.engine.set_theta(th)
+            self.engine.factorize()
+            self.n_refactor = 1
         self._theta_fitted = th
         self.MAP = self._theta_to_dict(th)
         return self.MAP

@@ -219,5 +219,8 @@ class IcmEngine:
             var += st["sigma"] ** 2 * st["bn"][task]
         return mean, var
 
+    def factor_is_current(self):
+        return False  # one inner engine serves the P systems in turn: nothing stays resident for all of them
+
     def close(self):
         self.eng.close()

@@ -163,10 +163,15 @@ int gmb_set_theta(gmb_engine* e, const double* theta, int32_t n);
  * (pymc/GP.py:845-847) does first.  Returns GMB_ENOTPD if a pivot is <= 0 or NaN. */
 int gmb_factorize(gmb_engine* e);
 int64_t gmb_notpd_index(const gmb_engine* e); /* 0-based failing row after GMB_ENOTPD, else -1 */
+/* 1 while the engine holds a usable factorisation of the current (data, kernel, theta): after gmb_factorize,
+ * and still after gmb_nlml with a gradient (the single-GPU gradient puts the factor's diagonal blocks back);
+ * 0 after gmb_set_* or after gmb_dist_nlml with a gradient (which leaves U = L^-T in the factor buffer). */
+int gmb_factor_valid(const gmb_engine* e);
 
 /* Negative log marginal likelihood  N/2 log 2pi + sum log L_ii + |v|^2/2  of the last
  * factorisation, and (if grad != NULL, length gmb_theta_size) its gradient w.r.t. natural-scale
- * theta: 1/2 tr((Sigma^-1 - a a^T) dSigma/dtheta).  Priors and Jacobians are added by the Python
+ * theta: 1/2 tr((Sigma^-1 - a a^T) dSigma/dtheta).  The factorisation stays valid (gmb_predict may follow
+ * without another gmb_factorize).  Priors and Jacobians are added by the Python
  * caller so the MAP formula stays auditable.  Replaces the likelihood part of pm.find_MAP's
  * objective/gradient (pymc/GP.py:580, 811). */
 int gmb_nlml(gmb_engine* e, double* nlml, double* grad);

@@ -55,6 +55,8 @@ def test_step_flops_counts_cholesky_inverse_and_prediction():
     final = N**3 / 3 + float(N) ** 2 * M                # re-factorisation + N^2 M solve of the grid prediction
     got = bench.step_flops(N, M, n_eval)
     assert abs(got - (n_eval * per_eval + final)) / got < 0.02
+    # no re-factorisation at the MAP when the optimiser ended on an evaluated point: one Cholesky less
+    assert abs(bench.step_flops(N, M, n_eval, 0) - (got - N**3 / 3)) / got < 1e-12
 
 
 def test_roofline_block_is_the_trailing_update_alone():

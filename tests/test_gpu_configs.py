@@ -167,7 +167,7 @@ def test_c5_size_on_one_gpu(gpu):
     assert val == nl and np.all(np.isfinite(g)) and g.shape == (d + 2,)
     alpha = eng.copy_alpha()
     assert np.isfinite(alpha).all()
-    eng.factorize()  # the gradient consumed the factor
+    assert eng.factor_is_current()  # the gradient leaves the factorisation intact: no second factorize
     Xs = O.synthetic_grid(d, res=100)
     t0 = time.perf_counter()
     mu, var = eng.predict(Xs, with_noise=True)

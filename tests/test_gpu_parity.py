@@ -299,12 +299,24 @@ def test_nlml_gradient_matches_oracle(gpu, kind, ard):
     theta = O.pack_theta(spec, ls if ard else [1.2], 1.2, 0.25)
     eng = make_engine(spec, theta, X, y)
     eng.factorize()
+    Xs = np.random.default_rng(4).standard_normal((40, d))
+    mu0, var0 = eng.predict(Xs)
+    L0, v0 = np.tril(eng.copy_factor()), eng.copy_v()
     val, g = eng.nlml(grad=True)
     val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
     assert np.isclose(val, val_r, rtol=1e-11)
     assert np.max(np.abs(g - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
-    with pytest.raises(ValueError):
-        eng.predict(X[:4])  # the factor was consumed by the gradient
+    # the gradient borrows the factor buffer's upper triangle and diagonal tiles for U = L^-T and puts the
+    # diagonal blocks back: the factorisation is intact afterwards -- same factor, same predictions, bit for bit,
+    # and a second gradient evaluation gives the same numbers without a re-factorisation
+    assert eng.factor_is_current()
+    assert np.array_equal(np.tril(eng.copy_factor()), L0) and np.array_equal(eng.copy_v(), v0)
+    mu1, var1 = eng.predict(Xs)
+    assert np.array_equal(mu1, mu0) and np.array_equal(var1, var0)
+    val2, g2 = eng.nlml(grad=True)
+    assert val2 == val and np.max(np.abs(g2 - g)) < 1e-12 * max(1.0, np.max(np.abs(g)))
+    eng.set_theta(theta)
+    assert not eng.factor_is_current()
 
 
 @pytest.mark.parametrize("two_outputs,lin,hetero,n", [(True, True, True, 90), (False, True, False, 300), (True, False, False, 200)])
