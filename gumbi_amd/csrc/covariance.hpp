@@ -28,7 +28,8 @@ constexpr int MAX_TABS = 5;     // GMB_MAX_COREG + output coregion
 constexpr int MAX_LIN = 8;      // GMB_MAX_LIN
 
 // Pre-processed coordinates of a point set (structure-of-arrays, padded length `npad`):
-//   xs[k*npad + i]  continuous dims scaled by 1/ls_k (zero for padded dims / points)
+//   xs[k*npad + i]  continuous dims scaled by 1/ls_k (zero for padded dims / points), k < nc_pad;
+//                   row nc_pad holds the squared norm of the scaled point (so xs has nc_pad + 1 <= 17 rows)
 //   xl[k*npad + i]  linear dims minus c_k
 //   cat[t*npad + i] category index per coregion table
 struct PointSet {
@@ -125,6 +126,73 @@ __device__ __forceinline__ double stationary(double r2) {
   }
 }
 
+// --- interior tiles: squared distances on the matrix pipe -------------------------------------------
+// exp(x) for FINITE x <= ~0 (interior tiles only, whose 256 points were checked finite): the reduction's
+// integer part comes out of the mantissa of x*log2(e) + 1.5*2^52 (no v_rndne / v_cvt), and 2^k goes straight
+// into the exponent field (x >= -700 keeps the result normal, so no v_ldexp).  Same polynomial as exp_nonpos.
+__device__ __forceinline__ double exp_interior(double x) {
+  x = fmax(x, -700.0);
+  const double magic = 6755399441055744.0;  // 1.5 * 2^52
+  const double t = fma(x, 1.4426950408889634074, magic);
+  const double k = t - magic;
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821614599e-10;
+  p = fma(p, r, 2.0876756987868098979e-09);
+  p = fma(p, r, 2.5052108385441718775e-08);
+  p = fma(p, r, 2.7557319223985890653e-07);
+  p = fma(p, r, 2.7557319223985892511e-06);
+  p = fma(p, r, 2.4801587301587301566e-05);
+  p = fma(p, r, 1.9841269841269841253e-04);
+  p = fma(p, r, 1.3888888888888889419e-03);
+  p = fma(p, r, 8.3333333333333332177e-03);
+  p = fma(p, r, 4.1666666666666664354e-02);
+  p = fma(p, r, 1.6666666666666665741e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const int hi = __double2hiint(p) + (__double2loint(t) << 20);
+  return __hiloint2double(hi, __double2loint(p));
+}
+
+// sqrt(p), p >= 1e-12 finite: sqrt_pos without the refinement of h (its error enters the last correction
+// only to second order)
+__device__ __forceinline__ double sqrt_interior(double p) {
+  const double y = __builtin_amdgcn_rsq(p);
+  double g = p * y;
+  const double h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  const double d = fma(-g, g, p);
+  return fma(d, h, g);
+}
+
+// eta2 * k(r2) from the contraction's output q: q = -r2/2 for ExpQuad (the -1/2 rides in the operands),
+// q = r2 otherwise.  Rounding of the expansion |a|^2 + |b|^2 - 2ab can leave q a few ulp(|a|^2) on the wrong
+// side of zero: clamped, as PyMC clips its own expansion (pm.gp.cov.Stationary.square_dist).
+template <int KIND>
+__device__ __forceinline__ double stationary_interior(double q, double eta2) {
+  if constexpr (KIND == 0) {
+    return eta2 * exp_interior(fmin(q, 0.0));
+  } else {
+    const double p = fmax(q + 1e-12, 1e-12);  // = max(q, 0) + 1e-12; the sum first, so that fmax sees an arithmetic
+                                              // result and needs no canonicalising v_max of its own
+    const double r = sqrt_interior(p);
+    if constexpr (KIND == 1) {
+      const double s5 = 2.23606797749978969641;
+      const double poly = fma(eta2 * (5.0 / 3.0), p, fma(eta2 * s5, r, eta2));
+      return poly * exp_interior(-s5 * r);
+    } else if constexpr (KIND == 2) {
+      const double s3 = 1.73205080756887729353;
+      return fma(eta2 * s3, r, eta2) * exp_interior(-s3 * r);
+    } else if constexpr (KIND == 3) {
+      return eta2 * exp_interior(-r);
+    } else {
+      return eta2 * exp_interior(-0.5 * r);
+    }
+  }
+}
+
 // d k / d r2 (for the NLML gradient)
 template <int KIND>
 __device__ __forceinline__ double stationary_dr2(double r2) {
@@ -171,11 +239,14 @@ __global__ void prep_points_kernel(PrepArgs a) {
   if (i >= a.npad) return;
   const bool real = i < a.n;
   const double* row = a.X + i * a.ldx;
+  double nrm = 0.0;
   for (int k = 0; k < a.nc_pad; ++k) {
     double v = 0.0;
     if (real && k < a.nc) v = row[a.idx_cont[k]] * a.inv_ls[k];
     a.xs[(int64_t)k * a.npad + i] = v;
+    nrm = fma(v, v, nrm);
   }
+  a.xs[(int64_t)a.nc_pad * a.npad + i] = nrm;  // row nc_pad: |x / ls|^2 (the interior tiles' augmented coordinate)
   for (int k = 0; k < a.n_lin; ++k)
     a.xl[(int64_t)k * a.npad + i] = real ? row[a.idx_lin[k]] - a.c_lin[k] : 0.0;
   for (int t = 0; t < a.n_tab; ++t) {
@@ -214,8 +285,80 @@ struct CovTileArgs {
   int32_t row_first, row_stride;
 };
 
+// One interior 128 x 128 tile (every row and column real, strictly below the diagonal of the training
+// matrix, stationary term only, all 256 points finite): the squared distances come off the MATRIX pipe.
+// With augmented coordinates  a' = (-2 x'_1 .. -2 x'_d, 1, |x'|^2),  b' = (x_1 .. x_d, |x|^2, 1)  the whole
+// r^2 = |x|^2 + |x'|^2 - 2 x.x' is ONE contraction of length d + 2 (PyMC's own expansion,
+// pm.gp.cov.Stationary.square_dist; for ExpQuad the operands carry the -1/2 as well), i.e. ceil((d+2)/4)
+// v_mfma_f64_16x16x4_f64 per 16 x 16 entries, and the vector pipe is left with the transcendental part
+// alone: Matern-5/2, d = 8: 54 -> 37 VALU instructions per entry and no LDS traffic at all (the direct
+// form spends 16 of them on differences and 4 ds_read_b128 on broadcasting the column point).
+// Operands sit in registers for the whole tile: a wave owns 32 rows x 128 columns; the D layout
+// (n = lane & 15 <-> row, m = (lane >> 4) + 4 reg <-> column) makes every store a set of 128 B row segments.
+template <int KIND, int NC, bool ACC>
+__device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const int64_t gi0, const int64_t gj0) {
+  constexpr int NG = (NC + 2 + 3) / 4;  // k groups of the augmented contraction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  constexpr double sc = KIND == 0 ? 1.0 : -2.0;  // scale of the column point's coordinates
+  constexpr double sn = KIND == 0 ? -0.5 : 1.0;  // scale of both squared norms
+  double brow[2][NG];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    const double* src = a.rows.xs + gi0 + 32 * wave + 16 * ib + r16;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int k = 4 * g + kq;
+      double v = k <= NC ? src[(int64_t)k * a.rows.npad] : 0.0;
+      if (k == NC) v *= sn;
+      if (k == NC + 1) v = 1.0;
+      brow[ib][g] = v;
+    }
+  }
+  double acol[8][NG];
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    const double* src = a.cols.xs + gj0 + 16 * jb + r16;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int k = 4 * g + kq;
+      // coordinate k of the column point; augmented slot NC is the constant 1, slot NC + 1 the norm (row NC)
+      double v = k <= NC + 1 ? src[(int64_t)(k == NC + 1 ? NC : k) * a.cols.npad] : 0.0;
+      v *= k < NC ? sc : sn;
+      if (k == NC) v = 1.0;
+      acol[jb][g] = v;
+    }
+  }
+  const double eta2 = a.p.eta2;
+  const uint64_t col_bytes = (uint64_t)a.ldo * 8u;
+  char* tile = reinterpret_cast<char*>(a.out + (gi0 - a.i0) + (gj0 - a.j0) * a.ldo);  // uniform
+  const uint32_t lane_off = (uint32_t)((32 * wave + r16) * 8) + (uint32_t)kq * (uint32_t)col_bytes;
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    d4 acc[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[jb][g], brow[ib][g], acc[ib], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        const double v = stationary_interior<KIND>(acc[ib][r], eta2);
+        double* dst = reinterpret_cast<double*>(tile + ((uint64_t)(16 * jb + 4 * r) * col_bytes + 128u * ib) + lane_off);
+        if constexpr (ACC) *dst += v;  // additive models: later terms add to the first pass
+        else *dst = v;
+      }
+  }
+}
+
+// (__launch_bounds__(256, 2): with at most 256 registers per lane the compiler keeps the MFMA results in
+// VGPRs; otherwise they land in AGPRs and every entry pays two v_accvgpr_read.)
 template <int KIND, int NC>
-__global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
+__global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
   __shared__ double xj[NC][TILE];
   __shared__ double lj[MAX_LIN][TILE];
   __shared__ double li[MAX_LIN][TILE];
@@ -255,10 +398,32 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
   if (a.mode == COV_TRAIN && a.lower_only && gi0 + TILE - 1 < gj0) return;
 
   const int tid = threadIdx.x;
+  const CovParams& p = a.p;
+  // Interior tiles (almost every tile of a large matrix): stationary term only, every row and column real
+  // and -- for the training matrix -- the tile strictly below the diagonal.  They take the matrix-pipe form
+  // (cov_interior_tile) unless one of their 256 points is not finite (or absurdly far out): such tiles, like
+  // the diagonal and boundary ones, go through the direct loop below, which propagates NaN into the
+  // factorisation (-> GMB_ENOTPD) and into predictions exactly as the reference's arithmetic would.
+  const bool full = gi0 + TILE <= a.rows.n && gj0 + TILE <= a.cols.n;
+  const bool below = a.mode != COV_TRAIN || gj0 + TILE <= gi0;
+#ifndef GMB_KBUILD_DIRECT
+  // (kinds with a kink at r = 0 -- Matern-1/2, Exponential -- keep the direct differences everywhere: an error e
+  // of the expansion becomes e / (2 r) in exp(-r) near coinciding points, 5e-10 at r^2 + 1e-12 = 1e-12)
+  if constexpr (KIND <= 2) {
+    if (full && below && p.n_lin == 0 && p.n_tab == 0) {
+      const double nrm = tid < TILE ? a.rows.xs[(int64_t)NC * a.rows.npad + gi0 + tid]
+                                    : a.cols.xs[(int64_t)NC * a.cols.npad + gj0 + (tid - TILE)];
+      if (!__syncthreads_or(!(nrm < 1.0e150))) {
+        if (a.accumulate) cov_interior_tile<KIND, NC, true>(a, gi0, gj0);
+        else cov_interior_tile<KIND, NC, false>(a, gi0, gj0);
+        return;
+      }
+    }
+  }
+#endif
   const int il = tid & (TILE - 1);
   const int jh = tid >> 7;  // which half of the tile's columns
   const int64_t gi = gi0 + il;
-  const CovParams& p = a.p;
 
   // stage the tile's column points
   for (int idx = tid; idx < NC * TILE; idx += 256) {
@@ -290,11 +455,8 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(CovTileArgs a) {
     ndiag += p.jitter;
   }
 
-  // Fast path (almost every tile of a large matrix): stationary term only, every row and column
-  // real, and -- for the training matrix -- the tile strictly below the diagonal: no per-entry
-  // conditionals at all (the general loop below carries ~90 branches for the boundary cases).
-  const bool full = gi0 + TILE <= a.rows.n && gj0 + TILE <= a.cols.n;
-  const bool below = a.mode != COV_TRAIN || gj0 + TILE <= gi0;
+  // Direct form without per-entry conditionals (interior tiles that hold a non-finite point; every interior
+  // tile under -DGMB_KBUILD_DIRECT, the A/B switch for the matrix-pipe form)
   if (full && below && p.n_lin == 0 && p.n_tab == 0) {
     const double* xjp = &xj[0][jh * (TILE / 2)];
     auto entry = [&](int jj) {

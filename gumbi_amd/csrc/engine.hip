@@ -692,6 +692,37 @@ int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int6
 
 PointSet train_set(const gmb_engine* e) { return PointSet{e->xs, e->xl, e->cat, e->N, e->Nr}; }
 
+// Covariance build: lower-triangular tiles of Sigma = K + noise + jitter, the y row, identity padding, written
+// column-major into `out` (Nr x Np, leading dimension ldo) -- the factor buffer in gmb_factorize.
+int build_sigma(gmb_engine* e, double* out, int64_t ldo) {
+  int rc;
+  CovTileArgs a{};
+  a.p = e->cp;
+  a.rows = train_set(e);
+  a.cols = train_set(e);
+  a.out = out;
+  a.ldo = ldo;
+  a.i0 = a.j0 = 0;
+  a.ti = (int)(e->Nr / TILE);
+  a.tj = (int)(e->Np / TILE);
+  a.mode = COV_TRAIN;
+  a.lower_only = 1;
+  a.tri_grid = 1;
+  a.y = e->dy;
+  if ((rc = launch_cov(e, a))) return rc;
+  // additive models: the other terms add their covariance to the real entries, one pass each
+  for (size_t t = 1; t < e->terms.size(); ++t) {
+    if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[t].pa))) return rc;
+    a.p = e->terms[t].cp;
+    a.accumulate = 1;
+    if ((rc = launch_cov(e, a))) return rc;
+  }
+  if (e->terms.size() > 1 &&
+      (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
+    return rc;
+  return GMB_OK;
+}
+
 // ---- Cholesky recursion -------------------------------------------------------------------
 // `rend`: block row where the panel solve / updates stop (the whole matrix, or the end of a
 // diagonal square when the rows below are solved later in bulk)
@@ -1590,7 +1621,7 @@ int gmb_set_theta(gmb_engine* e, const double* theta, int32_t n) {
   int rc = apply_theta(e);
   if (rc) return rc;
   if (e->cap_pts < e->Nr) {
-    if ((rc = alloc(e, &e->xs, (int64_t)16 * e->Nr))) return rc;
+    if ((rc = alloc(e, &e->xs, (int64_t)17 * e->Nr))) return rc;
     if ((rc = alloc(e, &e->xl, (int64_t)MAX_LIN * e->Nr))) return rc;
     if ((rc = alloc(e, &e->cat, (int64_t)MAX_TABS * e->Nr))) return rc;
     e->cap_pts = e->Nr;
@@ -1646,32 +1677,7 @@ int gmb_factorize(gmb_engine* e) {
 
   // 1. covariance build: lower-triangular tiles of Sigma, y row, identity padding
   PhaseTimer tk(e);
-  {
-    CovTileArgs a{};
-    a.p = e->cp;
-    a.rows = train_set(e);
-    a.cols = PointSet{e->xs, e->xl, e->cat, e->N, e->Nr};
-    a.out = e->dA;
-    a.ldo = e->ld;
-    a.i0 = a.j0 = 0;
-    a.ti = (int)(e->Nr / TILE);
-    a.tj = (int)(e->Np / TILE);
-    a.mode = COV_TRAIN;
-    a.lower_only = 1;
-    a.tri_grid = 1;
-    a.y = e->dy;
-    if ((rc = launch_cov(e, a))) return rc;
-    // additive models: the other terms add their covariance to the real entries, one pass each
-    for (size_t t = 1; t < e->terms.size(); ++t) {
-      if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[t].pa))) return rc;
-      a.p = e->terms[t].cp;
-      a.accumulate = 1;
-      if ((rc = launch_cov(e, a))) return rc;
-    }
-    if (e->terms.size() > 1 &&
-        (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
-      return rc;
-  }
+  if ((rc = build_sigma(e, e->dA, e->ld))) return rc;
   tk.stop();
   // 2. Cholesky
   PhaseTimer tc(e);
@@ -1755,7 +1761,7 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
   if (e->Mt_cap < Mt) {
     if ((rc = alloc(e, &e->dV, Mt * e->Np))) return rc;
     if ((rc = alloc(e, &e->dXs, Mt * (int64_t)e->D))) return rc;
-    if ((rc = alloc(e, &e->txs, (int64_t)16 * Mt))) return rc;
+    if ((rc = alloc(e, &e->txs, (int64_t)17 * Mt))) return rc;
     if ((rc = alloc(e, &e->txl, (int64_t)MAX_LIN * Mt))) return rc;
     if ((rc = alloc(e, &e->tcat, (int64_t)MAX_TABS * Mt))) return rc;
     if ((rc = alloc(e, &e->dkss, Mt))) return rc;
@@ -1999,6 +2005,16 @@ int64_t gmb_debug_tile_list(int32_t mt, int32_t nt, int32_t bm, int32_t bn, int3
     ++n;
   }
   return n;
+}
+
+int gmb_blk_covariance(gmb_engine* e, double* out, int64_t ldo) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  if (!out || ldo < e->Nr) return fail(e, GMB_EINVAL, "gmb_blk_covariance: out is null or ldo < %lld", (long long)e->Nr);
+  HIP_TRY(e, hipSetDevice(e->device));
+  if ((rc = build_sigma(e, out, ldo))) return rc;
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return GMB_OK;
 }
 
 int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, double* dinv16,

@@ -225,6 +225,7 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_int32]),
     "gmb_debug_tile_list": (C.c_int64, [C.c_int32] * 12 + [C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32)]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gmb_blk_covariance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "gmb_blk_trsm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                C.c_int32]),
     "gmb_blk_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
@@ -262,8 +263,8 @@ def _preload_hip_runtime():
 
 #: GMB_ABI_VERSION of include/gumbi_hip.h this binding was written against (the layout of
 #: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3; version 4 replaced the block-level
-#: multi-GPU entry points by the native driver ``gmb_dist_*``)
-ABI_VERSION = 4
+#: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``)
+ABI_VERSION = 5
 
 
 def load_library():
@@ -486,6 +487,10 @@ class Engine:
     def blk_invert(self, l_ptr, lda, nvalid, dinv16_ptr, inv_ptr):
         self._check(self._lib.gmb_blk_invert(self._h, C.c_void_p(l_ptr), lda, nvalid, C.c_void_p(dinv16_ptr),
                                              C.c_void_p(inv_ptr)), "gmb_blk_invert")
+
+    def blk_covariance(self, out_ptr, ldo):
+        """The covariance build alone into a caller's device buffer (lower-triangle tiles, y row, padding)."""
+        self._check(self._lib.gmb_blk_covariance(self._h, C.c_void_p(out_ptr), ldo), "gmb_blk_covariance")
 
     def blk_trsm(self, b_ptr, ldb, nrows, l_ptr, ldl, dinv16_ptr, nvalid=128):
         """B <- B inv(L)^T in place on ``nrows`` (multiple of 16) rows."""

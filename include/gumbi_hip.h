@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 4
+#define GMB_ABI_VERSION 5
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -219,6 +219,11 @@ int gmb_copy_alpha(const gmb_engine* e, double* out);
 int64_t gmb_debug_tile_list(int32_t mt, int32_t nt, int32_t bm, int32_t bn, int32_t k, int32_t tri,
                             int32_t tri_off, int32_t nblk_stride, int32_t klo_n, int32_t khi_n, int32_t order,
                             int32_t strip, int32_t* out, int64_t cap, int32_t* grid);
+/* The covariance build alone: what gmb_factorize factors -- the lower-triangle 128 x 128 tiles of
+ * Sigma = K + noise + jitter (pymc/GP.py:580), row N = y, identity padding -- written column-major into `out`
+ * (device memory; ceil((N+1)/128)*128 rows x ceil(N/128)*128 columns, leading dimension ldo >= the row count).
+ * Needs data, kernel and theta; the resident factor is left alone.  Entries above the tile diagonal are not written. */
+int gmb_blk_covariance(gmb_engine* e, double* out, int64_t ldo);
 /* Factor one 128 x 128 diagonal block in place (lower triangle; columns >= nvalid are identity
  * padding and are left alone).  dinv16 (optional, 8 x 256 doubles) receives the column-major
  * inverses of the eight 16 x 16 diagonal sub-blocks of the identity-padded factor: the operands

@@ -181,6 +181,73 @@ def test_potrf_leaf_flags_indefinite_block(gpu):
 
 
 # ----------------------------------------------------------------------------------------------
+# covariance build alone (gmb_blk_covariance): interior tiles take r^2 off the matrix pipe (PyMC's own
+# |x|^2 + |x'|^2 - 2 x.x' expansion as one MFMA contraction), diagonal / boundary tiles the direct form
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", list(O.KINDS))
+@pytest.mark.parametrize("N,d", [(700, 8), (515, 1), (640, 2), (600, 3), (520, 16), (1300, 5)])
+def test_covariance_build_matches_oracle_entrywise(gpu, kind, N, d):
+    import torch
+
+    X, y, ls = O.synthetic_table(N, d, seed=3 * N + d)
+    spec = O.make_spec(d, range(d), kind=kind)
+    theta = O.pack_theta(spec, ls, 1.3, 0.2)
+    eng = make_engine(spec, theta, X, y)
+    Nr, Np = (N + 1 + 127) // 128 * 128, (N + 127) // 128 * 128
+    out = torch.full((Np, Nr), float("nan"), dtype=torch.float64, device="cuda:0")  # column-major Nr x Np
+    torch.cuda.synchronize()
+    eng.blk_covariance(out.data_ptr(), Nr)
+    S = out.cpu().numpy().T  # S[i, j]
+    S_dir = O.sigma_matrix(spec, theta, X, dist_mode="direct")
+    S_gem = O.sigma_matrix(spec, theta, X, dist_mode="gemm")
+    low = np.tril(np.ones((N, N), bool))
+    eps = np.finfo(float).eps
+    if kind in ("Matern12", "Exponential"):
+        # kernels with a kink at r = 0 turn an r^2 error e into e / (2 r) near coinciding points (5e-10 in PyMC's own
+        # expansion at r^2 = 0: sqrt(r^2 + 1e-12)); they keep the direct form on every tile
+        assert np.max(np.abs(S[:N, :N][low] - S_dir[low])) < 16 * eps * 1.3**2
+    else:
+        # the expansion's rounding scales with |x / ls|^2; |dk/dr2| <= 3/2 for the smooth kinds
+        scale2 = float(np.max(np.sum((X / ls) ** 2, axis=1)))
+        tol = 40 * eps * max(1.0, scale2) * 1.3**2
+        assert np.max(np.abs(S[:N, :N][low] - S_dir[low])) < tol
+        assert np.max(np.abs(S[:N, :N][low] - S_gem[low])) < tol
+    # the tiles that hold a diagonal entry use the direct form: agreement to the last bits of exp / sqrt there
+    blk = (np.arange(N)[:, None] // 128) == (np.arange(N)[None, :] // 128)
+    assert np.max(np.abs(S[:N, :N][low & blk] - S_dir[low & blk])) < 8 * np.finfo(float).eps * 1.3**2
+    # y row and identity padding
+    assert np.array_equal(S[N, :N], y)
+    assert np.array_equal(S[N + 1:, :N], np.zeros((Nr - N - 1, N)))
+    pad = S[N:, N:Np]
+    assert np.array_equal(np.tril(pad), np.tril(np.eye(Nr - N, Np - N)))
+    eng.close()
+
+
+def test_covariance_build_with_a_nan_point_poisons_its_row_and_column(gpu):
+    """Interior tiles holding a non-finite point fall back to the direct form, so NaN spreads over the
+    point's whole row and column exactly as in the reference's arithmetic (and the factorisation fails)."""
+    import torch
+
+    N, d = 600, 3
+    X, y, ls = O.synthetic_table(N, d, seed=11)
+    X[450, 1] = np.nan
+    spec = O.make_spec(d, range(d), kind="Matern52")
+    eng = make_engine(spec, O.pack_theta(spec, ls, 1.0, 0.2), X, y)
+    Nr, Np = (N + 1 + 127) // 128 * 128, (N + 127) // 128 * 128
+    out = torch.zeros((Np, Nr), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    eng.blk_covariance(out.data_ptr(), Nr)
+    S = out.cpu().numpy().T
+    assert np.all(np.isnan(S[450, :451])) and np.all(np.isnan(S[450:N, 450]))
+    rest = np.tril(np.ones((N, N), bool))
+    rest[450, :] = rest[:, 450] = False
+    assert np.all(np.isfinite(S[:N, :N][rest]))
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.factorize()
+    eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
 # factorisation / prediction against the oracle
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,d,kind", [(1, 1, "ExpQuad"), (5, 2, "ExpQuad"), (127, 3, "Matern52"), (128, 4, "ExpQuad"),

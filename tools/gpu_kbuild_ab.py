@@ -1,6 +1,6 @@
 """A/B builds of libgumbi_hip.so (paths as argv; none = the in-tree library) on the covariance build ALONE
 (gmb_blk_covariance into a scratch buffer): min wall time of 5 launches and algorithmic GB/s, 8 N(N+1)/2 bytes.
-    python tools/gpu_kbuild_ab.py [LIB ...]      AB_CASES=50000x8xMatern52,10000x4xExpQuad overrides the cases
+    python tools/gpu_kbuild_ab.py [LIB ...]      AB_CASES=50000:8:Matern52,10000:4:ExpQuad overrides the cases
 """
 import os, subprocess, sys
 CODE = r'''
@@ -8,9 +8,9 @@ import os, sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
 import bench
 from gumbi_amd import engine
-cases = os.environ.get("AB_CASES", "50000x8xMatern52,50000x8xExpQuad,100000x8xExpQuad,10000x4xExpQuad,30000x2xMatern32,30000x16xMatern52")
+cases = os.environ.get("AB_CASES", "50000:8:Matern52,50000:8:ExpQuad,100000:8:ExpQuad,10000:4:ExpQuad,30000:2:Matern32,30000:16:Matern52")
 for c in cases.split(","):
-    N, d, kind = c.split("x"); N = int(N); d = int(d)
+    N, d, kind = c.split(":"); N = int(N); d = int(d)
     X, y, ls = bench.synthetic_table(N, d)
     e = engine.Engine(0); e.set_data(X, y); e.set_kernel(engine.KernelSpec(D=d, idx_cont=list(range(d)), kind=kind)); e.set_theta(np.concatenate([ls, [1.0, 0.2]]))
     Nr, Np = (N + 128) // 128 * 128, (N + 127) // 128 * 128
