@@ -22,6 +22,10 @@
 
 #include "gemm_f64.hpp"
 
+#ifndef GMB_KB_PROBE
+#define GMB_KB_PROBE 0  // 1 / 2: measurement probes of the interior covariance tiles (stores only / arithmetic only)
+#endif
+
 namespace gmb {
 
 constexpr int MAX_TABS = 5;     // GMB_MAX_COREG + output coregion
@@ -283,20 +287,26 @@ struct CovTileArgs {
   // enumerates, block row by owned block row row_first, row_first + row_stride, ... (< ti), the tiles
   // tj = 0 .. min(row, tj - 1).  row_stride == 0: off.
   int32_t row_first, row_stride;
+  int32_t stream_stores;  // interior tiles use non-temporal stores (set by launch_cov for outputs of >= 1 GiB)
+  int32_t strip;          // tiles per workgroup along the column index (set by launch_cov; see cov_tile_kernel)
 };
 
-// One interior 128 x 128 tile (every row and column real, strictly below the diagonal of the training
-// matrix, stationary term only, all 256 points finite): the squared distances come off the MATRIX pipe.
+// A run of interior 128 x 128 tiles of one tile row (every row and column real, strictly below the diagonal of
+// the training matrix, stationary term only, all points finite): the squared distances come off the MATRIX pipe.
 // With augmented coordinates  a' = (-2 x'_1 .. -2 x'_d, 1, |x'|^2),  b' = (x_1 .. x_d, |x|^2, 1)  the whole
 // r^2 = |x|^2 + |x'|^2 - 2 x.x' is ONE contraction of length d + 2 (PyMC's own expansion,
 // pm.gp.cov.Stationary.square_dist; for ExpQuad the operands carry the -1/2 as well), i.e. ceil((d+2)/4)
-// v_mfma_f64_16x16x4_f64 per 16 x 16 entries, and the vector pipe is left with the transcendental part
-// alone: Matern-5/2, d = 8: 54 -> 37 VALU instructions per entry and no LDS traffic at all (the direct
-// form spends 16 of them on differences and 4 ds_read_b128 on broadcasting the column point).
-// Operands sit in registers for the whole tile: a wave owns 32 rows x 128 columns; the D layout
-// (n = lane & 15 <-> row, m = (lane >> 4) + 4 reg <-> column) makes every store a set of 128 B row segments.
-template <int KIND, int NC, bool ACC>
-__device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const int64_t gi0, const int64_t gj0) {
+// v_mfma_f64_16x16x4_f64 per 16 x 16 entries, and the vector instructions are left with the transcendental
+// part alone: Matern-5/2, d = 8: 54 -> 33 VALU instructions per entry and no LDS traffic at all (the direct form
+// spends 16 of them on differences and 4 ds_read_b128 on broadcasting the column point).  It is NOT free: an f64
+// MFMA keeps the SIMD's sixteen double-precision lanes busy for its 64 cycles (the probes of tools/gpu_kbuild_ab.py:
+// MFMAs + tile set-up alone take 0.72 of the 2.5 ms at N = 50k), i.e. 3 MFMAs per 256 entries = 12 issue slots per
+// entry -- 45 slot-equivalents against 54 + LDS: C3 3.33 -> 3.9 TB/s, C5 (ExpQuad) 4.46 -> 5.3, d = 16 2.3 -> 3.2.
+// A wave owns 32 rows (its row operand stays in registers) and walks the strip's `ncb` blocks of 16 columns;
+// the D layout (n = lane & 15 <-> row, m = (lane >> 4) + 4 reg <-> column) makes every store a set of 128 B
+// row segments.
+template <int KIND, int NC, bool NT>
+__device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const int64_t gi0, const int64_t gj0, const int ncb) {
   constexpr int NG = (NC + 2 + 3) / 4;  // k groups of the augmented contraction
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
@@ -315,112 +325,86 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
       brow[ib][g] = v;
     }
   }
-  double acol[8][NG];
-#pragma unroll
-  for (int jb = 0; jb < 8; ++jb) {
-    const double* src = a.cols.xs + gj0 + 16 * jb + r16;
+  // column operand of one 16-column block: coordinate k of the column point; augmented slot NC is the constant 1,
+  // slot NC + 1 the norm (row NC of xs)
+  const double* csrc = a.cols.xs + gj0 + r16;
+  auto load_cols = [&](int jb, double (&dst)[NG]) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int k = 4 * g + kq;
-      // coordinate k of the column point; augmented slot NC is the constant 1, slot NC + 1 the norm (row NC)
-      double v = k <= NC + 1 ? src[(int64_t)(k == NC + 1 ? NC : k) * a.cols.npad] : 0.0;
+      double v = k <= NC + 1 ? csrc[(int64_t)(k == NC + 1 ? NC : k) * a.cols.npad + 16 * jb] : 0.0;
       v *= k < NC ? sc : sn;
       if (k == NC) v = 1.0;
-      acol[jb][g] = v;
+      dst[g] = v;
     }
-  }
+  };
   const double eta2 = a.p.eta2;
   const uint64_t col_bytes = (uint64_t)a.ldo * 8u;
   char* tile = reinterpret_cast<char*>(a.out + (gi0 - a.i0) + (gj0 - a.j0) * a.ldo);  // uniform
   const uint32_t lane_off = (uint32_t)((32 * wave + r16) * 8) + (uint32_t)kq * (uint32_t)col_bytes;
-#pragma unroll
-  for (int jb = 0; jb < 8; ++jb) {
+#if GMB_KB_PROBE >= 2
+  double probe_sum = 0.0;
+#endif
+  // A rolled loop over the `ncb` 16-column blocks of the strip (8 per tile), the next block's operands requested
+  // one iteration ahead.
+  double acol[NG], anext[NG];
+  load_cols(0, acol);
+#pragma unroll 1
+  for (int jb = 0; jb < ncb; ++jb) {
+    load_cols(jb + 1 < ncb ? jb + 1 : jb, anext);
     d4 acc[2];
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
       acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int g = 0; g < NG; ++g)
-        acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[jb][g], brow[ib][g], acc[ib], 0, 0, 0);
+        acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[g], brow[ib][g], acc[ib], 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib) {
+#if GMB_KB_PROBE == 1 || GMB_KB_PROBE == 3  // probes: the store stream alone (no transcendental work); 3: neither
+        const double v = acc[ib][r];
+#else
         const double v = stationary_interior<KIND>(acc[ib][r], eta2);
-        double* dst = reinterpret_cast<double*>(tile + ((uint64_t)(16 * jb + 4 * r) * col_bytes + 128u * ib) + lane_off);
-        if constexpr (ACC) *dst += v;  // additive models: later terms add to the first pass
+#endif
+        double* dst = reinterpret_cast<double*>(tile + ((uint64_t)(4 * r) * col_bytes + 128u * ib) + lane_off);
+#if GMB_KB_PROBE >= 2     // probe: the arithmetic alone (one store per lane and tile)
+        probe_sum += v;
+        if (jb == ncb - 1 && r == 3 && ib == 1) *dst = probe_sum;
+#else
+        // streaming stores for matrices far larger than the caches (the factorisation that follows starts at the
+        // other end of a 10 .. 80 GB buffer): +3 .. 7 % on the build at N = 50k / 100k
+        if constexpr (NT) __builtin_nontemporal_store(v, dst);
         else *dst = v;
+#endif
       }
+    tile += 16 * col_bytes;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acol[g] = anext[g];
   }
 }
 
-// (__launch_bounds__(256, 2): with at most 256 registers per lane the compiler keeps the MFMA results in
-// VGPRs; otherwise they land in AGPRs and every entry pays two v_accvgpr_read.)
+// One tile through the direct loop: diagonal and boundary tiles, models with linear / coregion terms, later passes
+// of additive models, interior tiles that hold a non-finite point (the differences carry NaN into the
+// factorisation -> GMB_ENOTPD, and into predictions, exactly as the reference's arithmetic would), and every tile
+// under -DGMB_KBUILD_DIRECT (the A/B switch for the matrix-pipe form).  Block-wide; ends with a barrier so that
+// the caller may go on to the next tile of its strip.
 template <int KIND, int NC>
-__global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
+__device__ __forceinline__ void cov_general_tile(const CovTileArgs& a, const int tix, const int tjx) {
   __shared__ double xj[NC][TILE];
   __shared__ double lj[MAX_LIN][TILE];
   __shared__ double li[MAX_LIN][TILE];
   __shared__ int32_t cj[MAX_TABS][TILE];
   __shared__ int32_t ci[MAX_TABS][TILE];
-
-  const int nwg = a.ti * a.tj;
-  // Triangular build: the tile columns carry very different amounts of work (column j has ti - j
-  // tiles below the diagonal), so contiguous per-XCD runs would leave the last XCDs idle; dealing
-  // consecutive tiles round-robin over the XCDs (the hardware's own order) balances them.
-  int tjx, tix;
-  if (a.row_stride > 0) {
-    int rem = blockIdx.x;
-    tix = a.row_first;
-    for (;;) {
-      const int cnt = (tix + 1 < a.tj) ? tix + 1 : a.tj;
-      if (rem < cnt) break;
-      rem -= cnt;
-      tix += a.row_stride;
-    }
-    tjx = rem;
-  } else if (a.tri_grid) {  // block b -> b-th tile of the lower triangle, column by column
-    int rem = blockIdx.x;
-    tjx = 0;
-    while (rem >= a.ti - tjx) {
-      rem -= a.ti - tjx;
-      ++tjx;
-    }
-    tix = tjx + rem;
-  } else {
-    const int wg = (a.mode == COV_TRAIN && a.lower_only) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
-    tjx = wg / a.ti;
-    tix = wg - tjx * a.ti;
-  }
   const int64_t gi0 = a.i0 + (int64_t)tix * TILE;
   const int64_t gj0 = a.j0 + (int64_t)tjx * TILE;
-  if (a.mode == COV_TRAIN && a.lower_only && gi0 + TILE - 1 < gj0) return;
-
+  if (a.mode == COV_TRAIN && a.lower_only && gi0 + TILE - 1 < gj0) return;  // (block-uniform)
   const int tid = threadIdx.x;
   const CovParams& p = a.p;
-  // Interior tiles (almost every tile of a large matrix): stationary term only, every row and column real
-  // and -- for the training matrix -- the tile strictly below the diagonal.  They take the matrix-pipe form
-  // (cov_interior_tile) unless one of their 256 points is not finite (or absurdly far out): such tiles, like
-  // the diagonal and boundary ones, go through the direct loop below, which propagates NaN into the
-  // factorisation (-> GMB_ENOTPD) and into predictions exactly as the reference's arithmetic would.
   const bool full = gi0 + TILE <= a.rows.n && gj0 + TILE <= a.cols.n;
   const bool below = a.mode != COV_TRAIN || gj0 + TILE <= gi0;
-#ifndef GMB_KBUILD_DIRECT
-  // (kinds with a kink at r = 0 -- Matern-1/2, Exponential -- keep the direct differences everywhere: an error e
-  // of the expansion becomes e / (2 r) in exp(-r) near coinciding points, 5e-10 at r^2 + 1e-12 = 1e-12)
-  if constexpr (KIND <= 2) {
-    if (full && below && p.n_lin == 0 && p.n_tab == 0) {
-      const double nrm = tid < TILE ? a.rows.xs[(int64_t)NC * a.rows.npad + gi0 + tid]
-                                    : a.cols.xs[(int64_t)NC * a.cols.npad + gj0 + (tid - TILE)];
-      if (!__syncthreads_or(!(nrm < 1.0e150))) {
-        if (a.accumulate) cov_interior_tile<KIND, NC, true>(a, gi0, gj0);
-        else cov_interior_tile<KIND, NC, false>(a, gi0, gj0);
-        return;
-      }
-    }
-  }
-#endif
   const int il = tid & (TILE - 1);
   const int jh = tid >> 7;  // which half of the tile's columns
   const int64_t gi = gi0 + il;
@@ -455,9 +439,7 @@ __global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
     ndiag += p.jitter;
   }
 
-  // Direct form without per-entry conditionals (interior tiles that hold a non-finite point; every interior
-  // tile under -DGMB_KBUILD_DIRECT, the A/B switch for the matrix-pipe form)
-  if (full && below && p.n_lin == 0 && p.n_tab == 0) {
+  if (full && below && p.n_lin == 0 && p.n_tab == 0) {  // no per-entry conditionals
     const double* xjp = &xj[0][jh * (TILE / 2)];
     auto entry = [&](int jj) {
       double r2 = 0.0;
@@ -475,42 +457,125 @@ __global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
 #pragma unroll 8
       for (int jj = 0; jj < TILE / 2; ++jj) outp[(int64_t)jj * a.ldo] = entry(jj);
     }
-    return;
-  }
-
-  for (int jj = 0; jj < TILE / 2; ++jj) {
-    const int j = jh * (TILE / 2) + jj;
-    const int64_t gj = gj0 + j;
-    double r2 = 0.0;
+  } else {
+    for (int jj = 0; jj < TILE / 2; ++jj) {
+      const int j = jh * (TILE / 2) + jj;
+      const int64_t gj = gj0 + j;
+      double r2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      const double d = xi[k] - xj[k][j];
-      r2 = fma(d, d, r2);
-    }
-    double v = p.eta2 * stationary<KIND>(r2);
-    if (p.n_lin > 0) {
-      double s = 0.0;
-      for (int k = 0; k < p.n_lin; ++k) s = fma(li[k][il], lj[k][j], s);
-      v = fma(p.tau, s, v);
-    }
-    for (int t = 0; t < p.n_tab; ++t)
-      v *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
-    const bool col_real = gj < a.cols.n;
-    if (a.accumulate) {
-      if (row_real && col_real && (a.mode != COV_TRAIN || gi >= gj)) outp[(int64_t)jj * a.ldo] += v;
-    } else if (a.mode == COV_TRAIN) {
-      if (!col_real) {
-        v = (gi == gj) ? 1.0 : 0.0;  // identity padding keeps the padded factor trivial
-      } else if (!row_real) {
-        v = (gi == a.rows.n) ? a.y[gj] : 0.0;  // appended y row: the factor's row n becomes L^-1 y
-      } else if (gi == gj) {
-        v += ndiag;
+      for (int k = 0; k < NC; ++k) {
+        const double d = xi[k] - xj[k][j];
+        r2 = fma(d, d, r2);
       }
-      if (gi >= gj) outp[(int64_t)jj * a.ldo] = v;  // lower triangle only
-    } else {
-      outp[(int64_t)jj * a.ldo] = (row_real && col_real) ? v : 0.0;
+      double v = p.eta2 * stationary<KIND>(r2);
+      if (p.n_lin > 0) {
+        double s = 0.0;
+        for (int k = 0; k < p.n_lin; ++k) s = fma(li[k][il], lj[k][j], s);
+        v = fma(p.tau, s, v);
+      }
+      for (int t = 0; t < p.n_tab; ++t)
+        v *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
+      const bool col_real = gj < a.cols.n;
+      if (a.accumulate) {
+        if (row_real && col_real && (a.mode != COV_TRAIN || gi >= gj)) outp[(int64_t)jj * a.ldo] += v;
+      } else if (a.mode == COV_TRAIN) {
+        if (!col_real) {
+          v = (gi == gj) ? 1.0 : 0.0;  // identity padding keeps the padded factor trivial
+        } else if (!row_real) {
+          v = (gi == a.rows.n) ? a.y[gj] : 0.0;  // appended y row: the factor's row n becomes L^-1 y
+        } else if (gi == gj) {
+          v += ndiag;
+        }
+        if (gi >= gj) outp[(int64_t)jj * a.ldo] = v;  // lower triangle only
+      } else {
+        outp[(int64_t)jj * a.ldo] = (row_real && col_real) ? v : 0.0;
+      }
     }
   }
+  __syncthreads();  // the staging arrays are reused by the strip's next tile
+}
+
+// blocks of the rows 0 .. i-1 of a lower-triangular tile grid cut into strips of S tiles along the column index:
+// row q (q + 1 tiles, at most tj) has floor(min(q, tj - 1) / S) + 1 strips
+__host__ __device__ __forceinline__ long long cov_tri_blocks_before(int i, int tj, int S) {
+  const int c = i < tj ? i : tj;
+  const long long q = c / S, r = c - (c / S) * S;
+  long long n = (long long)c + (long long)S * q * (q - 1) / 2 + q * r;  // sum_{q' < c} (floor(q' / S) + 1)
+  if (i > tj) n += (long long)(i - tj) * ((tj - 1) / S + 1);
+  return n;
+}
+
+// The grid.  A workgroup computes a STRIP of `strip` consecutive tiles of one tile row (same 128 row points,
+// 128 * strip column points): its interior tiles in one pass of cov_interior_tile, whatever else it holds (the
+// diagonal tile at the end of a row, boundary tiles) through cov_general_tile.  Strips amortise dispatch, decode,
+// the finiteness check and the row operand's loads over more entries: worth +5 % at N = 100k (strip 4), nothing
+// at N = 50k, and they cost balance on small grids -- launch_cov picks 1 / 2 / 4 by tile count.  Enumerations:
+//   tri_grid   : rows 0 .. ti-1 of the lower triangle, row q with its floor(q / S) + 1 strips (closed-form decode);
+//   row_stride : one rank's block rows row_first, row_first + row_stride, ...: ceil(tj / S) blocks per owned
+//                row, those right of the diagonal exit at once;
+//   otherwise  : rectangle ti x ceil(tj / S), dealt over the XCDs in equal runs (cross-covariance).
+// Consecutive blocks go to consecutive XCDs (the hardware's own order), which balances the triangle.
+// (__launch_bounds__(256, 2): with at most 256 registers per lane the compiler keeps the MFMA results in VGPRs;
+// otherwise they land in AGPRs and every entry pays two v_accvgpr_read.)
+template <int KIND, int NC>
+__global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
+  const int S = a.strip < 1 ? 1 : a.strip;
+  int tix, ts, ncols;  // tile row, strip index, tiles this row holds
+  if (a.row_stride > 0) {
+    const int nst = (a.tj + S - 1) / S;
+    const int m = blockIdx.x / nst;
+    ts = blockIdx.x - m * nst;
+    tix = a.row_first + m * a.row_stride;
+    ncols = tix + 1 < a.tj ? tix + 1 : a.tj;
+  } else if (a.tri_grid) {
+    // blocks before row i ~ i + i^2 / (2 S): invert, then step to the exact row
+    const double Sd = (double)S;
+    int i = (int)(__builtin_sqrt(Sd * Sd + 2.0 * Sd * (double)blockIdx.x) - Sd);
+    i = i < 0 ? 0 : (i > a.ti - 1 ? a.ti - 1 : i);
+    while (cov_tri_blocks_before(i, a.tj, S) > (long long)blockIdx.x) --i;
+    while (cov_tri_blocks_before(i + 1, a.tj, S) <= (long long)blockIdx.x) ++i;
+    tix = i;
+    ts = (int)((long long)blockIdx.x - cov_tri_blocks_before(i, a.tj, S));
+    ncols = tix + 1 < a.tj ? tix + 1 : a.tj;
+  } else {
+    const int nst = (a.tj + S - 1) / S;
+    const int wg = (a.mode == COV_TRAIN && a.lower_only) ? (int)blockIdx.x : xcd_remap(blockIdx.x, a.ti * nst);
+    ts = wg / a.ti;
+    tix = wg - ts * a.ti;
+    ncols = a.tj;
+  }
+  const int tj_lo = ts * S;
+  const int tj_hi = tj_lo + S < ncols ? tj_lo + S : ncols;
+  if (tix >= a.ti || tj_lo >= tj_hi) return;
+  int tj_gen = tj_lo;  // first tile of the strip that goes through the direct loop
+#ifndef GMB_KBUILD_DIRECT
+  // Interior tiles: stationary term only, every row and column real and -- for the training matrix -- the tile
+  // strictly below the diagonal; in a tile row they are the columns left of min(cols.n / 128, diagonal).
+  // (Kinds with a kink at r = 0 -- Matern-1/2, Exponential -- keep the direct differences everywhere: an error e
+  // of the expansion becomes e / (2 r) in exp(-r) near coinciding points, 5e-10 at r^2 + 1e-12 = 1e-12.)
+  if constexpr (KIND <= 2) {
+    const int64_t gi0 = a.i0 + (int64_t)tix * TILE;
+    const CovParams& p = a.p;
+    if (gi0 + TILE <= a.rows.n && p.n_lin == 0 && p.n_tab == 0 && !a.accumulate) {  // (additive models' later passes: direct loop)
+      int64_t jend = (a.cols.n - a.j0) / TILE;                         // tiles whose 128 columns are all real
+      if (a.mode == COV_TRAIN) jend = jend < (gi0 - a.j0) / TILE ? jend : (gi0 - a.j0) / TILE;  // ... and left of the diagonal
+      const int tj_int = (int)(jend < tj_hi ? (jend > tj_lo ? jend : tj_lo) : tj_hi);
+      if (tj_int > tj_lo) {
+        const int tid = threadIdx.x;
+        const int64_t gj0 = a.j0 + (int64_t)tj_lo * TILE;
+        bool bad = tid < TILE && !(a.rows.xs[(int64_t)NC * a.rows.npad + gi0 + tid] < 1.0e150);
+        for (int j = tid; j < (tj_int - tj_lo) * TILE; j += 256)
+          bad |= !(a.cols.xs[(int64_t)NC * a.cols.npad + gj0 + j] < 1.0e150);
+        if (!__syncthreads_or(bad)) {  // all norms finite (and no coordinate absurdly far out)
+          if (a.stream_stores) cov_interior_tile<KIND, NC, true>(a, gi0, gj0, 8 * (tj_int - tj_lo));
+          else cov_interior_tile<KIND, NC, false>(a, gi0, gj0, 8 * (tj_int - tj_lo));
+          tj_gen = tj_int;
+        }
+      }
+    }
+  }
+#endif
+  for (int tjx = tj_gen; tjx < tj_hi; ++tjx) cov_general_tile<KIND, NC>(a, tix, tjx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -626,12 +691,13 @@ __global__ __launch_bounds__(256) void ls_limits_kernel(const double* pts, int64
   __shared__ double xj[16][TILE];
   const int g = blockIdx.y;
   // decode lower-triangle tile pair (ti >= tj) from blockIdx.x
-  int tjx = 0, rem = blockIdx.x;
-  while (rem >= tiles - tjx) {
-    rem -= tiles - tjx;
-    ++tjx;
-  }
-  const int tix = tjx + rem;
+  const double t2 = 2.0 * (double)tiles + 1.0;
+  int tjx = (int)(0.5 * (t2 - __builtin_sqrt(t2 * t2 - 8.0 * (double)blockIdx.x)));
+  auto before = [&](int q) -> long long { return (long long)q * tiles - (long long)q * (q - 1) / 2; };
+  tjx = tjx < 0 ? 0 : (tjx > tiles ? tiles : tjx);
+  while (before(tjx) > (long long)blockIdx.x) --tjx;
+  while (before(tjx + 1) <= (long long)blockIdx.x) ++tjx;
+  const int tix = tjx + (int)((long long)blockIdx.x - before(tjx));
   const int tid = threadIdx.x;
   const int il = tid & (TILE - 1), jh = tid >> 7;
   const int64_t gi = (int64_t)tix * TILE + il, gj0 = (int64_t)tjx * TILE;

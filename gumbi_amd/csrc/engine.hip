@@ -141,6 +141,7 @@ struct gmb_engine {
   const double* plan_A = nullptr;
   bool batch_inverse = true;
   bool lpt_order = true;
+  int cov_strip = 0;   // GMB_COV_STRIP: tiles per workgroup of the covariance build (0 = by size)
   int tile_strip = 8;  // GMB_TILE_STRIP: m-tiles per strip of the L2-aware tile order (0 = row-major runs)
 
   // timing
@@ -474,14 +475,15 @@ int launch_leaf(gmb_engine* e, const LeafArgs& a) {
 
 template <int KIND>
 int launch_cov_nc(gmb_engine* e, const CovTileArgs& a, int nc) {
-  long long nb = (long long)a.ti * a.tj;
+  // grid = the strips of cov_tile_kernel's enumeration (a.strip tiles per workgroup along the column index)
+  const int S = a.strip < 1 ? 1 : a.strip;
+  const long long nst = (a.tj + S - 1) / S;
+  long long nb = (long long)a.ti * nst;
   if (a.row_stride > 0) {
-    nb = 0;
-    for (int i = a.row_first; i < a.ti; i += a.row_stride) nb += std::min(i + 1, a.tj);
+    nb = a.row_first < a.ti ? ((a.ti - 1 - a.row_first) / a.row_stride + 1) * nst : 0;
     if (nb == 0) return GMB_OK;
   } else if (a.tri_grid) {
-    nb = 0;
-    for (int j = 0; j < a.tj; ++j) nb += std::max(0, a.ti - j);
+    nb = cov_tri_blocks_before(a.ti, a.tj, S);
   }
   const dim3 grid((unsigned)nb), block(256);
   switch (nc) {
@@ -495,8 +497,13 @@ int launch_cov_nc(gmb_engine* e, const CovTileArgs& a, int nc) {
   return GMB_OK;
 }
 
-int launch_cov(gmb_engine* e, const CovTileArgs& a) {
-  if (a.ti <= 0 || a.tj <= 0) return GMB_OK;
+int launch_cov(gmb_engine* e, const CovTileArgs& a_in) {
+  if (a_in.ti <= 0 || a_in.tj <= 0) return GMB_OK;
+  CovTileArgs a = a_in;
+  const double tiles = (double)a.ti * a.tj * (a.lower_only ? 0.5 : 1.0);
+  a.stream_stores = tiles * TILE * TILE * 8.0 >= 1073741824.0;
+  // tiles per workgroup: enough strips left to fill the chip's ~800 workgroup slots several times over
+  a.strip = e->cov_strip > 0 ? e->cov_strip : (tiles >= 32768.0 ? 4 : tiles >= 12288.0 ? 2 : 1);
   switch (a.p.kind) {
     case GMB_EXPQUAD: return launch_cov_nc<0>(e, a, e->nc_pad);
     case GMB_MATERN52: return launch_cov_nc<1>(e, a, e->nc_pad);
@@ -1452,6 +1459,8 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream) {
   e->lpt_order = flag("GMB_LPT_ORDER", true);
   const char* ts = getenv("GMB_TILE_STRIP");
   if (ts) e->tile_strip = std::max(0, atoi(ts));
+  const char* cst = getenv("GMB_COV_STRIP");
+  if (cst) e->cov_strip = std::max(0, std::min(64, atoi(cst)));
   e->batch_inverse = flag("GMB_BATCH_INVERSE", true);
   e->par_inverse = flag("GMB_PAR_INVERSE", true);
   const char* pb = getenv("GMB_PANEL_BLOCKS");
@@ -1591,6 +1600,18 @@ int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t l
   HIP_TRY(e, hipMemcpyAsync(e->dy, y, N * sizeof(double), kind, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->N = N;
+  return GMB_OK;
+}
+
+int gmb_set_y(gmb_engine* e, const double* y, int32_t memspace) {
+  if (!e) return GMB_EINVAL;
+  if (e->N <= 0) return fail(e, GMB_EINVAL, "gmb_set_data must precede gmb_set_y");
+  if (!y) return fail(e, GMB_EINVAL, "y is null");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const hipMemcpyKind kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  e->factored = false;  // the y row of the factor (v = L^-1 y) belongs to the old observations
+  HIP_TRY(e, hipMemcpyAsync(e->dy, y, e->N * sizeof(double), kind, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));  // the caller may reuse its buffer
   return GMB_OK;
 }
 

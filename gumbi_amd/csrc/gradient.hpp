@@ -56,13 +56,17 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
   __shared__ double sacc[GRAD_MAX_LDS_ACC];
 
   // lower-triangle tile pair (ti >= tj), enumerated block row by owned block row
-  int tix = a.row_first, rem = blockIdx.x;
-  while (rem > tix) {
-    rem -= tix + 1;
-    tix += a.row_stride;
-  }
+  // (closed form: owned row m = (tix - row_first) / row_stride is preceded by m (row_first + 1) + row_stride m (m - 1) / 2
+  // tiles; a linear search cost the late rows of a large matrix thousands of scalar cycles per workgroup)
+  const double sd = (double)a.row_stride, f1 = (double)a.row_first + 1.0 - 0.5 * sd;
+  int m = (int)((__builtin_sqrt(f1 * f1 + 2.0 * sd * (double)blockIdx.x) - f1) / sd);
+  auto before = [&](int q) -> long long { return (long long)q * (a.row_first + 1) + (long long)a.row_stride * q * (q - 1) / 2; };
+  m = m < 0 ? 0 : m;
+  while (before(m) > (long long)blockIdx.x) --m;
+  while (before(m + 1) <= (long long)blockIdx.x) ++m;
+  const int tix = a.row_first + m * a.row_stride;
   if (tix >= a.tiles) return;
-  const int tjx = rem;
+  const int tjx = (int)((long long)blockIdx.x - before(m));
   const int64_t gi0 = (int64_t)tix * TILE, gj0 = (int64_t)tjx * TILE;
   const int tid = threadIdx.x;
   const int il = tid & (TILE - 1), jh = tid >> 7;

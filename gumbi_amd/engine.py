@@ -196,6 +196,7 @@ _SIGNATURES = {
     "gmb_last_error": (C.c_char_p, [C.c_void_p]),
     "gmb_stream": (C.c_void_p, [C.c_void_p]),
     "gmb_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int32]),
+    "gmb_set_y": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "gmb_set_kernel": (C.c_int, [C.c_void_p, C.POINTER(_Spec)]),
     "gmb_theta_size": (C.c_int, [C.POINTER(_Spec)]),
     "gmb_set_theta": (C.c_int, [C.c_void_p, _DBL_P, C.c_int32]),
@@ -263,7 +264,7 @@ def _preload_hip_runtime():
 
 #: GMB_ABI_VERSION of include/gumbi_hip.h this binding was written against (the layout of
 #: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3; version 4 replaced the block-level
-#: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``)
+#: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance`` and ``gmb_set_y``)
 ABI_VERSION = 5
 
 
@@ -365,6 +366,13 @@ class Engine:
         self._check(self._lib.gmb_set_data(self._h, _ptr(X), X.shape[0], X.shape[1], X.shape[1], _ptr(y), GMB_HOST),
                     "gmb_set_data")
         self.N, self.D = X.shape
+
+    def set_y(self, y):
+        """New observations for the same inputs: everything but the factorisation stays."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.shape != (self.N,):
+            raise ValueError(f"y must be ({self.N},), got {y.shape}")
+        self._check(self._lib.gmb_set_y(self._h, _ptr(y), GMB_HOST), "gmb_set_y")
 
     def set_data_device(self, x_ptr: int, N: int, D: int, ldx: int, y_ptr: int):
         """Inputs already in HBM (e.g. ``torch.Tensor.data_ptr()``)."""

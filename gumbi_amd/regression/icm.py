@@ -63,12 +63,15 @@ class IcmEngine:
         self.X = self.y = self.spec = self.theta = None
         self._state = None      # decomposition of the current theta
         self._resident = -1     # which system's factor the inner engine currently holds
+        self._resident_y = None  # ... for which rotation of the observations
+        self._declared = False  # inputs + kernel handed to the inner engine
 
     # -- declaration ------------------------------------------------------------------------------------------
     def set_data(self, X, y):
         self.X = np.ascontiguousarray(X, dtype=np.float64)
         self.y = np.ascontiguousarray(y, dtype=np.float64)
         self._state = None
+        self._declared = False
 
     def set_kernel(self, spec: KernelSpec):
         if not aligned_outputs(self.X, spec):
@@ -86,6 +89,7 @@ class IcmEngine:
         self.i_eta, self.i_sigma = n_ls, n_ls + 1
         self.i_tau = n_ls + 2 + len(spec.idx_lin) if spec.idx_lin else -1
         self._state = None
+        self._declared = False
 
     def set_theta(self, theta):
         theta = np.asarray(theta, dtype=np.float64)
@@ -135,9 +139,13 @@ class IcmEngine:
 
     def _load(self, p, st):
         """Make the inner engine hold system p, factorised."""
-        if self._resident != p:
-            self.eng.set_data(self.Xn, st["Yt"][p])
+        if not self._declared:   # inputs and kernel once; the P systems differ in y and theta only (gmb_set_y keeps
+            self.eng.set_data(self.Xn, st["Yt"][p])   # the workspaces -- a gmb_set_data per system re-allocated them)
             self.eng.set_kernel(self.spec_k)
+            self._declared = True
+        elif self._resident != p or self._resident_y is not st["Yt"]:
+            self.eng.set_y(st["Yt"][p])
+        self._resident_y = st["Yt"]
         self.eng.set_theta(self._theta_p(st["lam"][p]))
         self.eng.factorize()
         self._resident = p

@@ -147,6 +147,10 @@ void* gmb_stream(const gmb_engine* e);           /* the hipStream_t launches go 
  * (pymc/GP.py:521, 580): X is (N, D) with leading dimension ldx (>= D), y is (N,).  Copies in. */
 int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t ldx,
                  const double* y, int32_t memspace);
+/* New observations for the SAME inputs (length N): kernel, theta, prepared coordinates and every workspace
+ * stay; only the factorisation is invalidated.  No reference counterpart (there the model is rebuilt); used by
+ * the Kronecker multi-output path, whose P systems share X and differ in the rotated y (regression/icm.py). */
+int gmb_set_y(gmb_engine* e, const double* y, int32_t memspace);
 
 /* Replaces PymcGP._construct_kernels + the noise block of build_model (pymc/GP.py:560-569,
  * 652-729): fixes which columns feed which covariance term. */

@@ -16,6 +16,9 @@ class OracleEngine:
     def set_data(self, X, y):
         self.X, self.y = np.asarray(X, float), np.asarray(y, float)
 
+    def set_y(self, y):
+        self.y = np.asarray(y, float)
+
     def set_kernel(self, spec):
         self.spec = spec.as_dict()
 

@@ -19,8 +19,13 @@ for c in cases.split(","):
     for _ in range(6):
         t0 = time.perf_counter(); e.blk_covariance(out.data_ptr(), Nr); ts.append(time.perf_counter() - t0)
     t = min(ts[1:])
+    tf = []
+    for _ in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); out.fill_(1.5); torch.cuda.synchronize(); tf.append(time.perf_counter() - t0)
+    fill = out.numel() * 8 / min(tf[1:]) / 1e9
+    for _ in range(2): e.blk_covariance(out.data_ptr(), Nr)
     chk = float(out[:N, :N].diagonal().sum().cpu()), float(out[N // 3, N // 2:N].sum().cpu())
-    print("N=%d d=%d %s: %.3f ms  %.0f GB/s   (checks %.12g %.12g)" % (N, d, kind, t * 1e3, 8.0 * N * (N + 1) / 2 / t / 1e9, chk[0], chk[1]))
+    print("N=%d d=%d %s: %.3f ms  %.0f GB/s   (checks %.12g %.12g; torch fill of the whole buffer %.0f GB/s)" % (N, d, kind, t * 1e3, 8.0 * N * (N + 1) / 2 / t / 1e9, chk[0], chk[1], fill))
     e.close(); del out; torch.cuda.empty_cache()
 '''
 libs = sys.argv[1:] or [None]
