@@ -133,7 +133,7 @@ __device__ __forceinline__ double stationary(double r2) {
 // --- interior tiles: squared distances on the matrix pipe -------------------------------------------
 // exp(x) for FINITE x <= ~0 (interior tiles only, whose 256 points were checked finite): the reduction's
 // integer part comes out of the mantissa of x*log2(e) + 1.5*2^52 (no v_rndne / v_cvt), and 2^k goes straight
-// into the exponent field (x >= -700 keeps the result normal, so no v_ldexp).  Same polynomial as exp_nonpos.
+// into the exponent field (x >= -700 keeps the result normal, so no v_ldexp).
 __device__ __forceinline__ double exp_interior(double x) {
   x = fmax(x, -700.0);
   const double magic = 6755399441055744.0;  // 1.5 * 2^52
@@ -141,18 +141,19 @@ __device__ __forceinline__ double exp_interior(double x) {
   const double k = t - magic;
   double r = fma(-k, 6.93147180369123816490e-01, x);
   r = fma(-k, 1.90821492927058770002e-10, r);
-  double p = 1.6059043836821614599e-10;
-  p = fma(p, r, 2.0876756987868098979e-09);
-  p = fma(p, r, 2.5052108385441718775e-08);
-  p = fma(p, r, 2.7557319223985890653e-07);
-  p = fma(p, r, 2.7557319223985892511e-06);
-  p = fma(p, r, 2.4801587301587301566e-05);
-  p = fma(p, r, 1.9841269841269841253e-04);
-  p = fma(p, r, 1.3888888888888889419e-03);
-  p = fma(p, r, 8.3333333333333332177e-03);
-  p = fma(p, r, 4.1666666666666664354e-02);
-  p = fma(p, r, 1.6666666666666665741e-01);
-  p = fma(p, r, 0.5);
+  // degree-11 minimax polynomial of exp on |r| <= 0.34665 (relative error 3.1e-18 before rounding; Remez in
+  // 80-digit arithmetic, coefficients rounded to double; against long-double exp over 3e7 arguments in [-700, 0]
+  // the whole function stays below 0.98 ulp -- the degree-13 Taylor form of exp_nonpos: 0.89 ulp)
+  double p = 0x1.ad65ffe4d4e0dp-26;
+  p = fma(p, r, 0x1.28b328f7eba37p-22);
+  p = fma(p, r, 0x1.71df455cd7abcp-19);
+  p = fma(p, r, 0x1.a01992b813c66p-16);
+  p = fma(p, r, 0x1.a01a011026885p-13);
+  p = fma(p, r, 0x1.6c16c1878a4f7p-10);
+  p = fma(p, r, 0x1.1111111130ebcp-7);
+  p = fma(p, r, 0x1.555555554f344p-5);
+  p = fma(p, r, 0x1.55555555554a2p-3);
+  p = fma(p, r, 0x1.0000000000010p-1);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   const int hi = __double2hiint(p) + (__double2loint(t) << 20);
@@ -300,43 +301,59 @@ struct CovTileArgs {
 // part alone: Matern-5/2, d = 8: 54 -> 33 VALU instructions per entry and no LDS traffic at all (the direct form
 // spends 16 of them on differences and 4 ds_read_b128 on broadcasting the column point).  It is NOT free: an f64
 // MFMA keeps the SIMD's sixteen double-precision lanes busy for its 64 cycles (the probes of tools/gpu_kbuild_ab.py:
-// MFMAs + tile set-up alone take 0.72 of the 2.5 ms at N = 50k), i.e. 3 MFMAs per 256 entries = 12 issue slots per
-// entry -- 45 slot-equivalents against 54 + LDS: C3 3.33 -> 3.9 TB/s, C5 (ExpQuad) 4.46 -> 5.3, d = 16 2.3 -> 3.2.
+// MFMAs + tile set-up alone take 0.72 of the 2.5 ms at N = 50k): one MFMA per 256 entries = 4 issue slots per entry.
+// With the norms in the accumulator (below) and the degree-11 exp, d = 8 Matern-5/2 costs 31 + 1 + 8 = 40
+// slot-equivalents against 54 + LDS: C3 3.33 -> 4.1 TB/s, C5 (ExpQuad) 4.46 -> 5.55, d = 16 2.3 -> 3.3 (wall clock of
+// gmb_blk_covariance; a torch fill of the same buffer: 6.7 TB/s; stores alone in this pattern: 5.5 - 6.0).
 // A wave owns 32 rows (its row operand stays in registers) and walks the strip's `ncb` blocks of 16 columns;
 // the D layout (n = lane & 15 <-> row, m = (lane >> 4) + 4 reg <-> column) makes every store a set of 128 B
 // row segments.
 template <int KIND, int NC, bool NT>
 __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const int64_t gi0, const int64_t gj0, const int ncb) {
-  constexpr int NG = (NC + 2 + 3) / 4;  // k groups of the augmented contraction
+  // Where the two norm slots would cost a further MFMA (d = 4, 8, 16: ceil((d + 2) / 4) > d / 4) the norms enter
+  // through the accumulator instead -- C = |x|^2 + |x'|^2 (one v_add per entry, 1 slot against the MFMA's 4),
+  // contraction over the d coordinates alone; for d = 1, 2 they ride in the single MFMA's spare slots.
+  constexpr bool NORM_IN_C = (NC + 2 + 3) / 4 > (NC + 3) / 4;
+  constexpr int KA = NORM_IN_C ? NC : NC + 2;  // contraction length
+  constexpr int NG = (KA + 3) / 4;             // MFMAs per 16 x 16 entries
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   constexpr double sc = KIND == 0 ? 1.0 : -2.0;  // scale of the column point's coordinates
   constexpr double sn = KIND == 0 ? -0.5 : 1.0;  // scale of both squared norms
-  double brow[2][NG];
+  double brow[2][NG], nrow[2];
 #pragma unroll
   for (int ib = 0; ib < 2; ++ib) {
     const double* src = a.rows.xs + gi0 + 32 * wave + 16 * ib + r16;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int k = 4 * g + kq;
-      double v = k <= NC ? src[(int64_t)k * a.rows.npad] : 0.0;
-      if (k == NC) v *= sn;
-      if (k == NC + 1) v = 1.0;
+      double v = k < (NORM_IN_C ? NC : NC + 1) ? src[(int64_t)k * a.rows.npad] : 0.0;
+      if (!NORM_IN_C && k == NC) v *= sn;
+      if (!NORM_IN_C && k == NC + 1) v = 1.0;
       brow[ib][g] = v;
     }
+    nrow[ib] = NORM_IN_C ? sn * src[(int64_t)NC * a.rows.npad] : 0.0;  // this lane's row (r16 of block ib)
   }
-  // column operand of one 16-column block: coordinate k of the column point; augmented slot NC is the constant 1,
-  // slot NC + 1 the norm (row NC of xs)
+  // column operand of one 16-column block: coordinate k of the column point (augmented form: slot NC is the
+  // constant 1, slot NC + 1 the norm, row NC of xs); NORM_IN_C: the norms of the lane's 4 columns kq + 4 r
   const double* csrc = a.cols.xs + gj0 + r16;
-  auto load_cols = [&](int jb, double (&dst)[NG]) {
+  const double* nsrc = a.cols.xs + (int64_t)NC * a.cols.npad + gj0 + kq;
+  auto load_cols = [&](int jb, double (&dst)[NG], double (&nc)[4]) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int k = 4 * g + kq;
-      double v = k <= NC + 1 ? csrc[(int64_t)(k == NC + 1 ? NC : k) * a.cols.npad + 16 * jb] : 0.0;
-      v *= k < NC ? sc : sn;
-      if (k == NC) v = 1.0;
+      double v;
+      if constexpr (NORM_IN_C) {
+        v = k < NC ? sc * csrc[(int64_t)k * a.cols.npad + 16 * jb] : 0.0;
+      } else {
+        v = k <= NC + 1 ? csrc[(int64_t)(k == NC + 1 ? NC : k) * a.cols.npad + 16 * jb] : 0.0;
+        v *= k < NC ? sc : sn;
+        if (k == NC) v = 1.0;
+      }
       dst[g] = v;
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nc[r] = NORM_IN_C ? sn * nsrc[16 * jb + 4 * r] : 0.0;
   };
   const double eta2 = a.p.eta2;
   const uint64_t col_bytes = (uint64_t)a.ldo * 8u;
@@ -347,15 +364,16 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
 #endif
   // A rolled loop over the `ncb` 16-column blocks of the strip (8 per tile), the next block's operands requested
   // one iteration ahead.
-  double acol[NG], anext[NG];
-  load_cols(0, acol);
+  double acol[NG], anext[NG], ncol[4], nnext[4];
+  load_cols(0, acol, ncol);
 #pragma unroll 1
   for (int jb = 0; jb < ncb; ++jb) {
-    load_cols(jb + 1 < ncb ? jb + 1 : jb, anext);
+    load_cols(jb + 1 < ncb ? jb + 1 : jb, anext, nnext);
     d4 acc[2];
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
-      acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
+      if constexpr (NORM_IN_C) acc[ib] = d4{nrow[ib] + ncol[0], nrow[ib] + ncol[1], nrow[ib] + ncol[2], nrow[ib] + ncol[3]};
+      else acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[g], brow[ib][g], acc[ib], 0, 0, 0);
@@ -383,6 +401,8 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
     tile += 16 * col_bytes;
 #pragma unroll
     for (int g = 0; g < NG; ++g) acol[g] = anext[g];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ncol[r] = nnext[r];
   }
 }
 
