@@ -169,6 +169,7 @@ struct gmb_engine {
   bool lookahead = true;
   bool par_inverse = true;
   bool aux_shared = false;  // aux[2] is the process-wide masked stream (not ours to destroy)
+  bool aux_borrowed = false;  // aux[0..2] belong to the engine this one was created beside (gmb_create_sibling)
   int part_cus = 0;         // compute units the masked stream leaves free
   // multi-GPU driver (dist_driver.hpp): packed send / receive staging of the all-gathers
   double* dsend = nullptr;
@@ -1423,7 +1424,7 @@ hipStream_t shared_masked_stream(int device, int part_cus, int* ncu_out) {
   return st;
 }
 
-int gmb_create_impl(gmb_engine** out, int32_t device, void* stream) {
+int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_engine* peer = nullptr) {
   if (!out) return GMB_EINVAL;
   *out = nullptr;
   int n = gmb_device_count();
@@ -1482,7 +1483,13 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream) {
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   const char* pc = getenv("GMB_PART_CUS");
   const int part = pc ? atoi(pc) : 32;
-  for (int a = 0; a < 3; ++a) {
+  for (int a = 0; a < 3 && peer; ++a) {  // sibling: the peer's streams (its engines work one after the other)
+    e->aux[a] = peer->aux[a];
+    e->aux_borrowed = true;
+    e->aux_shared = peer->aux_shared;
+    e->part_cus = peer->part_cus;
+  }
+  for (int a = 0; a < 3 && !peer; ++a) {
     hipError_t st2 = hipSuccess;
     int ncu = 0;
     hipStream_t masked = (a == 2 && part > 0) ? shared_masked_stream(device, part, &ncu) : nullptr;
@@ -1527,6 +1534,11 @@ int gmb_device_count(void) {
 
 int gmb_create(gmb_engine** out, int32_t device, void* stream) { return gmb_create_impl(out, device, stream); }
 
+int gmb_create_sibling(gmb_engine** out, const gmb_engine* peer) {
+  if (!peer) return GMB_EINVAL;
+  return gmb_create_impl(out, peer->device, (void*)peer->stream, peer);
+}
+
 void gmb_destroy(gmb_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
@@ -1541,7 +1553,7 @@ void gmb_destroy(gmb_engine* e) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int a = 0; a < 3; ++a)
-    if (e->aux[a] && !(a == 2 && e->aux_shared)) (void)hipStreamDestroy(e->aux[a]);
+    if (e->aux[a] && !e->aux_borrowed && !(a == 2 && e->aux_shared)) (void)hipStreamDestroy(e->aux[a]);
   for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;

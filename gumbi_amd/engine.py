@@ -192,6 +192,7 @@ _SIGNATURES = {
     "gmb_abi_version": (C.c_int, []),
     "gmb_device_count": (C.c_int, []),
     "gmb_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "gmb_create_sibling": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     "gmb_destroy": (None, [C.c_void_p]),
     "gmb_last_error": (C.c_char_p, [C.c_void_p]),
     "gmb_stream": (C.c_void_p, [C.c_void_p]),
@@ -264,7 +265,7 @@ def _preload_hip_runtime():
 
 #: GMB_ABI_VERSION of include/gumbi_hip.h this binding was written against (the layout of
 #: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3; version 4 replaced the block-level
-#: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance`` and ``gmb_set_y``)
+#: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``, ``gmb_set_y`` and ``gmb_create_sibling``)
 ABI_VERSION = 5
 
 
@@ -308,10 +309,13 @@ def device_count() -> int:
 class Engine:
     """One GP resident on one MI355X: data, covariance / factor, predict workspaces."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, sibling_of: "Engine | None" = None):
         self._lib = load_library()
         self._h = C.c_void_p()
-        rc = self._lib.gmb_create(C.byref(self._h), int(device), C.c_void_p(stream) if stream else None)
+        if sibling_of is not None:  # borrows that engine's HIP streams (gmb_create_sibling); close it first
+            rc = self._lib.gmb_create_sibling(C.byref(self._h), sibling_of._h)
+        else:
+            rc = self._lib.gmb_create(C.byref(self._h), int(device), C.c_void_p(stream) if stream else None)
         if rc == GMB_ENODEVICE:
             raise GumbiHipError("no HIP device visible: gumbi_amd needs an MI355X (gfx950); there is no CPU fallback")
         if rc != GMB_OK:

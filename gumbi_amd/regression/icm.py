@@ -58,20 +58,24 @@ class IcmEngine:
     """Same calls as :class:`gumbi_amd.engine.Engine` (``set_data / set_kernel / set_theta / factorize /
     nlml / predict / close``) for an aligned multi-output table; ``theta`` keeps the stacked model's layout."""
 
+    #: device memory the P resident systems may take together (factor + gradient workspace each); above it ONE
+    #: inner engine serves the systems in turn and every switch re-factorises
+    RESIDENT_BYTES = 160e9
+
     def __init__(self, device=0, stream=None):
         self.eng = Engine(device=device, stream=stream)
+        self._engs = [self.eng]  # one inner engine per system when they fit (siblings: they share eng's streams)
+        self._slots = {}         # engine index -> what it holds: dict(p, y, theta)
         self.X = self.y = self.spec = self.theta = None
-        self._state = None      # decomposition of the current theta
-        self._resident = -1     # which system's factor the inner engine currently holds
-        self._resident_y = None  # ... for which rotation of the observations
-        self._declared = False  # inputs + kernel handed to the inner engine
+        self._state = None       # decomposition of the current theta
+        self._per_system = False
 
     # -- declaration ------------------------------------------------------------------------------------------
     def set_data(self, X, y):
         self.X = np.ascontiguousarray(X, dtype=np.float64)
         self.y = np.ascontiguousarray(y, dtype=np.float64)
         self._state = None
-        self._declared = False
+        self._slots = {}
 
     def set_kernel(self, spec: KernelSpec):
         if not aligned_outputs(self.X, spec):
@@ -89,7 +93,9 @@ class IcmEngine:
         self.i_eta, self.i_sigma = n_ls, n_ls + 1
         self.i_tau = n_ls + 2 + len(spec.idx_lin) if spec.idx_lin else -1
         self._state = None
-        self._declared = False
+        self._slots = {}
+        npad = -(-self.N // 128) * 128
+        self._per_system = self.P * 2.0 * 8.0 * npad * (npad + 128) <= self.RESIDENT_BYTES
 
     def set_theta(self, theta):
         theta = np.asarray(theta, dtype=np.float64)
@@ -100,7 +106,6 @@ class IcmEngine:
             raise ValueError("lengthscales, eta, sigma and tau must be positive")
         self.theta = theta.copy()
         self._state = None
-        self._resident = -1
 
     # -- decomposition ----------------------------------------------------------------------------------------
     def _decompose(self):
@@ -138,17 +143,28 @@ class IcmEngine:
         return tp
 
     def _load(self, p, st):
-        """Make the inner engine hold system p, factorised."""
-        if not self._declared:   # inputs and kernel once; the P systems differ in y and theta only (gmb_set_y keeps
-            self.eng.set_data(self.Xn, st["Yt"][p])   # the workspaces -- a gmb_set_data per system re-allocated them)
-            self.eng.set_kernel(self.spec_k)
-            self._declared = True
-        elif self._resident != p or self._resident_y is not st["Yt"]:
-            self.eng.set_y(st["Yt"][p])
-        self._resident_y = st["Yt"]
-        self.eng.set_theta(self._theta_p(st["lam"][p]))
-        self.eng.factorize()
-        self._resident = p
+        """The inner engine that holds system p, factorised at the current theta.  With one engine per system
+        (they fit: P x (factor + gradient workspace) <= RESIDENT_BYTES) nothing is recomputed while theta stands --
+        the gradient leaves the factor intact -- so ``predict`` after ``nlml`` and repeated ``predict`` calls reuse
+        the resident factors; otherwise engine 0 serves the systems in turn."""
+        k = p if self._per_system else 0
+        while len(self._engs) <= k:
+            self._engs.append(Engine(sibling_of=self.eng))
+        eng = self._engs[k]
+        slot = self._slots.get(k)
+        tp = self._theta_p(st["lam"][p])
+        if slot is None:   # inputs and kernel once; the systems differ in y and theta only (gmb_set_y keeps the
+            eng.set_data(self.Xn, st["Yt"][p])   # workspaces -- a gmb_set_data per system re-allocated them)
+            eng.set_kernel(self.spec_k)
+            slot = self._slots[k] = dict(p=p, y=st["Yt"], theta=None)
+        elif slot["p"] != p or slot["y"] is not st["Yt"]:
+            eng.set_y(st["Yt"][p])
+            slot.update(p=p, y=st["Yt"], theta=None)
+        if slot["theta"] is None or not np.array_equal(slot["theta"], tp) or not eng.factor_is_current():
+            eng.set_theta(tp)
+            eng.factorize()
+            slot["theta"] = tp
+        return eng
 
     # -- evaluation -------------------------------------------------------------------------------------------
     def factorize(self):
@@ -165,16 +181,15 @@ class IcmEngine:
         if not grad:
             val = const
             for p in range(P):
-                self._load(p, st)
-                val += self.eng.nlml()
+                val += self._load(p, st).nlml()
             return val
         val, gk = const, np.zeros(self.nk)
         s = np.zeros(P)
         At = np.zeros((P, N))
         for p in range(P):
-            self._load(p, st)
-            f, g = self.eng.nlml(grad=True)
-            a = self.eng.copy_alpha()
+            eng = self._load(p, st)
+            f, g = eng.nlml(grad=True)
+            a = eng.copy_alpha()
             val += f
             At[p] = a
             s[p] = g[self.i_sigma] + a @ a
@@ -217,8 +232,7 @@ class IcmEngine:
         mean, var = np.zeros(M), np.zeros(M)
         Q, Dd = st["Q"], st["Dd"]
         for p in range(self.P):
-            self._load(p, st)
-            m_p, v_p = self.eng.predict(x, with_noise=False)
+            m_p, v_p = self._load(p, st).predict(x, with_noise=False)
             mean += Q[task, p] * m_p
             var += Q[task, p] ** 2 * v_p
         mean *= np.sqrt(Dd[task])
@@ -228,7 +242,19 @@ class IcmEngine:
         return mean, var
 
     def factor_is_current(self):
-        return False  # one inner engine serves the P systems in turn: nothing stays resident for all of them
+        """True when every system's factor for the current theta is resident (one engine per system)."""
+        if not self._per_system or self._state is None:
+            return False
+        st = self._state
+        for p in range(self.P):
+            slot = self._slots.get(p)
+            if (slot is None or slot["p"] != p or slot["y"] is not st["Yt"] or slot["theta"] is None
+                    or not np.array_equal(slot["theta"], self._theta_p(st["lam"][p])) or not self._engs[p].factor_is_current()):
+                return False
+        return True
 
     def close(self):
-        self.eng.close()
+        for eng in reversed(self._engs):  # siblings first: they borrow engine 0's streams
+            eng.close()
+        self._engs = [self.eng]
+        self._slots = {}

@@ -138,6 +138,11 @@ int gmb_abi_version(void);
 /* Create an engine bound to HIP device `device`.  `stream` is an existing hipStream_t to launch
  * on (e.g. torch's current stream), or NULL to let the engine create its own. */
 int gmb_create(gmb_engine** out, int32_t device, void* stream);
+/* A second engine on `peer`'s device that borrows ALL of peer's HIP streams (its own state and buffers otherwise):
+ * for callers that keep several models resident and work on them one after the other -- the Kronecker
+ * multi-output path keeps its P factorisations this way -- without multiplying the process's hardware queues.
+ * Destroy it before `peer`; not for concurrent use with `peer`. */
+int gmb_create_sibling(gmb_engine** out, const gmb_engine* peer);
 void gmb_destroy(gmb_engine* e);
 const char* gmb_last_error(const gmb_engine* e); /* valid until the next call on `e` */
 void* gmb_stream(const gmb_engine* e);           /* the hipStream_t launches go to   */

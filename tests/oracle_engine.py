@@ -10,23 +10,31 @@ from oracle import gp_oracle as O
 class OracleEngine:
     """numpy stand-in for ``gumbi_amd.engine.Engine`` (test infrastructure only)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, sibling_of=None):
         self.X = self.y = self.spec = self.theta = None
+        self._factored = False
 
     def set_data(self, X, y):
         self.X, self.y = np.asarray(X, float), np.asarray(y, float)
+        self._factored = False
 
     def set_y(self, y):
         self.y = np.asarray(y, float)
+        self._factored = False
+
+    def factor_is_current(self):
+        return self._factored
 
     def set_kernel(self, spec):
         self.spec = spec.as_dict()
 
     def set_theta(self, theta):
         self.theta = np.asarray(theta, float).copy()
+        self._factored = False
 
     def factorize(self):
         O.factorize(self.spec, self.theta, self.X, self.y, dist_mode="direct")  # raises LinAlgError if not PD
+        self._factored = True
 
     def nlml(self, grad=False):
         if not grad:

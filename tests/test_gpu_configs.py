@@ -258,6 +258,52 @@ def test_kronecker_engine_matches_the_oracle_directly(gpu, n, d, lin):
     kron.close()
 
 
+def test_kronecker_path_keeps_every_system_resident(gpu, monkeypatch):
+    """One inner engine per system (siblings sharing one set of HIP streams): after a gradient evaluation every
+    factor is still resident, so predictions and repeated evaluations at the same theta factorise nothing; the
+    single-shared-engine mode (systems that do not fit together) gives the same numbers."""
+    from gumbi_amd.engine import KernelSpec
+    from gumbi_amd.regression.icm import IcmEngine
+
+    n, d = 700, 3
+    X, y, spec, theta = icm_problem(n, d, seed=5)
+    ks = KernelSpec(D=d + 1, idx_cont=list(range(d)), kind="ExpQuad", out_col=d, n_out=2, hetero_noise=True)
+    Xs1 = np.random.default_rng(1).standard_normal((150, d))
+    Xs = np.vstack([np.column_stack([Xs1, np.full(len(Xs1), p)]) for p in range(2)])
+    kron = IcmEngine(0)
+    kron.set_data(X, y)
+    kron.set_kernel(ks)
+    kron.set_theta(theta)
+    kron.factorize()
+    val, g = kron.nlml(grad=True)
+    assert len(kron._engs) == 2 and kron.factor_is_current()
+    calls = []
+    for e in kron._engs:
+        monkeypatch.setattr(e, "factorize", lambda orig=e.factorize: (calls.append(1), orig())[1])
+    mu, var = kron.predict(Xs)
+    mu_b, var_b = kron.predict(Xs[::-1])
+    val2, g2 = kron.nlml(grad=True)
+    assert not calls
+    assert val2 == val and np.array_equal(g2, g)
+    assert np.array_equal(mu_b[::-1], mu) and np.array_equal(var_b[::-1], var)
+    kron.set_theta(theta * 1.01)
+    assert not kron.factor_is_current()
+    kron.nlml()
+    assert len(calls) == 2 and kron.factor_is_current()
+    kron.close()
+    monkeypatch.setattr(IcmEngine, "RESIDENT_BYTES", 0.0)
+    shared = IcmEngine(0)
+    shared.set_data(X, y)
+    shared.set_kernel(ks)
+    shared.set_theta(theta)
+    shared.factorize()
+    val_s, g_s = shared.nlml(grad=True)
+    mu_s, var_s = shared.predict(Xs)
+    assert len(shared._engs) == 1 and not shared.factor_is_current()
+    assert val_s == val and np.array_equal(g_s, g) and np.array_equal(mu_s, mu) and np.array_equal(var_s, var)
+    shared.close()
+
+
 def test_c4_full_size_kronecker_equals_stacked(gpu):
     """C4 at full size both ways: the stacked 40k x 40k system and the Kronecker form (two 20k x 20k
     systems, gumbi_amd/regression/icm.py) give the same NLML, gradient and predictions; the
