@@ -525,6 +525,44 @@ __host__ __device__ __forceinline__ long long cov_tri_blocks_before(int i, int t
   return n;
 }
 
+// Block b of cov_tile_kernel's grid -> its strip: tile row *tix, tiles [*tj_lo, *tj_hi) along the column index;
+// false for blocks with nothing to do.  Shared by the kernel and gmb_debug_cov_grid (tests/test_abi.py checks on
+// the host that every tile of every enumeration comes out exactly once).  `sqrt_guess` differs between host and
+// device only in rounding; the stepping loops make the result exact either way.
+__host__ __device__ __forceinline__ bool cov_decode_block(int ti, int tj, int strip, int tri_grid, int row_first,
+                                                          int row_stride, bool keep_order, long long b, int* tix,
+                                                          int* tj_lo, int* tj_hi) {
+  const int S = strip < 1 ? 1 : strip;
+  int row, ts, ncols;  // tile row, strip index, tiles this row holds
+  if (row_stride > 0) {
+    const int nst = (tj + S - 1) / S;
+    const int m = (int)(b / nst);
+    ts = (int)(b - (long long)m * nst);
+    row = row_first + m * row_stride;
+    ncols = row + 1 < tj ? row + 1 : tj;
+  } else if (tri_grid) {
+    // blocks before row i ~ i + i^2 / (2 S): invert, then step to the exact row
+    const double Sd = (double)S;
+    int i = (int)(__builtin_sqrt(Sd * Sd + 2.0 * Sd * (double)b) - Sd);
+    i = i < 0 ? 0 : (i > ti - 1 ? ti - 1 : i);
+    while (cov_tri_blocks_before(i, tj, S) > b) --i;
+    while (cov_tri_blocks_before(i + 1, tj, S) <= b) ++i;
+    row = i;
+    ts = (int)(b - cov_tri_blocks_before(i, tj, S));
+    ncols = row + 1 < tj ? row + 1 : tj;
+  } else {
+    const int nst = (tj + S - 1) / S;
+    const int wg = keep_order ? (int)b : xcd_remap((int)b, ti * nst);
+    ts = wg / ti;
+    row = wg - ts * ti;
+    ncols = tj;
+  }
+  *tix = row;
+  *tj_lo = ts * S;
+  *tj_hi = *tj_lo + S < ncols ? *tj_lo + S : ncols;
+  return row < ti && *tj_lo < *tj_hi;
+}
+
 // The grid.  A workgroup computes a STRIP of `strip` consecutive tiles of one tile row (same 128 row points,
 // 128 * strip column points): its interior tiles in one pass of cov_interior_tile, whatever else it holds (the
 // diagonal tile at the end of a row, boundary tiles) through cov_general_tile.  Strips amortise dispatch, decode,
@@ -539,34 +577,10 @@ __host__ __device__ __forceinline__ long long cov_tri_blocks_before(int i, int t
 // otherwise they land in AGPRs and every entry pays two v_accvgpr_read.)
 template <int KIND, int NC>
 __global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
-  const int S = a.strip < 1 ? 1 : a.strip;
-  int tix, ts, ncols;  // tile row, strip index, tiles this row holds
-  if (a.row_stride > 0) {
-    const int nst = (a.tj + S - 1) / S;
-    const int m = blockIdx.x / nst;
-    ts = blockIdx.x - m * nst;
-    tix = a.row_first + m * a.row_stride;
-    ncols = tix + 1 < a.tj ? tix + 1 : a.tj;
-  } else if (a.tri_grid) {
-    // blocks before row i ~ i + i^2 / (2 S): invert, then step to the exact row
-    const double Sd = (double)S;
-    int i = (int)(__builtin_sqrt(Sd * Sd + 2.0 * Sd * (double)blockIdx.x) - Sd);
-    i = i < 0 ? 0 : (i > a.ti - 1 ? a.ti - 1 : i);
-    while (cov_tri_blocks_before(i, a.tj, S) > (long long)blockIdx.x) --i;
-    while (cov_tri_blocks_before(i + 1, a.tj, S) <= (long long)blockIdx.x) ++i;
-    tix = i;
-    ts = (int)((long long)blockIdx.x - cov_tri_blocks_before(i, a.tj, S));
-    ncols = tix + 1 < a.tj ? tix + 1 : a.tj;
-  } else {
-    const int nst = (a.tj + S - 1) / S;
-    const int wg = (a.mode == COV_TRAIN && a.lower_only) ? (int)blockIdx.x : xcd_remap(blockIdx.x, a.ti * nst);
-    ts = wg / a.ti;
-    tix = wg - ts * a.ti;
-    ncols = a.tj;
-  }
-  const int tj_lo = ts * S;
-  const int tj_hi = tj_lo + S < ncols ? tj_lo + S : ncols;
-  if (tix >= a.ti || tj_lo >= tj_hi) return;
+  int tix, tj_lo, tj_hi;
+  if (!cov_decode_block(a.ti, a.tj, a.strip, a.tri_grid, a.row_first, a.row_stride,
+                        a.mode == COV_TRAIN && a.lower_only, (long long)blockIdx.x, &tix, &tj_lo, &tj_hi))
+    return;
   int tj_gen = tj_lo;  // first tile of the strip that goes through the direct loop
 #ifndef GMB_KBUILD_DIRECT
   // Interior tiles: stationary term only, every row and column real and -- for the training matrix -- the tile

@@ -474,18 +474,19 @@ int launch_leaf(gmb_engine* e, const LeafArgs& a) {
   return GMB_OK;
 }
 
+// grid = the strips of cov_tile_kernel's enumeration (strip tiles per workgroup along the column index)
+long long cov_grid_blocks(int ti, int tj, int strip, int tri_grid, int row_first, int row_stride) {
+  const int S = strip < 1 ? 1 : strip;
+  const long long nst = (tj + S - 1) / S;
+  if (row_stride > 0) return row_first < ti ? ((ti - 1 - row_first) / row_stride + 1) * nst : 0;
+  if (tri_grid) return cov_tri_blocks_before(ti, tj, S);
+  return (long long)ti * nst;
+}
+
 template <int KIND>
 int launch_cov_nc(gmb_engine* e, const CovTileArgs& a, int nc) {
-  // grid = the strips of cov_tile_kernel's enumeration (a.strip tiles per workgroup along the column index)
-  const int S = a.strip < 1 ? 1 : a.strip;
-  const long long nst = (a.tj + S - 1) / S;
-  long long nb = (long long)a.ti * nst;
-  if (a.row_stride > 0) {
-    nb = a.row_first < a.ti ? ((a.ti - 1 - a.row_first) / a.row_stride + 1) * nst : 0;
-    if (nb == 0) return GMB_OK;
-  } else if (a.tri_grid) {
-    nb = cov_tri_blocks_before(a.ti, a.tj, S);
-  }
+  const long long nb = cov_grid_blocks(a.ti, a.tj, a.strip, a.tri_grid, a.row_first, a.row_stride);
+  if (nb <= 0) return GMB_OK;
   const dim3 grid((unsigned)nb), block(256);
   switch (nc) {
     case 1: hipLaunchKernelGGL((cov_tile_kernel<KIND, 1>), grid, block, 0, e->stream, a); break;
@@ -2036,6 +2037,27 @@ int64_t gmb_debug_tile_list(int32_t mt, int32_t nt, int32_t bm, int32_t bn, int3
       out[3 * n + 2] = tn;
     }
     ++n;
+  }
+  return n;
+}
+
+int64_t gmb_debug_cov_grid(int32_t ti, int32_t tj, int32_t strip, int32_t tri_grid, int32_t row_first, int32_t row_stride,
+                           int32_t keep_order, int32_t* out, int64_t cap, int64_t* grid) {
+  if (ti < 1 || tj < 1 || strip < 1 || row_first < 0 || row_stride < 0) return GMB_EINVAL;
+  const long long nb = cov_grid_blocks(ti, tj, strip, tri_grid, row_first, row_stride);
+  if (grid) *grid = nb;
+  int64_t n = 0;
+  for (long long b = 0; b < nb; ++b) {
+    int tix, lo, hi;
+    if (!cov_decode_block(ti, tj, strip, tri_grid, row_first, row_stride, keep_order != 0, b, &tix, &lo, &hi)) continue;
+    for (int t = lo; t < hi; ++t) {
+      if (out && n < cap) {
+        out[3 * n] = (int32_t)b;
+        out[3 * n + 1] = tix;
+        out[3 * n + 2] = t;
+      }
+      ++n;
+    }
   }
   return n;
 }

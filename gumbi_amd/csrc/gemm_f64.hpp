@@ -95,7 +95,7 @@ struct GemmArgs {
 // tiles that share an A panel on one L2; cutting the runs by accumulated work (triangular
 // updates skip tiles, triangular operands shorten k ranges) keeps the 8 XCDs equally busy --
 // equal tile COUNTS left the last XCD idle for half of a SYRK (23 vs 44 TFLOP/s measured).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {  // equal-count variant (K-build)
+__host__ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {  // equal-count variant (K-build)
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

@@ -225,6 +225,7 @@ _SIGNATURES = {
     "gmb_dist_nlml": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), _DBL_P, _DBL_P]),
     "gmb_dist_predict": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_int32]),
+    "gmb_debug_cov_grid": (C.c_int64, [C.c_int32] * 7 + [C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
     "gmb_debug_tile_list": (C.c_int64, [C.c_int32] * 12 + [C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32)]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gmb_blk_covariance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -527,6 +528,20 @@ def gemm_tile_list(mt, nt, bm=128, bn=128, k=1024, tri=0, tri_off=0, nblk_stride
     lib.gmb_debug_tile_list(*args, buf, n, C.byref(grid))
     arr = np.frombuffer(buf, dtype=np.int32).reshape(n, 3)
     return int(grid.value), [tuple(int(v) for v in row) for row in arr]
+
+
+def cov_grid(ti, tj, strip=1, tri_grid=1, row_first=0, row_stride=0, keep_order=1):
+    """(grid, array of (block, tile row, tile column)) of one covariance-build launch as cov_tile_kernel enumerates
+    it (host-only)."""
+    lib = load_library()
+    args = [int(v) for v in (ti, tj, strip, tri_grid, row_first, row_stride, keep_order)]
+    grid = C.c_int64()
+    n = lib.gmb_debug_cov_grid(*args, None, 0, C.byref(grid))
+    if n < 0:
+        raise ValueError("gmb_debug_cov_grid: bad arguments")
+    buf = (C.c_int32 * max(3 * n, 1))()
+    lib.gmb_debug_cov_grid(*args, buf, n, C.byref(grid))
+    return int(grid.value), np.frombuffer(buf, dtype=np.int32)[: 3 * n].reshape(n, 3).copy()
 
 
 def dist_plan(N: int, rank: int, world: int, panel_blocks: int = 0) -> list:

@@ -228,6 +228,12 @@ int gmb_copy_alpha(const gmb_engine* e, double* out);
 int64_t gmb_debug_tile_list(int32_t mt, int32_t nt, int32_t bm, int32_t bn, int32_t k, int32_t tri,
                             int32_t tri_off, int32_t nblk_stride, int32_t klo_n, int32_t khi_n, int32_t order,
                             int32_t strip, int32_t* out, int64_t cap, int32_t* grid);
+/* Host-only: the tiles of one covariance-build launch exactly as cov_tile_kernel enumerates them (strips of `strip`
+ * tiles of a tile row per workgroup; tri_grid: lower triangle of a ti x tj tile grid; row_stride > 0: one rank's
+ * block rows row_first, row_first + row_stride, ...; otherwise the ti x tj rectangle, XCD-remapped unless
+ * keep_order); out = (block, tile row, tile column) triples, *grid = the launch's grid size; returns the count. */
+int64_t gmb_debug_cov_grid(int32_t ti, int32_t tj, int32_t strip, int32_t tri_grid, int32_t row_first,
+                           int32_t row_stride, int32_t keep_order, int32_t* out, int64_t cap, int64_t* grid);
 /* The covariance build alone: what gmb_factorize factors -- the lower-triangle 128 x 128 tiles of
  * Sigma = K + noise + jitter (pymc/GP.py:580), row N = y, identity padding -- written column-major into `out`
  * (device memory; ceil((N+1)/128)*128 rows x ceil(N/128)*128 columns, leading dimension ldo >= the row count).

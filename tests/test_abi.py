@@ -135,3 +135,32 @@ def test_gemm_longest_first_orders_cover_every_tile():
             # n-major lists: with tri the m-tiles of n-tile tn are [0, (tn*bn + bn - 1)/bm]
             want = {(tm, tn) for tn in range(nt) for tm in range(mt) if not tri or tm <= (tn * 128 + 127) // 128}
             assert len(got) == len(set(got)) and set(got) == want
+
+
+@pytest.mark.parametrize("ti,tj", [(1, 1), (2, 1), (2, 2), (6, 5), (79, 79), (80, 79), (392, 391)])
+@pytest.mark.parametrize("strip", [1, 2, 3, 4, 8])
+def test_covariance_grid_covers_every_tile_exactly_once(ti, tj, strip):
+    """cov_tile_kernel's enumerations (closed-form decode of the triangular grid, one rank's block rows of the
+    multi-GPU build, the XCD-remapped rectangle of the cross-covariance), replayed on the host: every tile once,
+    every strip inside one tile row, no workgroup beyond the grid."""
+    from gumbi_amd.engine import cov_grid
+
+    want_tri = {(i, j) for i in range(ti) for j in range(min(i + 1, tj))}
+    grid, t = cov_grid(ti, tj, strip, tri_grid=1)
+    tiles = list(map(tuple, t[:, 1:]))
+    assert len(tiles) == len(set(tiles)) and set(tiles) == want_tri
+    assert t[:, 0].max() == grid - 1 and len(np.unique(t[:, 0])) == grid      # no idle workgroup in the triangle
+    for b in np.unique(t[:, 0])[:: max(1, grid // 50)]:
+        rows = t[t[:, 0] == b]
+        assert len(np.unique(rows[:, 1])) == 1 and len(rows) <= strip and np.all(np.diff(rows[:, 2]) == 1)
+    for world in (1, 2, 3, 8):
+        seen = []
+        for rank in range(world):
+            grid, t = cov_grid(ti, tj, strip, tri_grid=0, row_first=rank, row_stride=world)
+            assert np.all(t[:, 1] % world == rank) and (len(t) == 0 or t[:, 0].max() < grid)
+            seen += list(map(tuple, t[:, 1:]))
+        assert len(seen) == len(set(seen)) and set(seen) == want_tri
+    for keep in (0, 1):
+        grid, t = cov_grid(ti, tj, strip, tri_grid=0, keep_order=keep)
+        tiles = list(map(tuple, t[:, 1:]))
+        assert len(tiles) == len(set(tiles)) == ti * tj and grid == ti * -(-tj // strip)
