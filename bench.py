@@ -120,15 +120,18 @@ def pmc_traffic(config, kernel_filter):
     files = sorted(glob.glob(os.path.join(str(ROOT), "profiles", f"*_pmc_bench_{config}_summary.csv")))
     if not files:
         return None
-    launches, gbytes = 0, 0.0
+    launches, gbytes, flops = 0, 0.0, 0.0
     with open(files[-1]) as fh:
         for row in csv.DictReader(fh):
             if kernel_filter in row["Kernel"]:
                 launches += int(row["Launches"])
                 gbytes += float(row["FetchGB(x2 corrected)"]) + float(row["WriteGB(raw)"])
+                # flops of these launches from SQ_INSTS_VALU_MFMA_MOPS_F64 (rate x duration of the same pass)
+                flops += float(row["MFMA_F64_TFLOPs"]) * 1e12 * float(row["TotalMs(pass1)"]) * 1e-3
     if launches == 0:
         return None
-    return {"bytes_per_launch": gbytes * 1e9 / launches, "source": os.path.relpath(files[-1], str(ROOT)), "launches": launches}
+    return {"bytes_per_launch": gbytes * 1e9 / launches, "source": os.path.relpath(files[-1], str(ROOT)), "launches": launches,
+            "flops_per_launch": flops / launches}
 
 
 def cpu_baseline(cfg, target_seconds=20.0):
@@ -227,11 +230,17 @@ def roofline_block(tm, config):
             "frac_of_their_share_of_peak": round(mtf / (FP64_MFMA_PEAK_TFLOPS * tm["masked_cus"] / ncu), 4),
         }
     pt = pmc_traffic(config, "gemm_f64_kernel<2, 2, 4, 4")  # the 128 x 128 instantiation the bulk updates run
-    if pt is not None:
-        out["traffic"] = round(pt["bytes_per_launch"], 1)
-        out["traffic_unit"] = ("HBM bytes per launch of the 128x128 gemm_f64_kernel instantiation (2*FETCH_SIZE + WRITE_SIZE; "
-                               "all its launches of one bench step, the bulk trailing updates among them)")
+    if pt is not None and pt["flops_per_launch"] > 0:
+        # the PMC passes count every launch of the 128x128 instantiation (bulk updates, solves, inverse, Sigma^-1,
+        # predict: other launch sizes than the ones `achieved` is quoted on), so the bytes are scaled by flops
+        bytes_per_flop = pt["bytes_per_launch"] / pt["flops_per_launch"]
+        out["traffic"] = round(bytes_per_flop * tm["total_chol_gemm_flops"] / n_chol, 1)
+        out["traffic_unit"] = ("HBM-side bytes per bulk-update launch: (2*FETCH_SIZE + WRITE_SIZE) per flop of the 128x128 "
+                               "gemm_f64_kernel instantiation over one bench step (rocprofv3 PMC passes), times this launch's flops")
+        out["traffic_flop_per_byte"] = round(1.0 / bytes_per_flop, 2)
         out["traffic_source"] = pt["source"]
+        out["traffic_source_per_launch"] = {"launches": pt["launches"], "bytes": round(pt["bytes_per_launch"], 1),
+                                            "flops": round(pt["flops_per_launch"], 1)}
     return out
 
 
