@@ -502,8 +502,8 @@ int launch_cov_nc(gmb_engine* e, const CovTileArgs& a, int nc) {
 int launch_cov(gmb_engine* e, const CovTileArgs& a_in) {
   if (a_in.ti <= 0 || a_in.tj <= 0) return GMB_OK;
   CovTileArgs a = a_in;
-  const double tiles = (double)a.ti * a.tj * (a.lower_only ? 0.5 : 1.0);
-  a.stream_stores = tiles * TILE * TILE * 8.0 >= 1073741824.0;
+  const double tiles = (double)a.ti * a.tj * (a.lower_only ? 0.5 : 1.0) / (a.row_stride > 0 ? a.row_stride : 1);  // this launch's share
+  a.stream_stores = tiles * TILE * TILE * 8.0 >= 1073741824.0 / (a.row_stride > 0 ? a.row_stride : 1);  // by the whole matrix
   // tiles per workgroup: enough strips left to fill the chip's ~800 workgroup slots several times over
   a.strip = e->cov_strip > 0 ? e->cov_strip : (tiles >= 32768.0 ? 4 : tiles >= 12288.0 ? 2 : 1);
   switch (a.p.kind) {
