@@ -317,6 +317,26 @@ def test_predict_edge_cases(gpu):
     assert rel(mu, O.predict(spec, theta2, X, y, X[:50], dist_mode="direct")[0]) < 1e-10
 
 
+def test_predict_with_a_nan_test_point_poisons_only_that_point(gpu):
+    """Cross-covariance tiles holding a non-finite test point leave the matrix-pipe form for the direct loop:
+    that point's mean / variance come out NaN (as the reference's arithmetic gives), every other point is untouched."""
+    N, d, M = 700, 4, 400
+    X, y, ls = O.synthetic_table(N, d, seed=23)
+    spec = O.make_spec(d, range(d), kind="Matern32")
+    eng = make_engine(spec, O.pack_theta(spec, ls, 1.0, 0.2), X, y)
+    eng.factorize()
+    Xs = np.random.default_rng(3).standard_normal((M, d))
+    mu0, var0 = eng.predict(Xs)
+    Xs_bad = Xs.copy()
+    Xs_bad[200, 2] = np.nan
+    mu, var = eng.predict(Xs_bad)
+    assert np.isnan(mu[200]) and np.isnan(var[200])
+    keep = np.arange(M) != 200
+    # (its 127 tile-row neighbours take the direct loop too: same values to the rounding of r^2's two forms)
+    assert np.allclose(mu[keep], mu0[keep], rtol=0, atol=1e-12) and np.allclose(var[keep], var0[keep], rtol=0, atol=1e-12)
+    eng.close()
+
+
 def test_colliding_inputs_and_tiny_noise(gpu):
     """Exactly repeated rows make K rank-deficient: only sigma^2 + jitter keeps Sigma positive definite.
     The factor, NLML, gradient and predictions must still follow the oracle (the jitter is part of
