@@ -88,6 +88,10 @@ struct GemmArgs {
   // panel and 64 different B panels in the row-major order (strip == 0).  PMC at C3 (r02d): the row-major
   // 128 x 128 launches fetched 2.5 TB/s, 13x the algorithmic operand + C traffic.
   int32_t strip;
+  // strip > 0 (filled by gemm_schedule): the strip that holds the first tile of XCD run x starts at m-tile
+  // xs_t0[x] and at position xs_base[x] of the list -- a block starts its search for its strip there instead of
+  // at strip 0 (one rank's update at N = 100k has ~90 strips; the search cost ~60 us of a 1.4 ms tile)
+  int32_t xs_t0[8], xs_base[8];
 };
 
 // XCD-aware tile order.  The dispatcher places block b on XCD b % 8 (observed, speed only), and
@@ -109,9 +113,16 @@ __host__ __device__ __forceinline__ int64_t gemm_noff(int tn, int bn, int stride
 }
 __host__ __device__ __forceinline__ int gemm_first_tn(int64_t T, int bn, int stride) {
   if (T <= 0) return 0;
+  const int per = 128 / bn;
+  if (T < 0x7fffffff) {  // (every matrix the engine can hold: 32-bit division is several times cheaper on the device)
+    const uint32_t S = (uint32_t)stride * 128u, t = (uint32_t)T;
+    const uint32_t q = t / S, r = t - q * S;
+    if (r == 0) return (int)(q * per);
+    if (r > (uint32_t)(128 - bn)) return (int)((q + 1) * per);
+    return (int)(q * per + (r + bn - 1) / (uint32_t)bn);
+  }
   const int64_t S = (int64_t)stride * 128;
   const int64_t q = T / S, r = T % S;
-  const int per = 128 / bn;
   if (r == 0) return (int)(q * per);
   if (r > 128 - bn) return (int)((q + 1) * per);
   return (int)(q * per + (r + bn - 1) / bn);
@@ -133,7 +144,8 @@ __host__ __device__ inline bool gemm_decode_tile(const GemmArgs& g, const int BM
       const int f = gemm_first_tn((int64_t)t * BM - g.tri_off - (BN - 1), BN, g.nblk_stride);
       return f > g.nt ? g.nt : f;
     };
-    int t0 = 0;
+    int t0 = g.xs_t0[xcd];
+    ci -= g.xs_base[xcd];
     for (;;) {  // find the strip
       const int t1 = t0 + g.strip < g.mt ? t0 + g.strip : g.mt;
       int cnt = 0;
@@ -488,6 +500,7 @@ inline int gemm_schedule(GemmArgs& g, int bm, int bn, double* flops) {
     // work-balanced cuts of the strip-major list: walk the strips, inside the strip that holds a cut walk its
     // n-tiles (tile work depends on tn only: P)
     g.xstart[0] = 0;
+    for (int i = 0; i < 8; ++i) g.xs_t0[i] = g.xs_base[i] = 0;
     long long acc = 0, ci = 0;
     int x = 1;
     for (int t0 = 0; t0 < g.mt && x < 8; t0 += g.strip) {
@@ -505,7 +518,11 @@ inline int gemm_schedule(GemmArgs& g, int bm, int bn, double* flops) {
           while (have < sz && first_of(t0 + have) <= tn) ++have;
           const long long w1 = P[tn + 1] - P[tn];
           for (int q = 0; q < have && x < 8; ++q) {
-            if ((a2 + w1) * 8 >= (long long)x * total) g.xstart[x++] = (int)(c2 + 1);
+            if ((a2 + w1) * 8 >= (long long)x * total) {
+              g.xs_t0[x] = t0;
+              g.xs_base[x] = (int)ci;
+              g.xstart[x++] = (int)(c2 + 1);
+            }
             a2 += w1;
             ++c2;
           }
