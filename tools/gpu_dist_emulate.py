@@ -86,6 +86,17 @@ for w in widths:
     print(f"  rank {rank} of {G}, panel_blocks={w}: {t * 1e3:.1f} ms = {single / G / t:.2f} of ideal "
           f"({N**3 / 3 / G / t / 1e12:.1f} TF/s per GPU); {comm.calls} all-gathers, {comm.bytes / 1e9:.1f} GB received "
           f"(= {comm.bytes / 1e9 / 300:.3f} s at 300 GB/s if not hidden)", flush=True)
+    eng.set_profiling(True)  # one more run with an event pair around every launch: where the time goes
+    try:
+        eng.dist_factorize(comm, w)
+    except np.linalg.LinAlgError:
+        pass
+    tm = eng.timings()
+    eng.set_profiling(False)
+    print(f"    profiled: K-build {tm['kbuild_ms']:.1f} ms, Cholesky {tm['chol_ms']:.1f} ms of which the sum of U1 / U2 launches "
+          f"{tm['total_chol_gemm_ms']:.1f} ms ({tm['total_chol_gemm_flops'] / max(tm['total_chol_gemm_ms'], 1e-9) / 1e9:.1f} TF/s, "
+          f"{int(tm['total_chol_gemm_launches'])} launches), in-panel products {tm['total_chol_panel_gemm_ms']:.1f} ms, "
+          f"leaves {tm['chol_leaf_ms']:.1f} ms, strips {tm['chol_trsm_ms']:.1f} ms", flush=True)
 # gradient: every rank holds the complete factor after the factorisation, so a single-engine factorisation puts this
 # GPU in exactly that state; the row-partitioned gradient then runs as rank `rank` of G (the other ranks' rows of U
 # arrive as copies of this rank's -- garbage values, real timing)
