@@ -7,6 +7,7 @@ covariance build, Cholesky factorisation and posterior solves run in ``libgumbi_
 """
 
 from .aggregation import DataSet, Standardizer, TidyData, WideData
+from .array_utils import make_deltas_parray
 from .arrays import (
     LayeredArray,
     MVUncertainParameterArray,
@@ -27,5 +28,5 @@ mvuparray = MVUncertainParameterArray
 __all__ = [
     "DataSet", "Standardizer", "TidyData", "WideData", "LayeredArray", "ParameterArray", "UncertainArray",
     "UncertainParameterArray", "MVUncertainParameterArray", "GP", "HipGP", "Regressor", "parray", "uarray",
-    "uparray", "mvuparray",
+    "uparray", "mvuparray", "make_deltas_parray",
 ]

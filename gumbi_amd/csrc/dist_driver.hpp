@@ -120,50 +120,176 @@ int dist_pack(gmb_engine* e, hipStream_t st, double* mat, int64_t ld, double* pa
   return GMB_OK;
 }
 
-int dist_all_gather(gmb_engine* e, const gmb_comm* comm, hipStream_t st, const double* send, double* recv, int64_t count) {
+// ---- communication probes --------------------------------------------------------------------------------
+// A HIP event pair around every all-gather (on the stream it is ordered on: first event = the stream has
+// reached the collective, second = the collective is complete, i.e. transfer + wait for the slowest peer) and
+// an event on either side of every cross-stream wait of the panel loop.  Read back after the call's final
+// synchronisation; gmb_timings.dist_* (include/gumbi_hip.h) says what is derived from them.
+struct DistProbe {
+  struct Coll {
+    hipEvent_t a, b;
+    double bytes;
+    int group;      // factorisation: index of the panel chain the collective belongs to
+    bool exposed;   // sits on the main stream of a phase with nothing beside it
+  };
+  struct Wait {
+    hipEvent_t arrive, release;  // waiting stream reached the wait / the other stream reached the point waited for
+    int group;
+    int kind;  // 0: main waits for bulk (JOIN), 1: bulk waits for main (FORK), 2: main waits for the comm stream
+  };
+  std::vector<Coll> colls;
+  std::vector<Wait> waits;
+  int group = -1;
+};
+
+int dist_all_gather(gmb_engine* e, const gmb_comm* comm, hipStream_t st, const double* send, double* recv, int64_t count,
+                    DistProbe* probe = nullptr, bool exposed = false) {
+  DistProbe::Coll c{};
+  if (probe) {
+    c.a = next_time_event(e);
+    c.b = next_time_event(e);
+    c.bytes = 8.0 * (double)count * (double)(comm->world - 1);
+    c.group = probe->group;
+    c.exposed = exposed;
+    (void)hipEventRecord(c.a, st);
+  }
   const int32_t rc = comm->all_gather(comm->ctx, send, recv, count, (void*)st);
+  if (probe) {
+    (void)hipEventRecord(c.b, st);
+    probe->colls.push_back(c);
+  }
   if (rc != 0) return fail(e, GMB_EHIP, "all-gather of %lld doubles failed on rank %d (transport status %d)",
                            (long long)count, comm->rank, rc);
   return GMB_OK;
 }
 
+// `waiter` waits for everything enqueued on `other` so far (order_after), with an event on each side
+int dist_wait(gmb_engine* e, hipStream_t other, hipStream_t waiter, DistProbe* probe, int kind) {
+  if (other == waiter) return GMB_OK;
+  if (probe) {
+    DistProbe::Wait w{};
+    w.arrive = next_time_event(e);
+    w.release = next_time_event(e);
+    w.group = probe->group;
+    w.kind = kind;
+    (void)hipEventRecord(w.arrive, waiter);
+    (void)hipEventRecord(w.release, other);
+    probe->waits.push_back(w);
+  }
+  return order_after(e, other, waiter);
+}
+
+double dist_ms(hipEvent_t a, hipEvent_t b) {
+  float t = 0.f;
+  if (hipEventElapsedTime(&t, a, b) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0.0;
+  }
+  return t > 0.f ? (double)t : 0.0;
+}
+
 int dist_check_comm(gmb_engine* e, const gmb_comm* comm) {
-  if (!comm || !comm->all_gather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)
-    return fail(e, GMB_EINVAL, "bad communicator");
+  if (!comm || !comm->all_gather || comm->world < 1 || comm->world > DIST_MAX_WORLD || comm->rank < 0 ||
+      comm->rank >= comm->world)
+    return fail(e, GMB_EINVAL, "bad communicator (1 <= world <= %d)", DIST_MAX_WORLD);
   return GMB_OK;
 }
 
+// The ranks agree on a status: every rank contributes `mine` (0 or a negative gmb_status), every rank
+// receives the first non-zero one in rank order (and whose it was).  Synchronises e->stream.  A rank that
+// failed locally -- an allocation, a launch, its transport -- must not simply return from a collective
+// call: its peers would block in their next all-gather for ever.  gmb_dist_* therefore (i) allocate
+// everything first and agree on the outcome before the first data collective, (ii) after that never leave
+// the collective sequence: a failing rank keeps issuing the remaining all-gathers of the plan (on whatever its
+// buffers hold) and (iii) agree on the outcome once more at the end, so that every rank returns an error when
+// any rank failed.
+int dist_agree(gmb_engine* e, const gmb_comm* comm, int mine, const char* where) {
+  if (comm->world == 1) return mine;
+  const double v = (double)mine;
+  double all[DIST_MAX_WORLD];
+  hipError_t st = hipMemcpyAsync(e->dstat, &v, sizeof(double), hipMemcpyHostToDevice, e->stream);
+  if (st == hipSuccess) st = hipStreamSynchronize(e->stream);  // v lives on this frame
+  int32_t tr = comm->all_gather(comm->ctx, e->dstat, e->dstat + 8, 1, (void*)e->stream);
+  if (st == hipSuccess && tr == 0)
+    st = hipMemcpyAsync(all, e->dstat + 8, comm->world * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+  if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+  if (st != hipSuccess || tr != 0) {
+    (void)hipGetLastError();
+    if (mine) return mine;
+    return fail(e, GMB_EHIP, "%s: the ranks could not exchange their status (transport status %d, %s)", where, tr,
+                hipGetErrorString(st));
+  }
+  for (int q = 0; q < comm->world; ++q)
+    if (all[q] != 0.0) {
+      const int code = (int)all[q];
+      if (q == comm->rank) return mine;  // this rank's own message is already in e->err
+      return fail(e, code, "%s: rank %d of %d failed with status %d; no rank has a usable result", where, q, comm->world,
+                  code);
+    }
+  return GMB_OK;
+}
+
+// first error of a call that must go on issuing its collectives
+struct DistDeferred {
+  int rc = 0;
+  std::string msg;
+  void note(gmb_engine* e, int r) {
+    if (r && !rc) {
+      rc = r;
+      msg = e->err;
+    }
+  }
+  int give(gmb_engine* e) const {
+    if (rc) e->err = msg;
+    return rc;
+  }
+};
+
 int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
-  int rc = require_ready(e, false);
-  if (rc) return rc;
-  if ((rc = dist_check_comm(e, comm))) return rc;
-  HIP_TRY(e, hipSetDevice(e->device));
+  int rc = dist_check_comm(e, comm);
+  if (rc) return rc;  // nothing to talk through
   const int G = comm->world, rank = comm->rank;
+  gmb_timings& tm = e->tm;
+  // ---- everything that can fail locally happens before the first collective; then the ranks agree ----
+  rc = require_ready(e, false);
+  if (!rc && hipSetDevice(e->device) != hipSuccess) rc = fail(e, GMB_EHIP, "hipSetDevice(%d) failed", e->device);
+  std::vector<gmb_dist_step> plan;
+  if (!rc) {
+    plan = dist_build_plan(e->N, rank, G, panel_blocks > 0 ? panel_blocks : (e->panel_auto ? 0 : e->panel_blocks));
+    int64_t need = 0;
+    for (const gmb_dist_step& s : plan) need = std::max(need, s.elems);
+    if (!(rc = ensure(e, &e->dsend, &e->cap_send, need))) rc = ensure(e, &e->drecv, &e->cap_recv, need * G);
+  }
+  if ((rc = dist_agree(e, comm, rc, "gmb_dist_factorize (set-up)"))) return rc;
   e->factored = false;
   e->factor_consumed = false;
   e->have_alpha = false;
   e->notpd = -1;
-  gmb_timings& tm = e->tm;
   tm.kbuild_ms = tm.chol_ms = tm.chol_gemm_ms = tm.chol_gemm_flops = 0.0;
   tm.chol_leaf_ms = tm.chol_trsm_ms = 0.0;
   tm.chol_gemm_launches = 0;
-  HIP_TRY(e, hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream));
-  HIP_TRY(e, hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream));
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
-  const std::vector<gmb_dist_step> plan = dist_build_plan(e->N, rank, G, panel_blocks > 0 ? panel_blocks : (e->panel_auto ? 0 : e->panel_blocks));
-  int64_t need = 0;
-  for (const gmb_dist_step& s : plan) need = std::max(need, s.elems);
-  if ((rc = ensure(e, &e->dsend, &e->cap_send, need))) return rc;
-  if ((rc = ensure(e, &e->drecv, &e->cap_recv, need * G))) return rc;
   hipStream_t mainS = e->stream, bulkS = e->aux[2];
   e->sync_next = 0;
+  e->time_next = 0;
   e->cur = mainS;
   e->chol_update_kind = 0;  // chol_cols factors the panels' squares: in-panel products
+  DistDeferred bad;
+  DistProbe probe;
+  {
+    hipError_t st = hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream);
+    if (st == hipSuccess) st = hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream);
+    if (st != hipSuccess) bad.note(e, fail(e, GMB_EHIP, "hipMemsetAsync failed: %s", hipGetErrorString(st)));
+  }
   PhaseTimer tk(e);
   PhaseTimer* tc = nullptr;
   for (const gmb_dist_step& s : plan) {
     const int64_t W = (int64_t)(s.c1 - s.c0) * TILE;
-    switch (s.op) {
+    const bool has_collective = s.op == DIST_SQUARE || s.op == DIST_PANEL;
+    bool gathered = false;
+    rc = GMB_OK;
+    if (s.op == DIST_SQUARE) ++probe.group;
+    if (!bad.rc) switch (s.op) {
       case DIST_KBUILD: {  // this rank's block rows of the lower triangle, y row and padding included
         CovTileArgs a{};
         a.p = e->cp;
@@ -178,25 +304,22 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
         a.row_first = rank;
         a.row_stride = G;
         a.y = e->dy;
-        if ((rc = launch_cov(e, a))) return rc;
-        for (size_t t = 1; t < e->terms.size(); ++t) {  // additive models: accumulating passes
-          if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[t].pa))) return rc;
+        if ((rc = launch_cov(e, a))) break;
+        for (size_t t = 1; t < e->terms.size() && !rc; ++t) {  // additive models: accumulating passes
+          if ((rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[t].pa))) break;
           a.p = e->terms[t].cp;
           a.accumulate = 1;
-          if ((rc = launch_cov(e, a))) return rc;
+          rc = launch_cov(e, a);
         }
-        if (e->terms.size() > 1 &&
-            (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
-          return rc;
-        tk.stop();
-        tc = new PhaseTimer(e);
+        if (!rc && e->terms.size() > 1) rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa);
         break;
       }
       case DIST_SQUARE: {
         double* cols = e->dA + (int64_t)s.c0 * TILE * e->ld;  // column block c0 of the factor buffer
         const int64_t ldp = (int64_t)s.maxcount * TILE;
         if ((rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, true, 0, s.first, s.count, G, 0, 0, s.maxcount))) break;
-        if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems))) break;
+        gathered = true;
+        if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems, &probe))) break;
         if ((rc = dist_pack(e, mainS, cols, e->ld, e->drecv, ldp, s.elems, (int)W, false, G, 0, 0, G, s.lo, s.hi, s.maxcount))) break;
         e->cur = mainS;
         rc = chol_cols(e, s.c0, s.c1, s.c1);  // the square only: rows below are PANEL's
@@ -210,7 +333,8 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
         if (s.count > 0 &&
             (rc = trsm_cols(e, e->dsend - (int64_t)s.c0 * TILE * ldp, ldp, s.count, s.c0, s.c1, 2, 5)))
           break;
-        if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems))) break;
+        gathered = true;
+        if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems, &probe))) break;
         rc = dist_pack(e, mainS, cols, e->ld, e->drecv, ldp, s.elems, (int)W, false, G, 0, 0, G, s.lo, s.hi, s.maxcount);
         break;
       }
@@ -236,26 +360,38 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
         e->cur = mainS;
         break;
       }
-      case DIST_FORK: rc = order_after(e, mainS, bulkS); break;
-      case DIST_JOIN: rc = order_after(e, bulkS, mainS); break;
+      case DIST_FORK: rc = dist_wait(e, mainS, bulkS, &probe, 1); break;
+      case DIST_JOIN: rc = dist_wait(e, bulkS, mainS, &probe, 0); break;
     }
-    if (rc) {
-      delete tc;
-      return rc;
+    bad.note(e, rc);
+    // a rank in trouble keeps its place in the collective sequence: its peers are waiting in this all-gather
+    if (has_collective && !gathered) bad.note(e, dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems));
+    if (s.op == DIST_KBUILD) {
+      tk.stop();
+      tc = new PhaseTimer(e);
     }
   }
+  e->cur = mainS;
   // v = L^-1 y is row N of the (now complete, replicated) factor
-  hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv, e->dscal + 1);
-  if (tc) tc->stop();
-  double hs[2];
+  double hs[2] = {0.0, 0.0};
   int32_t info = 0;
-  hipError_t st = hipGetLastError();
-  if (st == hipSuccess) st = hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream);
-  if (st == hipSuccess) st = hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
-  if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
-  if (st != hipSuccess) {
+  if (!bad.rc) {
+    hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv, e->dscal + 1);
+    if (tc) tc->stop();
+    hipError_t st = hipGetLastError();
+    if (st == hipSuccess) st = hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    if (st != hipSuccess) bad.note(e, fail(e, GMB_EHIP, "distributed factorisation failed: %s", hipGetErrorString(st)));
+  } else if (tc) {
+    tc->stop();
+  }
+  rc = dist_agree(e, comm, bad.give(e), "gmb_dist_factorize");  // synchronises the main stream
+  if (rc) {
+    (void)hipStreamSynchronize(bulkS);
+    e->evs.clear();  // (their events leak on this path; the engine is unusable anyway)
     delete tc;
-    return fail(e, GMB_EHIP, "distributed factorisation failed: %s", hipGetErrorString(st));
+    return rc;
   }
   tm.kbuild_ms = tk.ms();
   tm.chol_ms = tc ? tc->ms() : 0.0;
@@ -267,6 +403,35 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
     tm.total_kbuild_ms += tm.kbuild_ms;
     tm.total_kbuild_bytes += tm.kbuild_bytes;
     tm.total_kbuild_launches += 1;
+  }
+  {  // communication probes (see gmb_timings): per panel chain, what the bulk stream had to wait for
+    tm.dist_world = G;
+    tm.dist_chol_collectives = (int64_t)probe.colls.size();
+    tm.dist_chol_comm_bytes = tm.dist_chol_comm_ms = tm.dist_chol_comm_exposed_ms = 0.0;
+    tm.dist_chol_main_wait_ms = tm.dist_chol_bulk_wait_ms = 0.0;
+    std::vector<double> chain_comm((size_t)probe.group + 2, 0.0);
+    for (const DistProbe::Coll& c : probe.colls) {
+      const double t = dist_ms(c.a, c.b);
+      tm.dist_chol_comm_bytes += c.bytes;
+      tm.dist_chol_comm_ms += t;
+      if (c.group >= 0) chain_comm[(size_t)c.group] += t;
+    }
+    std::vector<bool> seen(chain_comm.size(), false);
+    for (const DistProbe::Wait& w : probe.waits) {
+      const double t = dist_ms(w.arrive, w.release);
+      if (w.kind == 0) {
+        tm.dist_chol_main_wait_ms += t;
+      } else {
+        tm.dist_chol_bulk_wait_ms += t;
+        if (w.group >= 0) {
+          tm.dist_chol_comm_exposed_ms += std::min(t, chain_comm[(size_t)w.group]);
+          seen[(size_t)w.group] = true;
+        }
+      }
+    }
+    // chains with no update behind them (a matrix of a single panel): nothing could hide their collectives
+    for (size_t g = 0; g < chain_comm.size(); ++g)
+      if (!seen[g]) tm.dist_chol_comm_exposed_ms += chain_comm[g];
   }
   // every rank factored every diagonal square itself: log-det and the failure index are already global and
   // identical on all ranks (same kernels on the same bits) -- no reduction
@@ -288,106 +453,141 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
 constexpr int DIST_INV_CHUNK = 32;  // block columns of U = L^-T per pipeline stage (4096 columns)
 
 int dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
-  int rc = require_ready(e, true);
+  int rc = dist_check_comm(e, comm);
   if (rc) return rc;
-  if ((rc = dist_check_comm(e, comm))) return rc;
-  if (!nlml) return fail(e, GMB_EINVAL, "nlml output pointer is null");
-  *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
-  if (!grad) return GMB_OK;
-  if (e->factor_consumed) return fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
-  HIP_TRY(e, hipSetDevice(e->device));
+  if (!grad) {  // no collective: the value is replicated
+    if ((rc = require_ready(e, true))) return rc;
+    if (!nlml) return fail(e, GMB_EINVAL, "nlml output pointer is null");
+    *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
+    return GMB_OK;
+  }
   const int G = comm->world, rank = comm->rank;
+  // ---- local checks and every allocation first, then the ranks agree ----
+  rc = require_ready(e, true);
+  if (!rc && !nlml) rc = fail(e, GMB_EINVAL, "nlml output pointer is null");
+  if (!rc && e->factor_consumed) rc = fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
+  if (!rc && hipSetDevice(e->device) != hipSuccess) rc = fail(e, GMB_EHIP, "hipSetDevice(%d) failed", e->device);
   const int nt = (int)(e->Np / TILE);
-  int first, owned;
+  int first = 0, owned = 0;
   dist_owned(rank, G, 0, nt, &first, &owned);
   const int maxown = dist_max_owned(G, 0, nt);
   const int64_t ldv = (int64_t)maxown * TILE;
-  gmb_timings& tm = e->tm;
-  tm.grad_ms = tm.grad_gemm_ms = tm.grad_gemm_flops = 0.0;
-  // V = this rank's block rows of U (later: of Sigma^-1), (maxown * 128) x Np column-major
-  if ((rc = ensure(e, &e->dW, &e->cap_W, ldv * e->Np))) return rc;
-  if ((rc = grad_workspace(e))) return rc;
-  const int cw = std::min(DIST_INV_CHUNK, nt);
+  const int cw = std::min(DIST_INV_CHUNK, std::max(nt, 1));
   const int64_t chunk_elems = (int64_t)maxown * TILE * (int64_t)cw * TILE;
   const int64_t send_need = std::max<int64_t>(chunk_elems + ldv, GACC_DOUBLES);  // [chunk | this rank's alpha rows]
-  if ((rc = ensure(e, &e->dsend, &e->cap_send, send_need))) return rc;
-  if ((rc = ensure(e, &e->drecv, &e->cap_recv, send_need * G))) return rc;
+  // V = this rank's block rows of U (later: of Sigma^-1), (maxown * 128) x Np column-major
+  if (!rc) rc = ensure(e, &e->dW, &e->cap_W, ldv * e->Np);
+  if (!rc) rc = grad_workspace(e);
+  if (!rc) rc = ensure(e, &e->dsend, &e->cap_send, send_need);
+  if (!rc) rc = ensure(e, &e->drecv, &e->cap_recv, send_need * G);
+  if ((rc = dist_agree(e, comm, rc, "gmb_dist_nlml (set-up)"))) return rc;
+  *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
+  gmb_timings& tm = e->tm;
+  tm.grad_ms = tm.grad_gemm_ms = tm.grad_gemm_flops = 0.0;
   double* V = e->dW;
   hipStream_t mainS = e->stream, commS = e->aux[0];
   PhaseTimer tg(e);
   e->sync_next = 0;
+  e->time_next = 0;
   e->cur = mainS;
   e->factor_consumed = true;  // the upper triangle (and the diagonal squares) of the factor buffer become U
-  HIP_TRY(e, hipMemsetAsync(V, 0, (size_t)ldv * e->Np * sizeof(double), mainS));
-  if (owned > 0) hipLaunchKernelGGL(identity_rows_kernel, dim3(owned), dim3(TILE), 0, mainS, V, ldv, first, G);
-  HIP_TRY(e, hipGetLastError());
-  if ((rc = order_after(e, mainS, commS))) return rc;
+  DistDeferred bad;
+  DistProbe probe;
+  auto hip_ok = [&](hipError_t st, const char* what) {
+    if (st != hipSuccess) bad.note(e, fail(e, GMB_EHIP, "%s failed: %s", what, hipGetErrorString(st)));
+  };
+  hip_ok(hipMemsetAsync(V, 0, (size_t)ldv * e->Np * sizeof(double), mainS), "hipMemsetAsync");
+  if (!bad.rc && owned > 0) {
+    hipLaunchKernelGGL(identity_rows_kernel, dim3(owned), dim3(TILE), 0, mainS, V, ldv, first, G);
+    hip_ok(hipGetLastError(), "identity_rows_kernel");
+  }
+  bad.note(e, order_after(e, mainS, commS));
   for (int k0 = 0; k0 < nt; k0 += cw) {
     const int k1 = std::min(k0 + cw, nt);
     // rows of U with a non-zero in these columns: block rows b < k1, a prefix of the packed rows
     int f2, mine;
     dist_owned(rank, G, 0, k1, &f2, &mine);
     const int mc = dist_max_owned(G, 0, k1);
-    if (mine > 0 && (rc = trsm_cols(e, V, ldv, mine, k0, k1, 4, 6, first, G))) return rc;
-    if ((rc = order_after(e, mainS, commS))) return rc;  // the chunk is final
-    if (mine > 0) {
-      if (k1 < nt) {  // right-looking: V[:, k1:] -= V[:, k0:k1] L[k1:, k0:k1]^T, structural zeros skipped
-        GemmArgs g{};
-        g.C = V + (int64_t)k1 * TILE * ldv;
-        g.ldc = ldv;
-        g.A = e->dA + (int64_t)k1 * TILE + (int64_t)k0 * TILE * e->ld;
-        g.lda = e->ld;
-        g.B = V + (int64_t)k0 * TILE * ldv;
-        g.ldb = ldv;
-        g.mt = nt - k1;
-        g.nt = mine;
-        g.k = (k1 - k0) * TILE;
-        g.alpha = -1.0;
-        g.beta = 1.0;
-        g.klo_n = 1;
-        g.krow_stride = G;
-        g.krow_off = (first - k0) * TILE;
-        if ((rc = launch_gemm(e, g, 4))) return rc;
-      }
+    if (!bad.rc && mine > 0) bad.note(e, trsm_cols(e, V, ldv, mine, k0, k1, 4, 6, first, G));
+    bad.note(e, order_after(e, mainS, commS));  // the chunk is final
+    if (!bad.rc && mine > 0 && k1 < nt) {  // right-looking: V[:, k1:] -= V[:, k0:k1] L[k1:, k0:k1]^T, structural zeros skipped
+      GemmArgs g{};
+      g.C = V + (int64_t)k1 * TILE * ldv;
+      g.ldc = ldv;
+      g.A = e->dA + (int64_t)k1 * TILE + (int64_t)k0 * TILE * e->ld;
+      g.lda = e->ld;
+      g.B = V + (int64_t)k0 * TILE * ldv;
+      g.ldb = ldv;
+      g.mt = nt - k1;
+      g.nt = mine;
+      g.k = (k1 - k0) * TILE;
+      g.alpha = -1.0;
+      g.beta = 1.0;
+      g.klo_n = 1;
+      g.krow_stride = G;
+      g.krow_off = (first - k0) * TILE;
+      bad.note(e, launch_gemm(e, g, 4));
     }
     // ship the finished chunk while the update above runs (it only READS the chunk, and the unpack writes
     // rows < k1 of the factor buffer's chunk columns, the update reads rows >= k1 of them): rows b < k1 of
     // columns [k0, k1) go into the upper triangle of every rank's factor buffer
     const int ncols = (k1 - k0) * TILE;
     const int64_t ldp = (int64_t)mc * TILE, elems = ldp * ncols;
-    if ((rc = dist_pack(e, commS, V + (int64_t)k0 * TILE * ldv, ldv, e->dsend, ldp, 0, ncols, true, 0, 0, mine, 1, 0, 0, mc))) return rc;
-    if ((rc = dist_all_gather(e, comm, commS, e->dsend, e->drecv, elems))) return rc;
-    if ((rc = dist_pack(e, commS, e->dA + (int64_t)k0 * TILE * e->ld, e->ld, e->drecv, ldp, elems, ncols, false, G, 0, 0, G, 0, k1, mc))) return rc;
+    if (!bad.rc) bad.note(e, dist_pack(e, commS, V + (int64_t)k0 * TILE * ldv, ldv, e->dsend, ldp, 0, ncols, true, 0, 0, mine, 1, 0, 0, mc));
+    bad.note(e, dist_all_gather(e, comm, commS, e->dsend, e->drecv, elems, &probe));  // issued whatever happened above
+    if (!bad.rc) bad.note(e, dist_pack(e, commS, e->dA + (int64_t)k0 * TILE * e->ld, e->ld, e->drecv, ldp, elems, ncols, false, G, 0, 0, G, 0, k1, mc));
   }
   // alpha = U v: this rank's rows, then everybody's
-  if (owned > 0)
+  if (!bad.rc && owned > 0) {
     hipLaunchKernelGGL(urows_v_kernel, dim3(owned * 2), dim3(256), 0, mainS, V, ldv, e->dv, e->N, e->dsend + chunk_elems);
-  HIP_TRY(e, hipGetLastError());
-  if ((rc = order_after(e, mainS, commS))) return rc;
+    hip_ok(hipGetLastError(), "urows_v_kernel");
+  }
+  bad.note(e, order_after(e, mainS, commS));
   {
     double* a_send = e->dsend + chunk_elems;  // behind the chunk staging area (a chunk may still be in flight)
     double* a_recv = e->drecv;
     // the comm stream is strictly ordered: by the time this all-gather runs every chunk has been unpacked
-    if ((rc = dist_all_gather(e, comm, commS, a_send, a_recv, ldv))) return rc;
-    if ((rc = dist_pack(e, commS, e->dalpha, e->Np, a_recv, ldv, ldv, 1, false, G, 0, 0, G, 0, nt, maxown))) return rc;
+    bad.note(e, dist_all_gather(e, comm, commS, a_send, a_recv, ldv, &probe));
+    if (!bad.rc) bad.note(e, dist_pack(e, commS, e->dalpha, e->Np, a_recv, ldv, ldv, 1, false, G, 0, 0, G, 0, nt, maxown));
   }
-  if ((rc = order_after(e, commS, mainS))) return rc;
-  if (e->Np > e->N)
+  bad.note(e, dist_wait(e, commS, mainS, &probe, 2));
+  if (!bad.rc && e->Np > e->N) {
     hipLaunchKernelGGL(reset_pad_cols_kernel, dim3((unsigned)((e->Np + 255) / 256)), dim3(256), 0, mainS, e->dA, e->ld, e->N, e->Np);
-  HIP_TRY(e, hipGetLastError());
+    hip_ok(hipGetLastError(), "reset_pad_cols_kernel");
+  }
   // this rank's block rows of Sigma^-1 = U U^T, packed, into the buffer V occupied; reductions over them
-  if ((rc = grad_sigma_inv_rows(e, rank, G, e->dW, ldv, true))) return rc;
   std::vector<double> h;
-  if ((rc = grad_reduce(e, rank, G, e->dW, ldv, true, h))) return rc;
+  if (!bad.rc) bad.note(e, grad_sigma_inv_rows(e, rank, G, e->dW, ldv, true));
+  if (!bad.rc) bad.note(e, grad_reduce(e, rank, G, e->dW, ldv, true, h));
   // accumulators of all ranks, summed in rank order on every rank (bit-identical results everywhere)
-  HIP_TRY(e, hipMemcpyAsync(e->dsend, e->dgpart, GACC_DOUBLES * sizeof(double), hipMemcpyDeviceToDevice, mainS));
-  if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, GACC_DOUBLES))) return rc;
+  if (!bad.rc) hip_ok(hipMemcpyAsync(e->dsend, e->dgpart, GACC_DOUBLES * sizeof(double), hipMemcpyDeviceToDevice, mainS), "hipMemcpyAsync");
+  bad.note(e, dist_all_gather(e, comm, mainS, e->dsend, e->drecv, GACC_DOUBLES, &probe, true));
   std::vector<double> all((size_t)G * GACC_DOUBLES);
-  HIP_TRY(e, hipMemcpyAsync(all.data(), e->drecv, all.size() * sizeof(double), hipMemcpyDeviceToHost, mainS));
+  if (!bad.rc) hip_ok(hipMemcpyAsync(all.data(), e->drecv, all.size() * sizeof(double), hipMemcpyDeviceToHost, mainS), "hipMemcpyAsync");
   tg.stop();
-  HIP_TRY(e, hipStreamSynchronize(mainS));
+  rc = dist_agree(e, comm, bad.give(e), "gmb_dist_nlml");  // synchronises the main stream
+  if (rc) {
+    (void)hipStreamSynchronize(commS);
+    e->evs.clear();
+    return rc;
+  }
   tm.grad_ms = tg.ms();
   ev_collect(e);
+  {
+    tm.dist_world = G;
+    tm.dist_grad_collectives = (int64_t)probe.colls.size();
+    tm.dist_grad_comm_bytes = tm.dist_grad_comm_ms = tm.dist_grad_comm_exposed_ms = 0.0;
+    double on_comm_stream = 0.0;
+    for (const DistProbe::Coll& c : probe.colls) {
+      const double t = dist_ms(c.a, c.b);
+      tm.dist_grad_comm_bytes += c.bytes;
+      tm.dist_grad_comm_ms += t;
+      if (c.exposed) tm.dist_grad_comm_exposed_ms += t;
+      else on_comm_stream += t;
+    }
+    for (const DistProbe::Wait& w : probe.waits)
+      if (w.kind == 2) tm.dist_grad_comm_exposed_ms += std::min(dist_ms(w.arrive, w.release), on_comm_stream);
+  }
   e->have_alpha = true;
   h.assign(GACC_DOUBLES, 0.0);
   for (int q = 0; q < G; ++q)
@@ -398,31 +598,36 @@ int dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
 // ---- prediction: test points sharded over the ranks, results all-gathered -------------------------------
 int dist_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M, int64_t ldxs, int32_t with_noise,
                  double* mean, double* var, int32_t memspace) {
-  int rc = require_ready(e, true);
+  int rc = dist_check_comm(e, comm);
   if (rc) return rc;
-  if ((rc = dist_check_comm(e, comm))) return rc;
-  if (M < 0 || (M > 0 && (!Xs || !mean || !var)) || ldxs < e->D) return fail(e, GMB_EINVAL, "bad Xs/M/ldxs/mean/var");
-  if (M == 0) return GMB_OK;
-  HIP_TRY(e, hipSetDevice(e->device));
   const int G = comm->world, rank = comm->rank;
+  rc = require_ready(e, true);
+  if (!rc && (M < 0 || (M > 0 && (!Xs || !mean || !var)) || ldxs < e->D)) rc = fail(e, GMB_EINVAL, "bad Xs/M/ldxs/mean/var");
+  if (!rc && hipSetDevice(e->device) != hipSuccess) rc = fail(e, GMB_EHIP, "hipSetDevice(%d) failed", e->device);
   auto bound = [&](int q) { return (int64_t)((double)M * q / G); };
   int64_t width = 0;
-  for (int q = 0; q < G; ++q) width = std::max(width, bound(q + 1) - bound(q));
-  const int64_t lo = bound(rank), cnt = bound(rank + 1) - lo;
-  if ((rc = ensure(e, &e->dsend, &e->cap_send, std::max<int64_t>(2 * width, width * e->D)))) return rc;
-  if ((rc = ensure(e, &e->drecv, &e->cap_recv, std::max<int64_t>(2 * width, width * e->D) * G))) return rc;
+  for (int q = 0; q < G && M > 0; ++q) width = std::max(width, bound(q + 1) - bound(q));
+  const int64_t lo = M > 0 ? bound(rank) : 0, cnt = M > 0 ? bound(rank + 1) - lo : 0;
+  const int64_t stage = std::max<int64_t>(std::max<int64_t>(2 * width, width * std::max(e->D, 1)), 1);
+  if (!rc) rc = ensure(e, &e->dsend, &e->cap_send, stage);
+  if (!rc) rc = ensure(e, &e->drecv, &e->cap_recv, stage * G);
+  if ((rc = dist_agree(e, comm, rc, "gmb_dist_predict (set-up)"))) return rc;
+  if (M == 0) return GMB_OK;  // the same M on every rank by contract
+  DistDeferred bad;
   if (cnt > 0) {
     const double* xs_dev = Xs + lo * ldxs;
     int64_t ld_dev = ldxs;
     if (memspace != GMB_DEVICE) {  // stage this rank's slice (results stay on the device for the all-gather)
-      HIP_TRY(e, hipMemcpy2DAsync(e->drecv, e->D * sizeof(double), Xs + lo * ldxs, ldxs * sizeof(double),
-                                  e->D * sizeof(double), cnt, hipMemcpyHostToDevice, e->stream));
+      const hipError_t st = hipMemcpy2DAsync(e->drecv, e->D * sizeof(double), Xs + lo * ldxs, ldxs * sizeof(double),
+                                             e->D * sizeof(double), cnt, hipMemcpyHostToDevice, e->stream);
+      if (st != hipSuccess) bad.note(e, fail(e, GMB_EHIP, "hipMemcpy2DAsync failed: %s", hipGetErrorString(st)));
       xs_dev = e->drecv;
       ld_dev = e->D;
     }
-    if ((rc = gmb_predict(e, xs_dev, cnt, ld_dev, with_noise, e->dsend, e->dsend + width, GMB_DEVICE))) return rc;
+    if (!bad.rc) bad.note(e, gmb_predict(e, xs_dev, cnt, ld_dev, with_noise, e->dsend, e->dsend + width, GMB_DEVICE));
   }
-  if ((rc = dist_all_gather(e, comm, e->stream, e->dsend, e->drecv, 2 * width))) return rc;
+  bad.note(e, dist_all_gather(e, comm, e->stream, e->dsend, e->drecv, 2 * width));
+  if ((rc = dist_agree(e, comm, bad.give(e), "gmb_dist_predict"))) return rc;
   const hipMemcpyKind kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   for (int q = 0; q < G; ++q) {
     const int64_t lq = bound(q), cq = bound(q + 1) - lq;
@@ -442,6 +647,7 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
 };
 
 std::string g_rccl_error;
@@ -466,6 +672,7 @@ RcclApi* rccl_api(const char* path) {
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
   a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
   if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather) {
     g_rccl_error = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
     return nullptr;
@@ -556,6 +763,14 @@ int gmb_rccl_comm_create(gmb_comm** out, const char* librccl_path, const void* i
   c->all_gather = rccl_all_gather;
   *out = c;
   return GMB_OK;
+}
+
+int gmb_rccl_comm_ranks(const gmb_comm* c) {
+  if (!c || !c->ctx || c->all_gather != rccl_all_gather) return GMB_EINVAL;
+  const RcclCtx* ctx = (const RcclCtx*)c->ctx;
+  int n = 0;
+  if (!ctx->api->CommCount || ctx->api->CommCount(ctx->comm, &n) != ncclSuccess) return GMB_EHIP;
+  return n;
 }
 
 void gmb_rccl_comm_destroy(gmb_comm* c) {

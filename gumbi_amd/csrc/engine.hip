@@ -38,6 +38,8 @@ using namespace gmb;
 
 namespace {
 
+constexpr int DIST_MAX_WORLD = 64;  // ranks one GP can be spread over (status words of gmb_dist_*)
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 struct EventPair {
@@ -177,6 +179,9 @@ struct gmb_engine {
   int64_t cap_send = 0, cap_recv = 0;
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
+  double* dstat = nullptr;  // status words the ranks exchange: [0] this rank's, [8 .. 8 + world) everybody's
+  std::vector<hipEvent_t> time_pool;  // timing events of the multi-GPU driver's communication probes
+  size_t time_next = 0;
 };
 
 namespace {
@@ -783,6 +788,14 @@ hipEvent_t next_sync_event(gmb_engine* e) {
     e->sync_pool.push_back(ev);
   }
   return e->sync_pool[e->sync_next++];
+}
+hipEvent_t next_time_event(gmb_engine* e) {  // timing-enabled, reused from call to call
+  if (e->time_next == e->time_pool.size()) {
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    e->time_pool.push_back(ev);
+  }
+  return e->time_pool[e->time_next++];
 }
 // everything enqueued on `from` so far happens before anything enqueued on `to` from now on
 int order_after(gmb_engine* e, hipStream_t from, hipStream_t to) {
@@ -1509,6 +1522,7 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->wg_slots = 2LL * prop.multiProcessorCount;
   if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&e->dstat, (8 + DIST_MAX_WORLD) * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
     gmb_destroy(e);
     return GMB_ENOMEM;
@@ -1548,7 +1562,7 @@ void gmb_destroy(gmb_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (int a = 0; a < 3; ++a)
     if (e->aux[a]) (void)hipStreamSynchronize(e->aux[a]);
-  void* ptrs[] = {e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
+  void* ptrs[] = {e->dstat, e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv, e->dV, e->dXs, e->txs, e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart};
   for (void* p : ptrs)
@@ -1556,6 +1570,7 @@ void gmb_destroy(gmb_engine* e) {
   for (int a = 0; a < 3; ++a)
     if (e->aux[a] && !e->aux_borrowed && !(a == 2 && e->aux_shared)) (void)hipStreamDestroy(e->aux[a]);
   for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
+  for (auto ev : e->time_pool) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }

@@ -93,6 +93,11 @@ class RcclComm:
     def handle(self):
         return self._comm
 
+    @property
+    def ranks(self) -> int:
+        """``ncclCommCount`` of the communicator: the rank count RCCL itself reports."""
+        return int(self._lib.gmb_rccl_comm_ranks(self._comm))
+
     def close(self):
         if getattr(self, "_comm", None):
             self._lib.gmb_rccl_comm_destroy(self._comm)

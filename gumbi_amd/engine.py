@@ -82,6 +82,18 @@ class Timings(C.Structure):
         ("total_chol_gemm_wall_ms", C.c_double),
         ("total_chol_panel_gemm_ms", C.c_double),
         ("total_chol_panel_gemm_flops", C.c_double),
+        # multi-GPU driver: communication probes of the last gmb_dist_factorize / gmb_dist_nlml (this rank)
+        ("dist_world", C.c_int64),
+        ("dist_chol_collectives", C.c_int64),
+        ("dist_chol_comm_bytes", C.c_double),
+        ("dist_chol_comm_ms", C.c_double),
+        ("dist_chol_comm_exposed_ms", C.c_double),
+        ("dist_chol_main_wait_ms", C.c_double),
+        ("dist_chol_bulk_wait_ms", C.c_double),
+        ("dist_grad_collectives", C.c_int64),
+        ("dist_grad_comm_bytes", C.c_double),
+        ("dist_grad_comm_ms", C.c_double),
+        ("dist_grad_comm_exposed_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -219,6 +231,7 @@ _SIGNATURES = {
     "gmb_rccl_comm_create": (C.c_int, [C.POINTER(C.POINTER(GmbComm)), C.c_char_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32]),
     "gmb_rccl_comm_destroy": (None, [C.POINTER(GmbComm)]),
+    "gmb_rccl_comm_ranks": (C.c_int, [C.POINTER(GmbComm)]),
     "gmb_rccl_last_error": (C.c_char_p, []),
     "gmb_dist_plan": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(DistStep), C.c_int64]),
     "gmb_dist_factorize": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), C.c_int32]),
@@ -266,8 +279,9 @@ def _preload_hip_runtime():
 
 #: GMB_ABI_VERSION of include/gumbi_hip.h this binding was written against (the layout of
 #: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3; version 4 replaced the block-level
-#: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``, ``gmb_set_y`` and ``gmb_create_sibling``)
-ABI_VERSION = 5
+#: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``, ``gmb_set_y`` and ``gmb_create_sibling``;
+#: version 6 the communication fields of ``gmb_timings`` and ``gmb_rccl_comm_ranks``)
+ABI_VERSION = 6
 
 
 def load_library():
@@ -313,7 +327,8 @@ class Engine:
     def __init__(self, device: int = 0, stream: int | None = None, sibling_of: "Engine | None" = None):
         self._lib = load_library()
         self._h = C.c_void_p()
-        if sibling_of is not None:  # borrows that engine's HIP streams (gmb_create_sibling); close it first
+        self._peer = sibling_of  # a sibling borrows the peer's HIP streams: the peer must outlive it
+        if sibling_of is not None:  # gmb_create_sibling; close the sibling first
             rc = self._lib.gmb_create_sibling(C.byref(self._h), sibling_of._h)
         else:
             rc = self._lib.gmb_create(C.byref(self._h), int(device), C.c_void_p(stream) if stream else None)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 5
+#define GMB_ABI_VERSION 6
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -125,6 +125,29 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
   double total_chol_gemm_wall_ms; /* union of their launch intervals */
   double total_chol_panel_gemm_ms;
   double total_chol_panel_gemm_flops;
+  /* multi-GPU driver (gmb_dist_*), this rank, HIP events around every collective and at every stream join.
+     chol_*: the last gmb_dist_factorize; grad_*: the last gmb_dist_nlml with a gradient.
+       comm_ms         sum over the all-gathers of (stream reached the collective -> collective complete):
+                       transfer time plus the wait for the slowest peer
+       comm_exposed_ms the part of comm_ms that nothing hid.  Factorisation: per panel, min(time the bulk
+                       stream sat idle waiting for the panel chain, time that chain spent in its two
+                       all-gathers) -- the first chain has nothing to hide behind and counts in full.
+                       Gradient: the main stream's wait for the communication stream after the last chunk
+                       plus the two small all-gathers (alpha, accumulators) that sit on the main stream
+       main_wait_ms    main stream waiting for the bulk stream at the JOINs (trailing update U2 longer than
+                       the next panel's chain: communication fully hidden there)
+       bulk_wait_ms    bulk stream waiting for the main stream at the FORKs (chain-bound time)          */
+  int64_t dist_world;             /* ranks of the communicator the last gmb_dist_* call ran on            */
+  int64_t dist_chol_collectives;
+  double dist_chol_comm_bytes;    /* bytes received from the other ranks                                  */
+  double dist_chol_comm_ms;
+  double dist_chol_comm_exposed_ms;
+  double dist_chol_main_wait_ms;
+  double dist_chol_bulk_wait_ms;
+  int64_t dist_grad_collectives;
+  double dist_grad_comm_bytes;
+  double dist_grad_comm_ms;
+  double dist_grad_comm_exposed_ms;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;
@@ -280,6 +303,7 @@ int gmb_rccl_unique_id(const char* librccl_path, void* id128);  /* rank 0: 128 b
 int gmb_rccl_comm_create(gmb_comm** out, const char* librccl_path, const void* id128, int32_t rank,
                          int32_t world, int32_t device);         /* collective: ncclCommInitRank          */
 void gmb_rccl_comm_destroy(gmb_comm* c);
+int gmb_rccl_comm_ranks(const gmb_comm* c); /* ncclCommCount of the communicator (what RCCL itself reports) */
 const char* gmb_rccl_last_error(void);
 
 /* The schedule one rank executes, as data (host-only, no device needed): step kinds

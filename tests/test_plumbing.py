@@ -337,3 +337,44 @@ def test_parse_ls_limits_edge_cases():
     assert lo == [0.2, 0.7] and up == [2.0, 2.0]
     with pytest.raises(ValueError):
         parse_ls_limits(X, ARD=True, lower=[0.1, 0.2, 0.3])
+
+
+# ---------------------------------------------------------------------------- ls_bounds helper
+DELTA_CASES = {  # as in tests/golden/make_deltas_goldens.py (captured from the reference's make_deltas_parray)
+    "standardized_XY": ("standardized", {"X": [0.5, None], "Y": [0.25, 6.0]}),
+    "natural_log_logit": ("natural", {"Y": [20.0, None], "X": [0.05, 0.3], "d": [None, 0.5]}),
+    "transformed_mix": ("transformed", {"X": [0.2, 1.5], "Y": [0.1, 2.0], "d": [0.5, 3.0]}),
+    "standardized_plain": ("standardized", {"lg10_Z": [0.5, 3.0], "a": [None, 2.0]}),
+}
+
+
+@pytest.mark.parametrize("case", sorted(DELTA_CASES))
+def test_make_deltas_parray_matches_reference(case):
+    """``make_deltas_parray`` (reference gumbi/array_utils.py:8-33) and the bounds that reach the lengthscale
+    prior through ``_prepare_lengthscales`` -> ``parse_ls_limits`` (pymc/GP.py:630-650, gp_utils.py:15-48)."""
+    from gumbi_amd.array_utils import make_deltas_parray
+
+    gold = np.load(GOLD / "deltas_goldens.npz")
+    scale, deltas = DELTA_CASES[case]
+    pa = make_deltas_parray(stdzr=make_stdzr(), scale=scale, **deltas)
+    assert tuple(pa.shape) == tuple(gold[f"{case}/shape"])
+    for dim in deltas:
+        np.testing.assert_allclose(np.asarray(pa[dim].values(), float), gold[f"{case}/{dim}"], rtol=1e-12, equal_nan=True)
+    zb = [[None if np.isnan(b) else float(b) for b in np.atleast_1d(pa[dim].z.values().squeeze())] for dim in deltas]
+    lower, upper = (list(t) for t in zip(*zb))
+    lo, up = parse_ls_limits(gold["points"][:, : len(deltas)], ARD=True, lower=lower, upper=upper)
+    np.testing.assert_allclose(lo, gold[f"{case}/ls_lower"], rtol=1e-12)
+    np.testing.assert_allclose(up, gold[f"{case}/ls_upper"], rtol=1e-12)
+
+
+def test_make_deltas_parray_natural_scale_of_plain_variables():
+    """The reference raises a TypeError for natural- / transformed-scale deltas of UNtransformed variables
+    (a list minus a float in aggregation.py:393); here they mean what the docstring promises: delta / sigma."""
+    from gumbi_amd.array_utils import make_deltas_parray
+
+    pa = make_deltas_parray(stdzr=make_stdzr(), scale="natural", a=[0.3, 4.0], lg10_Z=[None, 5.0])
+    np.testing.assert_allclose(pa["a"].z.values().squeeze(), [0.3 / 1.258, 4.0 / 1.258], rtol=1e-12)
+    z = pa["lg10_Z"].z.values().squeeze()
+    assert np.isnan(z[0]) and abs(z[1] - 2.5) < 1e-12
+    with pytest.raises(ValueError):
+        make_deltas_parray(stdzr=make_stdzr(), scale="zscore", a=[0.3, 4.0])
