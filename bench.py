@@ -7,25 +7,40 @@ One GPU (default; BASELINE.json configs[2] = C3, the largest single-GPU configur
 Matern-5/2 ARD, M = 10^4 grid).  A *step* is one pass of the hot path the reference reaches through
 ``gp.fit()`` + ``gp.predict_grid()``, inputs already resident in HBM:
 
-    find_MAP  -- L-BFGS-B on -(log-lik + log-priors); every objective / gradient evaluation = covariance
-                 build -> Cholesky -> v = L^-1 y, log-det -> L^-T, Sigma^-1, fused trace reductions
-    refactor at the MAP, predict mean / variance on the M-point grid                (all in libgumbi_hip.so)
+    find_MAP  -- L-BFGS-B on -(log-lik + log-priors) TO CONVERGENCE (scipy defaults, what pm.find_MAP runs);
+                 every objective / gradient evaluation = covariance build -> Cholesky -> v = L^-1 y, log-det
+                 -> L^-T, Sigma^-1, fused trace reductions
+    predict   -- mean / variance on the M-point grid against the resident factor     (all in libgumbi_hip.so)
 
-``value`` = algorithmic GFLOP/s of the whole step; ``ms_per_step`` = fit + predict wall time.  The same JSON
-line carries: ``roofline`` (the Cholesky's trailing-update SYRK/GEMM launches alone -- the kernel the north
-star's MFMA target is stated on -- from per-launch HIP events of one extra step, plus the same figure over
-every GEMM launch), ``kbuild`` (HBM GB/s of the covariance build), ``phases``, ``end_to_end`` (the user-level
-``DataSet -> GP.fit() -> prepare_grid() -> predict_grid()`` wall time, host transfers included),
-``c5_single_gpu`` (the N = 100k problem of the multi-GPU runs on this one GPU: their strong-scaling base) and
-``cpu_baseline`` (the oracle on a bounded sample on the host cores).
+The model is declared as a Gumbi user who knows the scale of the inputs would: ``ls_bounds`` (the reference's own
+knob, pymc/GP.py:630-650, built with ``make_deltas_parray``) says "length scales of at least LS_LOWER_Z standard
+deviations".  With the PyMC DEFAULTS the lengthscale prior comes from the smallest pairwise gap (0.01 at these
+N), L-BFGS-B starts at l = 0.023 where K = I and -- at C3 -- stops after 8 evaluations on that white-noise
+plateau having learnt nothing; that run is kept as the side figure ``default_start``.
+``fit_quality`` says what the timed fits found: RMSE / correlation of the grid mean against the generator's
+noise-free f, sigma-hat against the generator's, the final NLML, evaluations, scipy's convergence flag.
+
+``value`` = algorithmic GFLOP/s of the whole step; ``ms_per_step`` = fit + predict wall time.  Warm-up steps run
+the same code path with the evaluation budget capped at WARMUP_EVALS (they are untimed; a full fit is ~30
+evaluations = 55 s at C3).  The same JSON line carries ``roofline`` (the Cholesky's trailing-update SYRK/GEMM
+launches alone -- the kernel the north star's MFMA target is stated on -- from per-launch HIP events of a few
+profiled evaluations after the timed region, plus the same figure over every GEMM launch, plus the register-only
+MFMA ceiling sampled for >= 1 s BEFORE and AFTER the timed region), ``kbuild`` (HBM GB/s of the covariance build),
+``phases``, ``cpu_baseline`` (the oracle on a bounded sample on the host cores) and, while the time budget
+(GUMBI_BENCH_BUDGET_S, default 1500 s of process time) allows, ``strong_scaling_base_gflops`` / ``c5_single_gpu``
+(the N = 100k problem of the multi-GPU runs on this one GPU), ``default_start`` and ``end_to_end`` (the user-level
+``DataSet -> GP.fit() -> prepare_grid() -> predict_grid()`` wall time, host transfers included).
 
 Several GPUs (``--gpus N``, launched by torch.distributed.run, one rank per GPU): ONE GP -- BASELINE.json
 configs[4] = C5, N = 100k, d = 8, RBF-ARD -- factored block-cyclically over all ranks by the native driver
-(gumbi_amd/csrc/dist_driver.hpp; all-gathers on RCCL over xGMI), hyper-parameters fixed.  A step = one MAP
-objective + gradient evaluation (factorise + row-partitioned gradient) + re-factorisation (``fit`` at fixed
-theta) + prediction of the 10^4 grid sharded over the ranks; the three parts are reported separately under
-``phases``; ``scaling`` is "strong" (the same problem at every N; ``python bench.py --config c5`` is its N = 1
-point).  The barrier / max-over-ranks timing contract is the same.
+(gumbi_amd/csrc/dist_driver.hpp; all-gathers on RCCL over xGMI).  Default: hyper-parameters fixed, a step = one
+MAP objective + gradient evaluation (factorise + row-partitioned gradient) + re-factorisation (``fit`` at fixed
+theta) + prediction of the 10^4 grid sharded over the ranks.  ``--map-evals k``: a step = a distributed
+``GP(distributed=True).find_MAP(maxeval=k)`` from the same declared model + the grid prediction.  ``scaling`` is
+"strong" (the same problem at every N); the line carries ``comm`` (transport, rank count as RCCL reports it,
+per-phase collective time and how much of it nothing hid -- gmb_timings.dist_*) and
+``strong_scaling_base_gflops``: the same step on ONE GPU of the same node, run by rank 0 after the timed region.
+The barrier / max-over-ranks timing contract is the same.
 """
 import argparse
 import json
@@ -42,6 +57,11 @@ import numpy as np  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet (vector = matrix FP64); MI355X_MICROARCH.md lists none
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+LS_LOWER_Z = 0.5     # ls_bounds of the headline fit: length scales >= half a standard deviation of the input
+WARMUP_EVALS = 3     # evaluation budget of an (untimed) warm-up step
+PROFILE_EVALS = 4    # evaluations of the profiled pass behind `roofline` (per-launch HIP events)
+T_PROCESS_START = time.perf_counter()
 
 CONFIGS = {
     # name: (N, d, kernel, M-grid resolution)
@@ -78,6 +98,38 @@ def synthetic_grid(d, res=100, lim=2.4):
     return Xs
 
 
+def synthetic_truth(cfg):
+    """What the generator knows and the fit does not: the noise-free f on the prediction grid and the noise
+    level, both in the z-scored units of y (the units the engine works in)."""
+    N, d = cfg["N"], cfg["d"]
+    rng = np.random.default_rng(2021)
+    X = rng.standard_normal((N, d))
+    ls = np.geomspace(0.7, 2.0, d) if d > 1 else np.array([1.0])
+    y = np.sum(np.sin(X / ls), axis=1) / np.sqrt(d) + 0.2 * rng.standard_normal(N)
+    Xs = synthetic_grid(d, cfg["res"])
+    f_grid = (np.sum(np.sin(Xs / ls), axis=1) / np.sqrt(d) - y.mean()) / y.std(ddof=1)
+    return f_grid, 0.2 / y.std(ddof=1)
+
+
+def fit_quality(gp, mean, cfg):
+    """Did the fit fit?  Grid mean against the generator's f, sigma-hat against the generator's sigma."""
+    f_grid, sigma_z = synthetic_truth(cfg)
+    mean = np.asarray(mean, dtype=float)
+    res = getattr(gp, "opt_result", None)
+    sig = float(np.asarray(gp.MAP["σ"]))
+    return {
+        "corr": round(float(np.corrcoef(mean, f_grid)[0, 1]), 5) if np.std(mean) > 0 else 0.0,
+        "rmse": round(float(np.sqrt(np.mean((mean - f_grid) ** 2))), 5),
+        "rmse_of_predicting_zero": round(float(np.sqrt(np.mean(f_grid**2))), 5),
+        "sigma_hat": round(sig, 5), "sigma_true": round(float(sigma_z), 5), "sigma_rel_err": round(abs(sig / sigma_z - 1.0), 4),
+        "nlml_final": round(float(gp.nlml_trace[-1]), 3) if gp.nlml_trace else None,
+        "n_eval": int(gp.n_eval), "rejected_evals": int(gp._rejected),
+        "converged": bool(res.success) if res is not None else None,
+        "optimizer_message": (res.message if isinstance(res.message, str) else res.message.decode())[:80] if res is not None else None,
+        "ls": [round(float(v), 3) for v in np.atleast_1d(gp.MAP["ls_total"])], "eta": round(float(np.asarray(gp.MAP["η_total"])), 4),
+    }
+
+
 def make_dataset(cfg):
     import pandas as pd
 
@@ -90,15 +142,43 @@ def make_dataset(cfg):
     return gmb.DataSet(df, outputs=["y"]), cols
 
 
-def build_gp(cfg, device):
+def ls_bounds_for(ds, cols, ls_lower):
+    """``ls_bounds`` as a Gumbi user states them (make_deltas_parray, gumbi/array_utils.py:8-33): a lower limit
+    of ``ls_lower`` standard deviations on every input's length scale, the upper limit left to the default."""
+    import gumbi_amd as gmb
+
+    if not ls_lower:
+        return None  # PyMC defaults: limits from the pairwise distances (gp_utils.py:34-46)
+    return gmb.make_deltas_parray(stdzr=ds.stdzr, scale="standardized", **{c: [float(ls_lower), None] for c in cols})
+
+
+def build_gp(cfg, device, ls_lower=LS_LOWER_Z, distributed=None):
     """Front-end objects exactly as a Gumbi user builds them (DataSet -> GP -> build_model)."""
     import gumbi_amd as gmb
 
     ds, cols = make_dataset(cfg)
-    gp = gmb.GP(ds, outputs=["y"], device=device)
+    gp = gmb.GP(ds, outputs=["y"], device=device, distributed=distributed)
     gp.specify_model(continuous_dims=cols)
-    gp.build_model(continuous_kernel=cfg["kernel"])
+    gp.build_model(continuous_kernel=cfg["kernel"], ls_bounds=ls_bounds_for(ds, cols, ls_lower))
     return gp
+
+
+class Budget:
+    """Wall-clock budget of the whole process (the driver gives a run 1800 s): side sections are skipped, and
+    say so in the JSON, when starting them would overrun it; the timed steps never are."""
+
+    def __init__(self):
+        self.total = float(os.environ.get("GUMBI_BENCH_BUDGET_S", "1500"))
+
+    def used(self):
+        return time.perf_counter() - T_PROCESS_START
+
+    def allows(self, estimate_s):
+        return self.used() + estimate_s <= self.total
+
+    def skipped(self, estimate_s):
+        return {"skipped": f"time budget: {self.used():.0f} s used of {self.total:.0f} s, this section needs ~{estimate_s:.0f} s "
+                           f"(GUMBI_BENCH_BUDGET_S)"}
 
 
 def step_flops(N, M, n_eval, n_refactor=1):
@@ -130,8 +210,25 @@ def pmc_traffic(config, kernel_filter):
                 flops += float(row["MFMA_F64_TFLOPs"]) * 1e12 * float(row["TotalMs(pass1)"]) * 1e-3
     if launches == 0:
         return None
-    return {"bytes_per_launch": gbytes * 1e9 / launches, "source": os.path.relpath(files[-1], str(ROOT)), "launches": launches,
-            "flops_per_launch": flops / launches}
+    out = {"bytes_per_launch": gbytes * 1e9 / launches, "source": os.path.relpath(files[-1], str(ROOT)), "launches": launches,
+           "flops_per_launch": flops / launches, "kernel_sources_sha16_then": None, "kernel_sources_sha16_now": kernel_sources_sha16()}
+    meta = files[-1].replace("_summary.csv", "_summary.meta.json")
+    if os.path.exists(meta):  # written by tools/gpu_pmc_bench.sh: the kernel sources the counters were taken on
+        with open(meta) as fh:
+            out["kernel_sources_sha16_then"] = json.load(fh).get("kernel_sources_sha16")
+    out["stale"] = out["kernel_sources_sha16_then"] != out["kernel_sources_sha16_now"]
+    return out
+
+
+def kernel_sources_sha16():
+    """sha256 over gumbi_amd/csrc/* (sorted): ties a committed counter summary to the kernels it was taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted((ROOT / "gumbi_amd" / "csrc").glob("*.h*")):
+        h.update(path.name.encode())
+        h.update(path.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(cfg, target_seconds=20.0):
@@ -192,13 +289,15 @@ def roofline_block(tm, config):
     out = {
         "bound": "mfma",
         "kernel": "gemm_f64_kernel, the Cholesky's bulk trailing-update launches U1 / U2 (v_mfma_f64_16x16x4_f64 SYRK/GEMM)",
+        "subset_note": "achieved / frac cover ONLY the Cholesky's bulk trailing updates (the launches the north star states its "
+                       "MFMA target on); all_gemm_launches beside it covers every MFMA GEMM launch of the profiled evaluations",
         "achieved": round(chol_tf, 3),
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(chol_tf / FP64_MFMA_PEAK_TFLOPS, 4),
         "traffic": None,
-        "measured_over": "one extra step of the same workload after the timed region (per-launch HIP events on the "
-                         "launch's own stream)",
+        "measured_over": f"{PROFILE_EVALS} evaluations + one prediction of the same workload after the timed region (per-launch HIP "
+                         "events on the launch's own stream)",
         "launches": int(tm["total_chol_gemm_launches"]),
         "avg_launch_ms": round(tm["total_chol_gemm_ms"] / n_chol, 5),
         "flops_per_launch": round(tm["total_chol_gemm_flops"] / n_chol, 1),
@@ -239,6 +338,8 @@ def roofline_block(tm, config):
                                "gemm_f64_kernel instantiation over one bench step (rocprofv3 PMC passes), times this launch's flops")
         out["traffic_flop_per_byte"] = round(1.0 / bytes_per_flop, 2)
         out["traffic_source"] = pt["source"]
+        out["traffic_is_stale"] = pt["stale"]  # the counters were taken on other kernel sources than the ones running now
+        out["traffic_kernel_sources_sha16"] = {"then": pt["kernel_sources_sha16_then"], "now": pt["kernel_sources_sha16_now"]}
         out["traffic_source_per_launch"] = {"launches": pt["launches"], "bytes": round(pt["bytes_per_launch"], 1),
                                             "flops": round(pt["flops_per_launch"], 1)}
     return out
@@ -282,6 +383,8 @@ class Clock:
 def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clock):
     import torch
 
+    from gumbi_amd import engine as E
+
     t_build = time.perf_counter()
     gp = build_gp(cfg, device=local_rank)
     t_build = time.perf_counter() - t_build
@@ -295,30 +398,39 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
     torch.cuda.synchronize()
     maxeval = map_evals if map_evals > 0 else 200
 
-    def one_step():
-        gp.find_MAP(maxeval=maxeval)
+    def one_step(budget=maxeval):
+        gp.find_MAP(maxeval=budget)
         eng.predict_device(xs_dev.data_ptr(), M, cfg["d"], mean_dev.data_ptr(), var_dev.data_ptr(), True)
         return gp.n_eval, gp.n_refactor
 
     for _ in range(warmup):
-        one_step()
+        one_step(min(maxeval, WARMUP_EVALS))
+    torch.cuda.synchronize()
+    ceiling_before = E.mfma_f64_sustained(local_rank, 1.0)  # register-only MFMA loop, >= 1 s, right before the timed region
     clock.sync()
     t0 = time.perf_counter()
     counts = [one_step() for _ in range(steps)]
     n_evals = [c[0] for c in counts]
     clock.sync()
     elapsed = time.perf_counter() - t0
-    # Roofline pass: ONE more step of the same workload with a HIP event pair around every GEMM launch (on
-    # the stream it is launched on).  Kept out of the timed region: event pairs cost host time per launch.
+    ceiling_after = E.mfma_f64_sustained(local_rank, 1.0)   # ... and right after it
+    mean_host = mean_dev.cpu().numpy()
+    var_host = var_dev.cpu().numpy()
+    finite = bool(np.all(np.isfinite(mean_host)) and np.all(var_host > 0))
+    quality = fit_quality(gp, mean_host, cfg)
+    theta_fit = gp._theta_fitted.copy()
+    # Roofline pass: a few more evaluations + one prediction of the same workload with a HIP event pair around
+    # every GEMM launch (on the stream it is launched on).  Kept out of the timed region: event pairs cost host
+    # time per launch.
     eng.set_profiling(True)  # resets the totals
-    one_step()
+    one_step(min(maxeval, PROFILE_EVALS))
     torch.cuda.synchronize()
     tm = eng.timings()
     eng.set_profiling(False)
 
     # Phases of one evaluation timed separately, wall clock, unprofiled, at the
     # fitted hyper-parameters; outside the timed region.
-    def wall_ms(fn, reps=3):
+    def wall_ms(fn, reps=2):
         best = float("inf")
         for _ in range(reps):
             torch.cuda.synchronize()
@@ -332,6 +444,7 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
         eng.factorize()
         eng.nlml(grad=True)
 
+    eng.set_theta(theta_fit)
     phases = {
         "specify_plus_build_model_s": round(t_build, 3),  # DataSet -> specify_model -> build_model (ls priors, H2D copy)
         "factorize_ms": wall_ms(eng.factorize),          # K-build + Cholesky + L^-1 y + log-det
@@ -347,18 +460,37 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
         "map_evaluation": round(float(N) ** 3 / phases["factorize_plus_gradient_ms"] / 1e9, 2),
         "predict": round(float(N) ** 2 * M / phases["predict_ms"] / 1e9, 2),
     }
+    phases["at_theta"] = "the MAP of the timed fits"
     phases["profiled_last_evaluation_ms"] = {k: round(tm[k], 3) for k in
                                              ("kbuild_ms", "chol_ms", "chol_leaf_ms", "chol_trsm_ms", "chol_gemm_ms",
                                               "grad_ms", "grad_gemm_ms", "predict_ms", "predict_gemm_ms")}
-    mean_host = mean_dev.cpu().numpy()
-    var_host = var_dev.cpu().numpy()
-    finite = bool(np.all(np.isfinite(mean_host)) and np.all(var_host > 0))
     # the engine's streams go away before any other section creates its own: more than four live HIP
     # streams per process slow every kernel down on this stack
     eng.close()
     gp.engine = None
     return dict(elapsed=elapsed, n_evals=n_evals, n_refactor=[c[1] for c in counts], M=M, tm=tm, phases=phases, finite=finite,
-                flops=sum(step_flops(N, M, n, r) for n, r in counts))
+                flops=sum(step_flops(N, M, n, r) for n, r in counts), quality=quality,
+                ceiling={"before_timed_region": ceiling_before, "after_timed_region": ceiling_after})
+
+
+def default_start_fit(cfg, local_rank):
+    """Side figure: the same table fitted with the reference's DEFAULTS -- no ls_bounds, lengthscale prior from the
+    smallest pairwise gap (gp_utils.py:34-46), PyMC's initial point (the prior's mode, l = 0.023)."""
+    import torch
+
+    gp = build_gp(cfg, device=local_rank, ls_lower=None)
+    Xs = synthetic_grid(cfg["d"], cfg["res"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gp.find_MAP(maxeval=200)
+    mean, var = gp.predict(Xs)
+    dt = time.perf_counter() - t0
+    out = {"fit_predict_seconds": round(dt, 3), "start_ls": [round(float(v), 4) for v in gp._initial_theta()[: cfg["d"]]],
+           "fit_quality": fit_quality(gp, mean, cfg),
+           "note": "PyMC-default prior and start (no ls_bounds): L-BFGS-B starts where K = I; at C3 it stops there"}
+    gp.engine.close()
+    gp.engine = None
+    return out
 
 
 def end_to_end_fit(cfg, local_rank, map_evals):
@@ -370,7 +502,8 @@ def end_to_end_fit(cfg, local_rank, map_evals):
     ds, cols = make_dataset(cfg)
     t1 = time.perf_counter()
     gp = gmb.GP(ds, outputs=["y"], device=local_rank)
-    gp.fit(continuous_dims=cols, continuous_kernel=cfg["kernel"], MAP_kwargs={"maxeval": map_evals if map_evals > 0 else 200})
+    gp.fit(continuous_dims=cols, continuous_kernel=cfg["kernel"], ls_bounds=ls_bounds_for(ds, cols, LS_LOWER_Z),
+           MAP_kwargs={"maxeval": map_evals if map_evals > 0 else 200})
     t2 = time.perf_counter()
     if cfg["d"] > 2:
         gp.prepare_grid(at=gp.parray(**{c: 0.0 for c in cols[2:]}, stdzd=True), resolution=cfg["res"])
@@ -383,52 +516,106 @@ def end_to_end_fit(cfg, local_rank, map_evals):
     gp.engine = None
     return {"dataset_s": round(t1 - t0, 3), "fit_s": round(t2 - t1, 3), "prepare_and_predict_grid_s": round(t3 - t2, 3),
             "total_s": round(t3 - t0, 3), "map_evals": int(gp.n_eval), "results_finite": ok,
-            "note": "gp.fit() = specify_model + build_model + find_MAP, host <-> device transfers included"}
+            "note": "gp.fit(ls_bounds=...) = specify_model + build_model + find_MAP, host <-> device transfers included"}
 
 
 # -----------------------------------------------------------------------------------------------------
-# workload B: ONE GP at fixed hyper-parameters over `world` GPUs (C5)
+# workload B: ONE GP over `world` GPUs (C5): fixed hyper-parameters, or a distributed find_MAP(maxeval=k)
 # -----------------------------------------------------------------------------------------------------
-def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock):
+COMM_KEYS = ("dist_world", "dist_chol_collectives", "dist_chol_comm_bytes", "dist_chol_comm_ms", "dist_chol_comm_exposed_ms",
+             "dist_chol_main_wait_ms", "dist_chol_bulk_wait_ms", "dist_grad_collectives", "dist_grad_comm_bytes",
+             "dist_grad_comm_ms", "dist_grad_comm_exposed_ms")
+
+
+def comm_block(tm, eng, transport, clock):
+    """Communication of the LAST factorisation and the LAST gradient evaluation of the run (gmb_timings.dist_*): what
+    rank 0 saw, and the maximum over the ranks of the exposed part."""
+    comm = getattr(eng, "comm", None)
+    ranks = None
+    if comm is not None and hasattr(comm, "ranks"):
+        try:
+            ranks = comm.ranks
+        except Exception:
+            ranks = None
+    chol_exp, grad_exp, chol_ms, grad_ms = clock.max_over_ranks([tm["dist_chol_comm_exposed_ms"], tm["dist_grad_comm_exposed_ms"],
+                                                                  tm["dist_chol_comm_ms"], tm["dist_grad_comm_ms"]])
+    return {
+        "transport": transport, "rccl_ranks": ranks, "world": int(tm["dist_world"]),
+        "comm_ms_total": round(tm["dist_chol_comm_ms"] + tm["dist_grad_comm_ms"], 3),
+        "comm_ms_exposed": round(tm["dist_chol_comm_exposed_ms"] + tm["dist_grad_comm_exposed_ms"], 3),
+        "per": "one factorisation + one gradient evaluation (the last of the run), rank 0; *_max = maximum over the ranks",
+        "factorize": {"collectives": int(tm["dist_chol_collectives"]), "received_GB": round(tm["dist_chol_comm_bytes"] / 1e9, 3),
+                      "comm_ms": round(tm["dist_chol_comm_ms"], 3), "comm_ms_exposed": round(tm["dist_chol_comm_exposed_ms"], 3),
+                      "comm_ms_max": round(chol_ms, 3), "comm_ms_exposed_max": round(chol_exp, 3),
+                      "main_stream_wait_at_joins_ms": round(tm["dist_chol_main_wait_ms"], 3),
+                      "bulk_stream_wait_at_forks_ms": round(tm["dist_chol_bulk_wait_ms"], 3),
+                      "chol_ms": round(tm["chol_ms"], 3)},
+        "gradient": {"collectives": int(tm["dist_grad_collectives"]), "received_GB": round(tm["dist_grad_comm_bytes"] / 1e9, 3),
+                     "comm_ms": round(tm["dist_grad_comm_ms"], 3), "comm_ms_exposed": round(tm["dist_grad_comm_exposed_ms"], 3),
+                     "comm_ms_max": round(grad_ms, 3), "comm_ms_exposed_max": round(grad_exp, 3), "grad_ms": round(tm["grad_ms"], 3)},
+    }
+
+
+def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock, map_evals=0):
     import torch
 
     from gumbi_amd import engine as E
 
     N, d = cfg["N"], cfg["d"]
-    X, y, ls = synthetic_table(N, d)
     Xs = synthetic_grid(d, cfg["res"])
     M = len(Xs)
-    theta = np.concatenate([ls, [1.0, 0.2]])
-    spec = E.KernelSpec(D=d, idx_cont=list(range(d)), kind=cfg["kernel"])
-    if world == 1:
-        eng = E.Engine(local_rank)
-        transport = "single engine"
-    else:
-        from gumbi_amd.distributed import DistributedEngine
-
-        eng = DistributedEngine(local_rank)
-        transport = eng.comm.kind
-    eng.set_data(X, y)
-    eng.set_kernel(spec)
-    eng.set_theta(theta)
-    part = {"map_eval": 0.0, "fit_fixed_theta": 0.0, "predict": 0.0}
+    part = {"map_eval": 0.0, "fit_fixed_theta": 0.0, "predict": 0.0, "find_map": 0.0}
     last = {}
+    gp = None
+    if map_evals > 0:
+        # the front end, as a user would call it: GP(distributed=True) on every rank, same declared model as C3's
+        gp = build_gp(cfg, device=local_rank, distributed=(True if world > 1 else None))
+        eng = gp.engine
+        transport = eng.comm.kind if world > 1 else "single engine"
+        counts = []
 
-    def one_step(record=False):
-        t0 = time.perf_counter()
-        eng.factorize()
-        val, grad = eng.nlml(grad=True)      # one MAP objective + gradient evaluation
-        t1 = time.perf_counter()
-        eng.factorize()                      # fit at fixed theta: K-build + Cholesky + v + log-det
-        nl = eng.nlml()
-        t2 = time.perf_counter()
-        mu, var = eng.predict(Xs)            # 10^4-point grid (sharded over the ranks)
-        t3 = time.perf_counter()
-        if record:
-            part["map_eval"] += t1 - t0
-            part["fit_fixed_theta"] += t2 - t1
-            part["predict"] += t3 - t2
-        last.update(val=val, grad=grad, nl=nl, mu=mu, var=var)
+        def one_step(record=False):
+            t0 = time.perf_counter()
+            gp.find_MAP(maxeval=map_evals)
+            t1 = time.perf_counter()
+            mu, var = eng.predict(Xs)
+            t2 = time.perf_counter()
+            if record:
+                part["find_map"] += t1 - t0
+                part["predict"] += t2 - t1
+                counts.append((gp.n_eval, gp.n_refactor))
+            last.update(mu=mu, var=var, grad=np.zeros(1), nl=gp.nlml_trace[-1] if gp.nlml_trace else float("nan"))
+    else:
+        X, y, ls = synthetic_table(N, d)
+        theta = np.concatenate([ls, [1.0, 0.2]])
+        spec = E.KernelSpec(D=d, idx_cont=list(range(d)), kind=cfg["kernel"])
+        if world == 1:
+            eng = E.Engine(local_rank)
+            transport = "single engine"
+        else:
+            from gumbi_amd.distributed import DistributedEngine
+
+            eng = DistributedEngine(local_rank)
+            transport = eng.comm.kind
+        eng.set_data(X, y)
+        eng.set_kernel(spec)
+        eng.set_theta(theta)
+
+        def one_step(record=False):
+            t0 = time.perf_counter()
+            eng.factorize()
+            val, grad = eng.nlml(grad=True)      # one MAP objective + gradient evaluation
+            t1 = time.perf_counter()
+            eng.factorize()                      # fit at fixed theta: K-build + Cholesky + v + log-det
+            nl = eng.nlml()
+            t2 = time.perf_counter()
+            mu, var = eng.predict(Xs)            # 10^4-point grid (sharded over the ranks)
+            t3 = time.perf_counter()
+            if record:
+                part["map_eval"] += t1 - t0
+                part["fit_fixed_theta"] += t2 - t1
+                part["predict"] += t3 - t2
+            last.update(val=val, grad=grad, nl=nl, mu=mu, var=var)
 
     for _ in range(warmup):
         one_step()
@@ -439,24 +626,38 @@ def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock):
     clock.sync()
     elapsed = time.perf_counter() - t0
     eng.set_profiling(True)
-    one_step()
+    if map_evals > 0:
+        gp.find_MAP(maxeval=min(map_evals, 2))
+        eng.predict(Xs)
+    else:
+        one_step()
     torch.cuda.synchronize()
     tm = eng.timings()
     eng.set_profiling(False)
-    eng.close()
-    per = clock.max_over_ranks([part["map_eval"] / steps, part["fit_fixed_theta"] / steps, part["predict"] / steps])
+    comm = comm_block(tm, eng, transport, clock) if world > 1 else None
     n3 = float(N) ** 3
-    phases = {
-        "map_eval_s": round(per[0], 4), "fit_fixed_theta_s": round(per[1], 4), "predict_s": round(per[2], 4),
-        "rates_tflops_whole_job": {"map_eval": round(n3 / per[0] / 1e12, 2), "fit_fixed_theta": round(n3 / 3.0 / per[1] / 1e12, 2),
-                                   "predict": round(float(N) ** 2 * M / per[2] / 1e12, 2)},
-        "profiled_last_step_ms_rank0": {k: round(tm[k], 3) for k in ("kbuild_ms", "chol_ms", "chol_gemm_ms", "grad_ms",
-                                                                      "grad_gemm_ms", "predict_ms")},
-        "nlml": float(last["nl"]),
-    }
+    if map_evals > 0:
+        per = clock.max_over_ranks([part["find_map"] / steps, part["predict"] / steps])
+        flops = sum(step_flops(N, M, n, r) for n, r in counts)
+        phases = {"find_map_s": round(per[0], 4), "predict_s": round(per[1], 4), "map_evals_per_step": [c[0] for c in counts],
+                  "refactorizations_at_the_map_per_step": [c[1] for c in counts],
+                  "fit_quality_after_k_evals": fit_quality(gp, last["mu"], cfg), "nlml": float(last["nl"])}
+    else:
+        per = clock.max_over_ranks([part["map_eval"] / steps, part["fit_fixed_theta"] / steps, part["predict"] / steps])
+        flops = steps * step_flops(N, M, 1)
+        phases = {
+            "map_eval_s": round(per[0], 4), "fit_fixed_theta_s": round(per[1], 4), "predict_s": round(per[2], 4),
+            "rates_tflops_whole_job": {"map_eval": round(n3 / per[0] / 1e12, 2), "fit_fixed_theta": round(n3 / 3.0 / per[1] / 1e12, 2),
+                                       "predict": round(float(N) ** 2 * M / per[2] / 1e12, 2)},
+            "nlml": float(last["nl"]),
+        }
+    phases["profiled_last_step_ms_rank0"] = {k: round(tm[k], 3) for k in ("kbuild_ms", "chol_ms", "chol_gemm_ms", "grad_ms",
+                                                                         "grad_gemm_ms", "predict_ms")}
     finite = bool(np.all(np.isfinite(last["mu"])) and np.all(last["var"] > 0) and np.all(np.isfinite(last["grad"])))
-    return dict(elapsed=elapsed, M=M, tm=tm, phases=phases, finite=finite, transport=transport,
-                flops=steps * step_flops(N, M, 1))
+    eng.close()
+    if gp is not None:
+        gp.engine = None
+    return dict(elapsed=elapsed, M=M, tm=tm, phases=phases, finite=finite, transport=transport, flops=flops, comm=comm)
 
 
 def run_with_deadline(fn, seconds):
@@ -490,7 +691,8 @@ def main():
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
                     help="default: c3 on one GPU, c5 (ONE GP over all ranks) on several")
     ap.add_argument("--map-evals", type=int, default=0,
-                    help="cap on L-BFGS objective evaluations per fit (0 = run to convergence, cap 200)")
+                    help="one GPU: cap on L-BFGS objective evaluations per fit (0 = run to convergence, cap 200); c5 / several "
+                         "GPUs: 0 = fixed hyper-parameters, k > 0 = a (distributed) find_MAP(maxeval=k) per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -523,16 +725,26 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libgumbi_hip has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     clock = Clock(dist, dev)
+    budget = Budget()
     healthy = True
 
     if config_name == "c5":
         def section():
             torch.cuda.set_device(local_rank)  # the current device is per-thread state
-            return one_gp_workload(cfg, world, local_rank, dist, args.steps, args.warmup, clock)
+            return one_gp_workload(cfg, world, local_rank, dist, args.steps, args.warmup, clock, args.map_evals)
 
         res, healthy = run_with_deadline(section, float(os.environ.get("GUMBI_BENCH_DEADLINE", "1500")))
     else:
         res = map_fit_workload(cfg, config_name, local_rank, args.steps, args.warmup, args.map_evals, clock)
+
+    def c5_on_one_gpu(steps, warmup):
+        torch.cuda.set_device(local_rank)
+        r = one_gp_workload(CONFIGS["c5"], 1, local_rank, None, steps, warmup, Clock(None, dev), args.map_evals if config_name == "c5" else 0)
+        return {"workload": CONFIGS["c5"]["label"], "note": "the multi-GPU runs' problem on ONE GPU: their strong-scaling base "
+                                                           "(python bench.py --config c5)",
+                "value": round(r["flops"] / r["elapsed"] / 1e9, 2), "unit": "GFLOP/s", "steps": steps, "warmup": warmup,
+                "ms_per_step": round(1e3 * r["elapsed"] / steps, 3), "phases": r["phases"], "results_finite": r["finite"],
+                "trailing_update_tflops": roofline_block(r["tm"], "c5")["achieved"]}
 
     out = None
     if "error" in res:
@@ -545,9 +757,14 @@ def main():
         (elapsed,) = clock.max_over_ranks([res["elapsed"]]) if healthy else (res["elapsed"],)
         if rank == 0:
             tm = res["tm"]
+            if config_name != "c5":
+                metric = "fit+predict achieved GFLOP/s (fp64 exact GP: MAP fit to convergence + grid prediction)"
+            elif args.map_evals > 0:
+                metric = f"fit+predict achieved GFLOP/s (fp64 exact GP: find_MAP(maxeval={args.map_evals}) + grid prediction)"
+            else:
+                metric = "fit+predict achieved GFLOP/s (fp64 exact GP: one MAP evaluation + fit at fixed theta + grid prediction)"
             out = {
-                "metric": "fit+predict achieved GFLOP/s (fp64 exact GP: MAP fit + grid prediction)" if config_name != "c5"
-                          else "fit+predict achieved GFLOP/s (fp64 exact GP: one MAP evaluation + fit at fixed theta + grid prediction)",
+                "metric": metric,
                 "value": round(res["flops"] / elapsed / 1e9, 2),
                 "unit": "GFLOP/s",
                 "n_gpus": world,
@@ -574,33 +791,68 @@ def main():
             if "n_evals" in res:
                 out["config"]["map_evals_per_step"] = res["n_evals"]
                 out["config"]["refactorizations_at_the_map_per_step"] = res["n_refactor"]
-            try:
-                tf, cyc = engine.mfma_f64_peak(local_rank)
-                out["roofline"]["mfma_only_microbench_tflops"] = round(tf, 2)  # sustained ceiling under DVFS
-            except Exception:
-                pass
+                out["config"]["ls_bounds"] = f"lower = {LS_LOWER_Z} standardized units on every input (make_deltas_parray), upper = default"
+                out["config"]["warmup_step"] = f"same code path, evaluation budget {WARMUP_EVALS} (untimed)"
+                out["fit_quality"] = res["quality"]
+                out["seconds_per_map_evaluation"] = round(elapsed / max(sum(res["n_evals"]), 1), 4)
+            if res.get("comm") is not None:
+                out["comm"] = res["comm"]
+                out["transport"], out["rccl_ranks"] = res["comm"]["transport"], res["comm"]["rccl_ranks"]
+                out["comm_ms_total"], out["comm_ms_exposed"] = res["comm"]["comm_ms_total"], res["comm"]["comm_ms_exposed"]
+            if "ceiling" in res:
+                cb, ca = res["ceiling"]["before_timed_region"], res["ceiling"]["after_timed_region"]
+                out["roofline"]["mfma_only_ceiling"] = {
+                    "kernel": "register-only v_mfma_f64_16x16x4_f64 loop with the GEMM's register pattern, >= 1 s back to back",
+                    "before_timed_region": {k: round(v, 2) if isinstance(v, float) else v for k, v in cb.items()},
+                    "after_timed_region": {k: round(v, 2) if isinstance(v, float) else v for k, v in ca.items()},
+                    "datasheet_tflops_at_2400_mhz": FP64_MFMA_PEAK_TFLOPS}
+                out["roofline"]["mfma_only_microbench_tflops"] = round(max(cb["tflops_mean"], ca["tflops_mean"]), 2)
+                out["roofline"]["achieved_le_ceiling"] = bool(out["roofline"]["achieved"] <= out["roofline"]["mfma_only_microbench_tflops"])
 
-    # side sections of the one-GPU run (outside the timed steps)
+    # side sections of the one-GPU run (outside the timed steps), most important first, while the time budget lasts
     if world == 1 and out is not None and "error" not in out and config_name != "c5":
-        if os.environ.get("GUMBI_BENCH_NO_E2E") != "1":
-            try:
-                out["end_to_end"] = end_to_end_fit(cfg, local_rank, args.map_evals)
-            except Exception as err:
-                out["end_to_end"] = {"error": f"{type(err).__name__}: {err}"[:300]}
-        if os.environ.get("GUMBI_BENCH_NO_DIST") != "1":
-            def c5_side():
-                torch.cuda.set_device(local_rank)
-                r = one_gp_workload(CONFIGS["c5"], 1, local_rank, None, 2, 1, clock)
-                return {"workload": CONFIGS["c5"]["label"], "note": "strong-scaling base of the multi-GPU runs (python bench.py --config c5)",
-                        "value": round(r["flops"] / r["elapsed"] / 1e9, 2), "unit": "GFLOP/s", "steps": 2, "warmup": 1,
-                        "ms_per_step": round(1e3 * r["elapsed"] / 2, 3), "phases": r["phases"], "results_finite": r["finite"],
-                        "trailing_update_tflops": roofline_block(r["tm"], "c5")["achieved"]}
-
-            out["c5_single_gpu"], _ = run_with_deadline(c5_side, 900.0)
         if not args.no_cpu_baseline and os.environ.get("GUMBI_BENCH_NO_CPU") != "1":
             out["cpu_baseline"] = cpu_baseline(cfg)
+        if os.environ.get("GUMBI_BENCH_NO_DIST") != "1":
+            est = 75.0
+            if budget.allows(est):
+                out["c5_single_gpu"], _ = run_with_deadline(lambda: c5_on_one_gpu(1, 1), 600.0)
+                out["strong_scaling_base_gflops"] = out["c5_single_gpu"].get("value")
+            else:
+                out["c5_single_gpu"] = budget.skipped(est)
+                out["strong_scaling_base_gflops"] = None
+        if os.environ.get("GUMBI_BENCH_NO_DEFAULT_START") != "1":
+            est = 10.0 + 12.0 * out["seconds_per_map_evaluation"]
+            if budget.allows(est):
+                try:
+                    out["default_start"] = default_start_fit(cfg, local_rank)
+                except Exception as err:
+                    out["default_start"] = {"error": f"{type(err).__name__}: {err}"[:300]}
+            else:
+                out["default_start"] = budget.skipped(est)
+        if os.environ.get("GUMBI_BENCH_NO_E2E") != "1":
+            est = 1.15 * out["fit_predict_seconds"] + 10.0
+            if budget.allows(est):
+                try:
+                    out["end_to_end"] = end_to_end_fit(cfg, local_rank, args.map_evals)
+                except Exception as err:
+                    out["end_to_end"] = {"error": f"{type(err).__name__}: {err}"[:300]}
+            else:
+                out["end_to_end"] = budget.skipped(est)
+    # several GPUs: the same step on ONE GPU of this node, by rank 0 (the other ranks wait at the final barrier)
+    if world > 1 and out is not None and "error" not in out and healthy and os.environ.get("GUMBI_BENCH_NO_BASE") != "1":
+        base, _ = run_with_deadline(lambda: c5_on_one_gpu(1, 1), 500.0)
+        out["strong_scaling_base"] = base
+        out["strong_scaling_base_gflops"] = base.get("value")
+        if base.get("value"):
+            out["speedup_over_one_gpu"] = round(out["value"] / base["value"], 3)
+    elif world == 1 and out is not None and "error" not in out and config_name == "c5":
+        out["strong_scaling_base_gflops"] = out["value"]  # this IS the one-GPU point
+    if out is not None:
+        out["bench_wall_s"] = round(budget.used(), 1)
     if rank == 0 and out is not None:
         print(json.dumps(out, ensure_ascii=False), flush=True)
+    failed = out is not None and "error" in out
     if dist is not None:
         def leave():
             torch.cuda.set_device(local_rank)
@@ -608,11 +860,13 @@ def main():
             dist.destroy_process_group()
 
         if healthy:
-            _, healthy = run_with_deadline(leave, 180.0)
+            _, healthy = run_with_deadline(leave, 700.0)
         if not healthy:
             sys.stderr.write(f"[bench rank {rank}] leaving without the final barrier\n")
             sys.stderr.flush()
-            os._exit(0 if out is None or "error" not in out else 1)
+            os._exit(1)  # a run whose ranks hung or died is not a healthy run, whatever was printed
+    if failed or not healthy:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -1979,8 +1979,10 @@ int gmb_ls_limits(int32_t device, const double* X, int64_t N, int32_t n_cols, in
   return GMB_OK;
 }
 
-int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
-  if (!tflops) return GMB_EINVAL;
+// Register-only MFMA loop, launched back to back until `seconds` have passed (at least once): per-launch HIP
+// events give the rate, block 0's s_memtime span over its own loop gives the shader clock.
+static int mfma_f64_run(int32_t device, double seconds, int iters, double* mean_tf, double* min_tf, double* mhz,
+                        double* cyc_per_mfma, int64_t* launches) {
   int nd = gmb_device_count();
   if (nd < 0) return GMB_ENODEVICE;
   if (device < 0 || device >= nd) return GMB_EINVAL;
@@ -1990,32 +1992,54 @@ int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
-  // tuning knobs for ceiling experiments: resident blocks per CU and operand magnitude (0 = idle datapath)
-  const char* eb = getenv("GMB_PEAK_BLOCKS_PER_CU");
-  const char* ez = getenv("GMB_PEAK_SCALE");
-  const int per_cu = (eb && atoi(eb) > 0) ? atoi(eb) : 2;
-  const double scale = ez ? atof(ez) : 1.0;
-  const char* ei = getenv("GMB_PEAK_ITERS");
-  const int blocks = 256 * per_cu, iters = (ei && atoi(ei) > 0) ? atoi(ei) : 2000;
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100, scale);  // warm-up
-  (void)hipEventRecord(a, 0);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, scale);
-  (void)hipEventRecord(b, 0);
+  const int blocks = 256 * 2;  // two workgroups per compute unit, as the GEMM runs
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 100, 1.0);  // warm-up
+  const double flops = (double)blocks * 4.0 * (double)iters * 16.0 * 2.0 * 16 * 16 * 4;
+  double sum_ms = 0.0, worst_ms = 0.0, sum_mhz = 0.0, sum_cyc = 0.0;
+  int64_t n = 0;
   int rc = GMB_OK;
-  if (hipEventSynchronize(b) != hipSuccess || hipGetLastError() != hipSuccess) rc = GMB_EHIP;
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, a, b);
+  do {
+    (void)hipEventRecord(a, 0);
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, 1.0);
+    (void)hipEventRecord(b, 0);
+    if (hipEventSynchronize(b) != hipSuccess || hipGetLastError() != hipSuccess) {
+      rc = GMB_EHIP;
+      break;
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    double hsink[2] = {0.0, 0.0};
+    if (hipMemcpy(hsink, sink, 16, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = GMB_EHIP;
+      break;
+    }
+    sum_ms += ms;
+    worst_ms = std::max(worst_ms, (double)ms);
+    sum_mhz += hsink[1] / ((double)ms * 1e3);  // block 0's loop spans (almost) the whole launch
+    sum_cyc += hsink[1] / ((double)iters * 16.0);
+    ++n;
+  } while (sum_ms < seconds * 1e3);
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
-  double hsink[2] = {0.0, 0.0};
-  if (rc == GMB_OK && hipMemcpy(hsink, sink, 16, hipMemcpyDeviceToHost) != hipSuccess) rc = GMB_EHIP;
   (void)hipFree(sink);
   if (rc) return rc;
-  // block 0 times its own MFMA stream with s_memtime; 2 waves share each SIMD at this occupancy
-  if (cycles_per_mfma) *cycles_per_mfma = hsink[1] / ((double)iters * 16.0);
-  const double flops = (double)blocks * 4.0 * (double)iters * 16.0 * 2.0 * 16 * 16 * 4;
-  *tflops = flops / ((double)ms * 1e-3) / 1e12;
+  if (mean_tf) *mean_tf = flops * (double)n / (sum_ms * 1e-3) / 1e12;
+  if (min_tf) *min_tf = flops / (worst_ms * 1e-3) / 1e12;
+  if (mhz) *mhz = sum_mhz / (double)n;
+  if (cyc_per_mfma) *cyc_per_mfma = sum_cyc / (double)n;
+  if (launches) *launches = n;
   return GMB_OK;
+}
+
+int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma) {
+  if (!tflops) return GMB_EINVAL;
+  return mfma_f64_run(device, 0.0, 2000, tflops, nullptr, nullptr, cycles_per_mfma, nullptr);
+}
+
+int gmb_mfma_f64_sustained(int32_t device, double seconds, double* mean_tflops, double* min_tflops, double* shader_mhz,
+                           int64_t* launches) {
+  if (!mean_tflops || !(seconds >= 0.0) || seconds > 60.0) return GMB_EINVAL;
+  return mfma_f64_run(device, seconds, 40000, mean_tflops, min_tflops, shader_mhz, nullptr, launches);  // ~37 ms per launch
 }
 
 // ---- block-level operations (multi-GPU driver) ---------------------------------------------

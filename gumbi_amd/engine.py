@@ -221,6 +221,7 @@ _SIGNATURES = {
                               C.c_void_p, C.c_int32]),
     "gmb_ls_limits": (C.c_int, [C.c_int32, _DBL_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _DBL_P, _DBL_P]),
     "gmb_mfma_f64_peak": (C.c_int, [C.c_int32, _DBL_P, _DBL_P]),
+    "gmb_mfma_f64_sustained": (C.c_int, [C.c_int32, C.c_double, _DBL_P, _DBL_P, _DBL_P, C.POINTER(C.c_int64)]),
     "gmb_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_timings_get": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     "gmb_copy_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _DBL_P]),
@@ -584,6 +585,18 @@ def ls_limits(X, ard: bool, device: int = 0):
     if rc != GMB_OK:
         raise GumbiHipError(f"gmb_ls_limits failed with status {rc}")
     return lo, hi
+
+
+def mfma_f64_sustained(device: int = 0, seconds: float = 1.0) -> dict:
+    """The register-only MFMA loop run back to back for ``seconds``: mean / worst launch rate (TFLOP/s), the
+    shader clock it ran at (MHz) and the number of launches (``gmb_mfma_f64_sustained``)."""
+    mean, worst, mhz, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+    rc = load_library().gmb_mfma_f64_sustained(int(device), float(seconds), C.byref(mean), C.byref(worst), C.byref(mhz),
+                                                C.byref(n))
+    if rc != GMB_OK:
+        raise GumbiHipError(f"gmb_mfma_f64_sustained failed with status {rc}")
+    return {"tflops_mean": mean.value, "tflops_min": worst.value, "shader_mhz": mhz.value, "launches": int(n.value),
+            "seconds": float(seconds)}
 
 
 def mfma_f64_peak(device: int = 0):

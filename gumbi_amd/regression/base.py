@@ -584,27 +584,27 @@ class Regressor(ABC):
         return {"train": {"data": train_ds, "NLPDs": train_nlpd, "errors": train_err},
                 "test": {"data": test_ds, "NLPDs": test_nlpd, "errors": test_err}}
 
-    def cross_validate_replicas(self, seeds, **kwargs):
+    def cross_validate_replicas(self, seeds, group=None, **kwargs):
         """Independent :meth:`cross_validate` splits, one per seed, as replica-parallel jobs: with an
         initialised ``torch.distributed`` process group (one process per GPU) the seeds are dealt
         round-robin over the ranks -- no data-path communication, each fit runs on the rank's own GPU --
         and every rank receives the complete list of results in seed order.  Without a process group
-        the splits simply run one after the other.  (the folds of a
-        cross-validation are independent GPs.)"""
+        the splits simply run one after the other.  ``group``: a ``torch.distributed`` group instead of the
+        default one.  (the folds of a cross-validation are independent GPs.)"""
         seeds = list(seeds)
         rank, world, dist = 0, 1, None
         try:
             import torch.distributed as dist_mod
 
             if dist_mod.is_available() and dist_mod.is_initialized():
-                dist, rank, world = dist_mod, dist_mod.get_rank(), dist_mod.get_world_size()
+                dist, rank, world = dist_mod, dist_mod.get_rank(group), dist_mod.get_world_size(group)
         except ImportError:
             pass
         mine = {i: self.cross_validate(seed=seeds[i], **kwargs) for i in range(rank, len(seeds), world)}
         if dist is None:
             return [mine[i] for i in range(len(seeds))]
         gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
+        dist.all_gather_object(gathered, mine, group=group)
         merged = {}
         for part in gathered:
             merged.update(part)

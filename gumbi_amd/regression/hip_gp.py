@@ -316,6 +316,9 @@ class HipGP(Regressor):
         w.r.t. the unconstrained u (u = log theta for the positive parameters)."""
         theta = np.where(pos, np.exp(np.clip(u, -700, 700)), u)
         eng = self.engine
+        # from here on the engine's factor belongs to THIS theta (or to none): an evaluation that is rejected further
+        # down must not leave `_last_eval_theta` pointing at an earlier point whose factor is gone
+        self._last_eval_theta = None
         try:
             eng.set_theta(theta)
             eng.factorize()

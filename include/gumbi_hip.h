@@ -230,6 +230,11 @@ int gmb_timings_get(const gmb_engine* e, gmb_timings* out);
  * kernel, no memory traffic) -- the measured denominator for the MFMA roofline -- and the shader
  * cycles one wave spends per MFMA (64 = the datasheet issue rate; wall rate / this = clock). */
 int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma);
+/* The same register-only loop launched back to back for `seconds` (<= 60; 37 ms per launch): mean and worst
+ * per-launch rate and the shader clock in MHz the loop ran at (s_memtime span / launch duration) -- the sustained
+ * ceiling under the box's power management, to be sampled before AND after a timed region. */
+int gmb_mfma_f64_sustained(int32_t device, double seconds, double* mean_tflops, double* min_tflops,
+                           double* shader_mhz, int64_t* launches);
 
 /* Copy out pieces of the resident state (tests / multi-GPU driver):
  *   rows [r0, r0+nr) x cols [c0, c0+nc) of the factor buffer (lower triangle meaningful),

@@ -1,8 +1,13 @@
 """Multi-rank path on real HIP kernels: the native driver (gumbi_amd/csrc/dist_driver.hpp, ``gmb_dist_*``)
-with two / three processes sharing the one GPU of the test box and exchanging panels through ``gloo``
+with two / three / four processes sharing the one GPU of the test box and exchanging panels through ``gloo``
 (RCCL refuses two ranks on one device), and with the library's own RCCL communicator on one rank; the 8-GPU
-RCCL run is the driver's SCALE job.  Checks factor, v, NLML, gradient and predictions against the oracle."""
+RCCL run is the driver's SCALE job.  Checks factor, v, NLML, gradient and predictions against the oracle.
+
+ONE pool of four worker processes serves every multi-rank test of this module (a ``gloo`` world of four with
+sub-groups of one to four ranks): a process that imports torch costs 5 - 20 s on a cold box, and a spawn per
+parametrisation (41 processes in round 2) was two thirds of the suite's wall time there."""
 import os
+import queue
 import socket
 
 import numpy as np
@@ -10,9 +15,112 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+POOL_WORLD = 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _pool_main(rank, port, tasks, out):
+    """A pool worker: joins the 4-rank gloo world once, then serves (function name, ranks, args) tasks.  A task
+    runs on ranks < `ranks` with the sub-group of exactly those ranks; its function puts ONE result on `out`."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from datetime import timedelta
+
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=POOL_WORLD, timeout=timedelta(seconds=240))
+    groups = {w: dist.new_group(list(range(w)), timeout=timedelta(seconds=240)) for w in range(1, POOL_WORLD)}
+    groups[POOL_WORLD] = dist.group.WORLD
+    out.put(("ready", rank))
+    try:
+        while True:
+            task = tasks.get()
+            if task is None:
+                break
+            name, ranks, args = task
+            try:
+                globals()[name](rank, ranks, groups[ranks], out, *args)
+            except BaseException:
+                import traceback
+
+                out.put(("error", f"rank {rank}: " + traceback.format_exc()[-3000:]))
+    finally:
+        dist.destroy_process_group()
+
+
+class Pool:
+    def __init__(self):
+        import torch.multiprocessing as mp
+
+        ctx = mp.get_context("spawn")
+        self.tasks = [ctx.Queue() for _ in range(POOL_WORLD)]
+        self.out = ctx.Queue()
+        port = _free_port()
+        self.procs = [ctx.Process(target=_pool_main, args=(r, port, self.tasks[r], self.out), daemon=True)
+                      for r in range(POOL_WORLD)]
+        for p in self.procs:
+            p.start()
+        for _ in range(POOL_WORLD):
+            assert self.out.get(timeout=600)[0] == "ready"
+        self.broken = False
+
+    def run(self, fn, ranks, *args, timeout=300):
+        """fn(rank, ranks, group, out, *args) on ranks 0 .. ranks-1; their results, or the test fails with the
+        first worker's traceback (and the pool is rebuilt for the next test: its ranks may be out of step)."""
+        for r in range(ranks):
+            self.tasks[r].put((fn.__name__, ranks, args))
+        results = []
+        for _ in range(ranks):
+            try:
+                r = self.out.get(timeout=timeout)
+            except queue.Empty:
+                self.broken = True
+                pytest.fail(f"{fn.__name__}: no result from a worker within {timeout} s")
+            if isinstance(r, tuple) and r and r[0] == "error":
+                self.broken = True
+                pytest.fail("worker failed:\n" + r[1])
+            results.append(r)
+        return results
+
+    def close(self):
+        for q in self.tasks:
+            q.put(None)
+        for p in self.procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+
+
+_POOL = [None]
+
+
+@pytest.fixture
+def pool(gpu):
+    if _POOL[0] is not None and _POOL[0].broken:
+        for p in _POOL[0].procs:
+            p.kill()
+        _POOL[0] = None
+    if _POOL[0] is None:
+        _POOL[0] = Pool()
+    return _POOL[0]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _close_pool():
+    yield
+    if _POOL[0] is not None:
+        _POOL[0].close()
+        _POOL[0] = None
+
 
 def _collect(out, n, timeout):
-    """n results from the workers' queue; a worker that died reports its traceback instead of a result."""
+    """n results from a worker queue; a worker that died reports its traceback instead of a result."""
     results = []
     for _ in range(n):
         r = out.get(timeout=timeout)
@@ -22,179 +130,137 @@ def _collect(out, n, timeout):
     return results
 
 
-def _worker(rank, world, port, N, d, M, out, model="matern", panel=0):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch  # noqa: F401
-    import torch.distributed as dist
+# ---------------------------------------------------------------------------------------------------------
+def _oracle_task(rank, world, group, out, N, d, M, model, panel):
+    from gumbi_amd.distributed import DistributedEngine
+    from gumbi_amd.engine import KernelSpec, dist_plan
+    from oracle import gp_oracle as O
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from gumbi_amd.distributed import DistributedEngine
-        from gumbi_amd.engine import KernelSpec
-        from oracle import gp_oracle as O
+    if model == "additive":
+        # additive two-output model with a linear and a categorical dim (reference pymc/GP.py:732-754):
+        # the K-build of the owned block rows and the sharded gradient run term by term
+        from test_oracle import additive_problem
 
-        if model == "additive":
-            # additive two-output model with a linear and a categorical dim (reference pymc/GP.py:732-754):
-            # the K-build of the owned block rows and the sharded gradient run term by term
-            from test_oracle import additive_problem
+        spec, theta, X, y = additive_problem(n=N // 2)
+        Xs = X[::3].copy()
+        Xs[:, 0] += 0.21
+        kspec = KernelSpec(**{k: spec[k] for k in ("D", "idx_cont", "kind", "ard", "idx_lin", "coreg", "out_col",
+                                                    "n_out", "hetero_noise", "jitter", "additive")})
+    elif model == "composite":
+        # linear x coregion x two outputs x heteroskedastic noise: every accumulator class of the sharded
+        # gradient (lengthscales, linear, coregion tables, noise table) is hit
+        from pathlib import Path
 
-            spec, theta, X, y = additive_problem(n=N // 2)
-            Xs = X[::3].copy()
-            Xs[:, 0] += 0.21
-            kspec = KernelSpec(**{k: spec[k] for k in ("D", "idx_cont", "kind", "ard", "idx_lin", "coreg", "out_col",
-                                                        "n_out", "hetero_noise", "jitter", "additive")})
-        elif model == "composite":
-            # linear x coregion x two outputs x heteroskedastic noise: every accumulator class of the sharded
-            # gradient (lengthscales, linear, coregion tables, noise table) is hit
-            from pathlib import Path
+        gold = np.load(Path(__file__).resolve().parent / "golden" / "gp_goldens.npz", allow_pickle=True)
+        spec = O.make_spec(4, [0, 1], idx_lin=[1], coreg=[(2, 3)], out_col=3, n_out=2, hetero_noise=True)
+        Xg, yg, theta = (gold[f"composite_N140/{k}"] for k in ("X", "y", "theta"))
+        rng = np.random.default_rng(3)
+        reps = max(2, N // len(yg))
+        X = np.concatenate([Xg] * reps)
+        X[:, spec["idx_cont"]] += 0.05 * rng.standard_normal((len(X), len(spec["idx_cont"])))
+        y = np.concatenate([yg] * reps) + 0.1 * rng.standard_normal(len(X))
+        Xs = X[::5].copy()
+        Xs[:, spec["idx_cont"][0]] += 0.13
+        kspec = KernelSpec(**{k: spec[k] for k in ("D", "idx_cont", "kind", "ard", "idx_lin", "coreg", "out_col",
+                                                    "n_out", "hetero_noise", "jitter")})
+    else:
+        X, y, ls = O.synthetic_table(N, d, seed=5)
+        spec = O.make_spec(d, range(d), kind="Matern52")
+        theta = O.pack_theta(spec, ls, 1.1, 0.3)
+        Xs = np.random.default_rng(1).standard_normal((M, d))
+        kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind="Matern52")
+    eng = DistributedEngine(0, group, panel_blocks=panel)
+    assert eng.comm.kind == "torch-gloo" and eng.comm.world == world
+    eng.set_data(X, y)
+    eng.set_kernel(kspec)
+    eng.set_theta(theta)
+    eng.factorize()
+    tm = eng.timings()
+    # communication probes of the factorisation: one all-gather per SQUARE / PANEL step of this rank's plan, the
+    # bytes it received, and an exposed part that cannot exceed the total
+    plan = dist_plan(len(y), rank, world, panel)
+    n_coll = sum(1 for st in plan if st["op"] in ("SQUARE", "PANEL"))
+    recv = 8.0 * (world - 1) * sum(st["elems"] for st in plan if st["op"] in ("SQUARE", "PANEL"))
+    probes_ok = (tm["dist_world"] == world and tm["dist_chol_collectives"] == n_coll and tm["dist_chol_comm_bytes"] == recv
+                 and 0.0 < tm["dist_chol_comm_ms"] and 0.0 <= tm["dist_chol_comm_exposed_ms"] <= tm["dist_chol_comm_ms"] * (1 + 1e-9)
+                 and tm["dist_chol_main_wait_ms"] >= 0.0 and tm["dist_chol_bulk_wait_ms"] >= 0.0)
+    L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
+    L = np.tril(eng.copy_factor())
+    err_L = np.max(np.abs(L - L_ref)) / np.max(np.abs(L_ref))
+    err_v = np.max(np.abs(eng.copy_v() - v_ref)) / np.max(np.abs(v_ref))
+    err_nl = abs(eng.nlml() - O.nlml(spec, theta, X, y, dist_mode="direct"))
+    mu, var = eng.predict(Xs)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+    err_mu = np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))
+    err_var = np.max(np.abs(var - var_r))
+    # distributed gradient: every rank must return the same (value, gradient) == the oracle's
+    eng.factorize()
+    val, g = eng.nlml(grad=True)
+    tm = eng.timings()
+    probes_ok = probes_ok and (tm["dist_grad_collectives"] >= 3 and tm["dist_grad_comm_bytes"] > 0 and
+                               0.0 <= tm["dist_grad_comm_exposed_ms"] <= tm["dist_grad_comm_ms"] * (1 + 1e-9))
+    val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+    err_g = max(abs(val - val_r) / abs(val_r), np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r))))
+    # alpha = Sigma^-1 y assembled from the ranks' rows of U
+    from scipy.linalg import solve_triangular
 
-            gold = np.load(Path(__file__).resolve().parent / "golden" / "gp_goldens.npz", allow_pickle=True)
-            spec = O.make_spec(4, [0, 1], idx_lin=[1], coreg=[(2, 3)], out_col=3, n_out=2, hetero_noise=True)
-            Xg, yg, theta = (gold[f"composite_N140/{k}"] for k in ("X", "y", "theta"))
-            rng = np.random.default_rng(3)
-            reps = max(2, N // len(yg))
-            X = np.concatenate([Xg] * reps)
-            X[:, spec["idx_cont"]] += 0.05 * rng.standard_normal((len(X), len(spec["idx_cont"])))
-            y = np.concatenate([yg] * reps) + 0.1 * rng.standard_normal(len(X))
-            Xs = X[::5].copy()
-            Xs[:, spec["idx_cont"][0]] += 0.13
-            kspec = KernelSpec(**{k: spec[k] for k in ("D", "idx_cont", "kind", "ard", "idx_lin", "coreg", "out_col",
-                                                        "n_out", "hetero_noise", "jitter")})
-        else:
-            X, y, ls = O.synthetic_table(N, d, seed=5)
-            spec = O.make_spec(d, range(d), kind="Matern52")
-            theta = O.pack_theta(spec, ls, 1.1, 0.3)
-            Xs = np.random.default_rng(1).standard_normal((M, d))
-            kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind="Matern52")
-        eng = DistributedEngine(0, panel_blocks=panel)
-        assert eng.comm.kind == "torch-gloo"
-        eng.set_data(X, y)
-        eng.set_kernel(kspec)
-        eng.set_theta(theta)
-        eng.factorize()
-        L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
-        L = np.tril(eng.copy_factor())
-        err_L = np.max(np.abs(L - L_ref)) / np.max(np.abs(L_ref))
-        err_v = np.max(np.abs(eng.copy_v() - v_ref)) / np.max(np.abs(v_ref))
-        err_nl = abs(eng.nlml() - O.nlml(spec, theta, X, y, dist_mode="direct"))
-        mu, var = eng.predict(Xs)
-        mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
-        err_mu = np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))
-        err_var = np.max(np.abs(var - var_r))
-        # distributed gradient: every rank must return the same (value, gradient) == the oracle's
-        eng.factorize()
-        val, g = eng.nlml(grad=True)
-        val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
-        err_g = max(abs(val - val_r) / abs(val_r), np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r))))
-        # alpha = Sigma^-1 y assembled from the ranks' rows of U
-        from scipy.linalg import solve_triangular
-
-        err_g = max(err_g, float(np.max(np.abs(eng.copy_alpha() - solve_triangular(L_ref, v_ref, lower=True, trans="T")))
-                               / np.max(np.abs(v_ref))) * 1e-2)
-        out.put((rank, err_L, err_v, err_nl, err_mu, err_var, err_g, g.tobytes()))
-        eng.close()
-    except BaseException:
-        import traceback
-
-        out.put(("error", traceback.format_exc()[-3000:]))
-        raise
-    finally:
-        dist.destroy_process_group()
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    err_g = max(err_g, float(np.max(np.abs(eng.copy_alpha() - solve_triangular(L_ref, v_ref, lower=True, trans="T")))
+                           / np.max(np.abs(v_ref))) * 1e-2)
+    eng.close()
+    out.put((rank, err_L, err_v, err_nl, err_mu, err_var, err_g, bool(probes_ok), g.tobytes()))
 
 
 @pytest.mark.parametrize("world,N,model,panel", [(2, 700, "matern", 0), (2, 512, "matern", 1), (3, 1000, "matern", 2),
                                                  (2, 600, "additive", 0), (3, 420, "composite", 1),
                                                  (2, 2500, "matern", 3), (3, 5000, "matern", 0),
                                                  (3, 100, "matern", 0), (2, 128, "matern", 1), (4, 130, "matern", 2)])
-def test_two_ranks_one_gpu_match_oracle(gpu, world, N, model, panel):
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, 333, out, model, panel)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = _collect(out, world, 300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, err_L, err_v, err_nl, err_mu, err_var, err_g, gbytes in results:
+def test_two_ranks_one_gpu_match_oracle(pool, world, N, model, panel):
+    results = pool.run(_oracle_task, world, N, 3, 333, model, panel)
+    for rank, err_L, err_v, err_nl, err_mu, err_var, err_g, probes_ok, gbytes in results:
         assert err_L < 1e-10 and err_v < 1e-10 and err_nl < 1e-8
         assert err_mu < 1e-8 and err_var < 1e-9
         assert err_g < 1e-8
+        assert probes_ok
     assert len({r[-1] for r in results}) == 1  # bit-identical gradient on every rank (optimisers stay in lock step)
 
 
-def _notpd_worker(rank, world, port, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch  # noqa: F401
-    import torch.distributed as dist
+def _notpd_task(rank, world, group, out):
+    from gumbi_amd.distributed import DistributedEngine
+    from gumbi_amd.engine import Engine, KernelSpec
+    from oracle import gp_oracle as O
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from gumbi_amd.distributed import DistributedEngine
-        from gumbi_amd.engine import Engine, KernelSpec
-        from oracle import gp_oracle as O
-
-        N, d = 900, 3
-        X, y, ls = O.synthetic_table(N, d, seed=2)
-        bad = 517  # in the fifth block row: owned by another rank than block row 0
-        X[bad, 1] = np.nan
-        theta = np.concatenate([ls, [1.0, 0.2]])
-        got = []
-        for eng in (DistributedEngine(0, panel_blocks=2), Engine(0)):
-            eng.set_data(X, y)
-            eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d))))
-            eng.set_theta(theta)
-            try:
-                eng.factorize()
-                got.append(("no error", -1))
-            except np.linalg.LinAlgError as err:
-                got.append(("LinAlgError", eng.notpd_index(), str(err)[:80]))
-            # the engine stays usable: a clean table factorises afterwards
-            X2 = X.copy()
-            X2[bad, 1] = 0.25
-            eng.set_data(X2, y)
-            eng.set_theta(theta)
+    N, d = 900, 3
+    X, y, ls = O.synthetic_table(N, d, seed=2)
+    bad = 517  # in the fifth block row: owned by another rank than block row 0
+    X[bad, 1] = np.nan
+    theta = np.concatenate([ls, [1.0, 0.2]])
+    got = []
+    for eng in (DistributedEngine(0, group, panel_blocks=2), Engine(0)):
+        eng.set_data(X, y)
+        eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d))))
+        eng.set_theta(theta)
+        try:
             eng.factorize()
-            got.append(round(float(eng.nlml()), 6))
-            eng.close()
-        out.put((rank, got))
-    except BaseException:
-        import traceback
+            got.append(("no error", -1))
+        except np.linalg.LinAlgError as err:
+            got.append(("LinAlgError", eng.notpd_index(), str(err)[:80]))
+        # the engine stays usable: a clean table factorises afterwards
+        X2 = X.copy()
+        X2[bad, 1] = 0.25
+        eng.set_data(X2, y)
+        eng.set_theta(theta)
+        eng.factorize()
+        got.append(round(float(eng.nlml()), 6))
+        eng.close()
+    out.put((rank, got))
 
-        out.put(("error", traceback.format_exc()[-3000:]))
-        raise
-    finally:
-        dist.destroy_process_group()
 
-
-def test_not_positive_definite_is_reported_identically_on_every_rank(gpu):
+def test_not_positive_definite_is_reported_identically_on_every_rank(pool):
     """A NaN input makes the covariance non-factorisable at its row: every rank of the multi-GPU driver must
     return the SAME failure (GMB_ENOTPD -> LinAlgError, same global row index as the single engine -- the
     diagonal squares are factored redundantly, so no rank can run ahead into a collective the others skip),
     and the engines must remain usable afterwards."""
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_notpd_worker, args=(r, 3, port, out)) for r in range(3)]
-    for p in procs:
-        p.start()
-    results = _collect(out, 3, 300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = pool.run(_notpd_task, 3)
     for rank, got in results:
         dist_err, dist_nl, single_err, single_nl = got
         assert dist_err[0] == "LinAlgError" and single_err[0] == "LinAlgError", got
@@ -203,70 +269,104 @@ def test_not_positive_definite_is_reported_identically_on_every_rank(gpu):
     assert len({str(g) for _, g in results}) == 1
 
 
-def _large_worker(rank, world, port, N, d, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch  # noqa: F401
-    import torch.distributed as dist
+def _local_failure_task(rank, world, group, out, mode):
+    """One rank fails LOCALLY; no rank may be left blocked in an all-gather, and every rank must get an error."""
+    from gumbi_amd import engine as E
+    from gumbi_amd.distributed import DistributedEngine, TorchDistComm
+    from oracle import gp_oracle as O
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, d = 1500, 3
+    X, y, ls = O.synthetic_table(N, d, seed=11)
+    theta = np.concatenate([ls, [1.0, 0.2]])
+
+    class FlakyComm(TorchDistComm):
+        """performs every collective (the peers are never blocked) but reports a transport error for the k-th"""
+
+        calls = 0
+
+        def _all_gather(self, ctx, send, recv, count, stream):
+            rc = super()._all_gather(ctx, send, recv, count, stream)
+            FlakyComm.calls += 1
+            return -7 if (self.rank == 1 and FlakyComm.calls == 6) else rc
+
+    comm = FlakyComm(0, group) if mode == "mid-sequence" else None
+    eng = DistributedEngine(0, group, comm=comm, panel_blocks=2)
+    eng.set_data(X, y)
+    eng.set_kernel(E.KernelSpec(D=d, idx_cont=list(range(d))))
+    if not (mode == "set-up" and rank == 1):
+        eng.set_theta(theta)  # rank 1 "forgets" its hyper-parameters: its gmb_dist_factorize fails before any collective
     try:
-        from gumbi_amd.distributed import DistributedEngine
-        from gumbi_amd.engine import Engine, KernelSpec
-        from oracle import gp_oracle as O
-
-        X, y, ls = O.synthetic_table(N, d, seed=7)
-        theta = np.concatenate([ls, [1.0, 0.2]])
-        kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind="ExpQuad")
-        Xs = O.synthetic_grid(d, 24)
-        res = {}
-        for name, eng in (("dist", DistributedEngine(0)), ("single", Engine(0))):
-            eng.set_data(X, y)
-            eng.set_kernel(kspec)
-            eng.set_theta(theta)
-            eng.factorize()
-            rows = [0, 127, 128, 5000, N // 2 + 1, N - 1]
-            Lr = np.stack([eng.copy_factor(r, 1, 0, N)[0] for r in rows])
-            for a, r in enumerate(rows):
-                Lr[a, r + 1:] = 0.0  # above the diagonal the buffer holds scratch (schedule-dependent)
-            v = eng.copy_v()
-            mu, var = eng.predict(Xs)
-            val, g = eng.nlml(grad=True)
-            res[name] = (Lr, v, mu, var, val, g)
-            eng.close()
-            del eng
-        a, b = res["dist"], res["single"]
-        errs = [float(np.max(np.abs(x - z)) / max(np.max(np.abs(z)), 1e-300)) for x, z in zip(a[:4], b[:4])]
-        errs.append(abs(a[4] - b[4]) / abs(b[4]))
-        errs.append(float(np.max(np.abs(a[5] - b[5])) / max(1.0, np.max(np.abs(b[5])))))
-        ref = O.nlml(O.make_spec(d, range(d)), theta, X, y) if rank == 0 else a[4]
-        out.put((rank, errs, abs(a[4] - ref) / abs(ref), a[5].tobytes()))
-    except BaseException:
-        import traceback
-
-        out.put(("error", traceback.format_exc()[-3000:]))
-        raise
-    finally:
-        dist.destroy_process_group()
+        eng.factorize()
+        got = "no error"
+    except (ValueError, E.GumbiHipError) as err:
+        got = f"{type(err).__name__}: {err}"
+    # after the failure every rank is still in step: the same engines factorise a well-posed problem together
+    eng.set_theta(theta)
+    if comm is not None:
+        FlakyComm.calls = 1000
+    eng.factorize()
+    val = eng.nlml()
+    ref = O.nlml(O.make_spec(d, range(d)), theta, X, y)
+    eng.close()
+    out.put((rank, got, abs(val - ref) / abs(ref)))
 
 
-def test_two_ranks_one_gpu_at_n_20k_match_the_single_engine(gpu):
+@pytest.mark.parametrize("mode", ["set-up", "mid-sequence"])
+def test_a_rank_that_fails_locally_takes_every_rank_to_an_error_and_blocks_nobody(pool, mode):
+    """ADVICE r02 (dist_driver.hpp): a failure local to one rank -- a call-order / allocation error before the
+    first collective, or an error in the middle of the panel loop -- used to make that rank return between
+    collectives while its peers blocked in the next all-gather for ever.  Now the ranks agree on a status before
+    the first data collective and after the last, and a failing rank keeps issuing the plan's all-gathers."""
+    results = pool.run(_local_failure_task, 2, mode, timeout=200)
+    by_rank = {r[0]: r for r in results}
+    assert "no error" not in (by_rank[0][1], by_rank[1][1]), results
+    if mode == "set-up":
+        assert "gmb_set_theta has not been called" in by_rank[1][1]
+    else:
+        assert "transport status -7" in by_rank[1][1]
+    assert "rank 1 of 2 failed" in by_rank[0][1], by_rank[0][1]
+    assert by_rank[0][2] < 1e-10 and by_rank[1][2] < 1e-10  # both recovered together
+
+
+def _large_task(rank, world, group, out, N, d):
+    from gumbi_amd.distributed import DistributedEngine
+    from gumbi_amd.engine import Engine, KernelSpec
+    from oracle import gp_oracle as O
+
+    X, y, ls = O.synthetic_table(N, d, seed=7)
+    theta = np.concatenate([ls, [1.0, 0.2]])
+    kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind="ExpQuad")
+    Xs = O.synthetic_grid(d, 24)
+    res = {}
+    for name, eng in (("dist", DistributedEngine(0, group)), ("single", Engine(0))):
+        eng.set_data(X, y)
+        eng.set_kernel(kspec)
+        eng.set_theta(theta)
+        eng.factorize()
+        rows = [0, 127, 128, 5000, N // 2 + 1, N - 1]
+        Lr = np.stack([eng.copy_factor(r, 1, 0, N)[0] for r in rows])
+        for a, r in enumerate(rows):
+            Lr[a, r + 1:] = 0.0  # above the diagonal the buffer holds scratch (schedule-dependent)
+        v = eng.copy_v()
+        mu, var = eng.predict(Xs)
+        val, g = eng.nlml(grad=True)
+        res[name] = (Lr, v, mu, var, val, g)
+        eng.close()
+        del eng
+    a, b = res["dist"], res["single"]
+    errs = [float(np.max(np.abs(x - z)) / max(np.max(np.abs(z)), 1e-300)) for x, z in zip(a[:4], b[:4])]
+    errs.append(abs(a[4] - b[4]) / abs(b[4]))
+    errs.append(float(np.max(np.abs(a[5] - b[5])) / max(1.0, np.max(np.abs(b[5])))))
+    ref = O.nlml(O.make_spec(d, range(d)), theta, X, y) if rank == 0 else a[4]
+    out.put((rank, errs, abs(a[4] - ref) / abs(ref), a[5].tobytes()))
+
+
+def test_two_ranks_one_gpu_at_n_20k_match_the_single_engine(pool):
     """The block-cyclic driver well beyond a handful of blocks: N = 20,480 (160 block columns, 20 panels of
     the default width, 5 chunks of the row-partitioned inverse) over two ranks sharing the GPU: sampled rows
     of the factor, v, predictions, NLML and gradient equal the single-GPU engine's (same kernels, different
     order of the trailing updates), the NLML equals the oracle's, both ranks hold identical bits."""
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_large_worker, args=(r, 2, port, 20_480, 4, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = _collect(out, 2, 900)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    results = pool.run(_large_task, 2, 20_480, 4, timeout=900)
     for rank, errs, err_oracle, _ in results:
         assert max(errs[:2]) < 1e-9 and errs[2] < 1e-8 and errs[3] < 1e-8, errs   # factor rows, v, mean, variance
         assert errs[4] < 1e-11 and errs[5] < 1e-7, errs                            # NLML, gradient
@@ -274,118 +374,87 @@ def test_two_ranks_one_gpu_at_n_20k_match_the_single_engine(gpu):
     assert results[0][-1] == results[1][-1]
 
 
-def _fit_worker(rank, world, port, N, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch  # noqa: F401
-    import torch.distributed as dist
-
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import pandas as pd
-
-        import gumbi_amd as gmb
-        from oracle import gp_oracle as O
-
-        X, y, _ = O.synthetic_table(N, 2, seed=9)
-        df = pd.DataFrame(X, columns=["a", "b"])
-        df["y"] = y
-        grid = np.random.default_rng(2).uniform(-1.5, 1.5, (50, 2))
-
-        def fit(distributed):
-            gp = gmb.GP(gmb.DataSet(df, outputs=["y"]), outputs=["y"], distributed=distributed)
-            gp.specify_model(continuous_dims=["a", "b"])
-            gp.build_model()
-            gp.find_MAP()
-            pts = gp.parray(a=grid[:, 0], b=grid[:, 1])
-            pred = gp.predict_points(pts)
-            res = (gp._theta_fitted.copy(), np.asarray(pred.μ).copy(), np.asarray(pred.σ2).copy(), gp.n_eval)
-            gp.engine.close()
-            return res
-
-        th_d, mu_d, var_d, n_d = fit(True)
-        th_s, mu_s, var_s, n_s = fit(None)  # the same fit on this rank's GPU alone
-        out.put((rank, float(np.max(np.abs(th_d - th_s) / np.maximum(np.abs(th_s), 1e-3))),
-                 float(np.max(np.abs(mu_d - mu_s))), float(np.max(np.abs(var_d - var_s))), n_d, n_s, th_d.tobytes()))
-    except BaseException:
-        import traceback
-
-        out.put(("error", traceback.format_exc()[-3000:]))
-        raise
-    finally:
-        dist.destroy_process_group()
-
-
-def test_distributed_map_fit_matches_single_gpu_fit(gpu):
-    """GP(..., distributed=True).find_MAP() over two ranks: same optimum and predictions as the
-    single-GPU fit, identical parameters on both ranks."""
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    world = 2
-    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, 400, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = _collect(out, world, 300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, err_th, err_mu, err_var, n_d, n_s, _ in results:
-        assert err_th < 1e-5 and err_mu < 1e-6 and err_var < 1e-6
-    assert results[0][-1] == results[1][-1]
-
-
-def _cv_worker(rank, world, port, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch  # noqa: F401
-    import torch.distributed as dist
-
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import pandas as pd
-
-        import gumbi_amd as gmb
-        from oracle import gp_oracle as O
-
-        X, y, _ = O.synthetic_table(300, 2, seed=4)
-        df = pd.DataFrame(X, columns=["a", "b"])
-        df["y"] = y
-        gp = gmb.GP(gmb.DataSet(df, outputs=["y"]), outputs=["y"])
-        gp.specify_model(continuous_dims=["a", "b"])
-        gp.build_model()
-        res = gp.cross_validate_replicas([11, 12, 13], pct_train=0.7)
-        out.put((rank, [float(r["test"]["NLPDs"].mean()) for r in res], [len(r["train"]["data"].wide) for r in res]))
-    except BaseException:
-        import traceback
-
-        out.put(("error", traceback.format_exc()[-3000:]))
-        raise
-    finally:
-        dist.destroy_process_group()
-
-
-def test_cross_validation_replicas_over_ranks(gpu):
-    """Three independent splits dealt over two ranks: both ranks end up with all three results, equal
-    to what one process computes alone."""
+def _fit_task(rank, world, group, out, N, d, ls_lower):
     import pandas as pd
-    import torch.multiprocessing as mp
 
     import gumbi_amd as gmb
     from oracle import gp_oracle as O
 
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_cv_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = _collect(out, 2, 300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    X, y, ls = O.synthetic_table(N, d, seed=9)
+    cols = [f"x{k}" for k in range(d)]
+    df = pd.DataFrame(X, columns=cols)
+    df["y"] = y
+    grid = np.random.default_rng(2).uniform(-1.5, 1.5, (400, d))
+    # the generator's noise-free function at the grid, in the z-scored units of y
+    rng = np.random.default_rng(9)
+    Xr = rng.standard_normal((N, d))
+    y_raw = np.sum(np.sin(Xr / ls), axis=1) / np.sqrt(d) + 0.2 * rng.standard_normal(N)
+    f_grid = (np.sum(np.sin(grid / ls), axis=1) / np.sqrt(d) - y_raw.mean()) / y_raw.std(ddof=1)
+
+    def fit(distributed):
+        ds = gmb.DataSet(df, outputs=["y"])
+        gp = gmb.GP(ds, outputs=["y"], distributed=distributed)
+        lsb = gmb.make_deltas_parray(stdzr=ds.stdzr, scale="standardized", **{c: [ls_lower, None] for c in cols}) if ls_lower else None
+        gp.fit(continuous_dims=cols, ls_bounds=lsb)  # the user-level call: specify_model + build_model + find_MAP
+        pred = gp.predict_points(gp.parray(**{c: grid[:, k] for k, c in enumerate(cols)}))
+        mu_z = gp.predict(np.asarray(grid, float))[0]
+        res = (gp._theta_fitted.copy(), np.asarray(pred.μ).copy(), np.asarray(pred.σ2).copy(), gp.n_eval,
+               float(np.corrcoef(mu_z, f_grid)[0, 1]), float(np.asarray(gp.MAP["σ"])) / (0.2 / y_raw.std(ddof=1)))
+        gp.engine.close()
+        return res
+
+    th_d, mu_d, var_d, n_d, corr_d, sig_d = fit(group)
+    th_s, mu_s, var_s, n_s, corr_s, sig_s = fit(None)  # the same fit on this rank's GPU alone
+    out.put((rank, float(np.max(np.abs(th_d - th_s) / np.maximum(np.abs(th_s), 1e-3))),
+             float(np.max(np.abs(mu_d - mu_s))), float(np.max(np.abs(var_d - var_s))), n_d, n_s, corr_d, sig_d, th_d.tobytes()))
+
+
+def test_distributed_map_fit_matches_single_gpu_fit(pool):
+    """GP(..., distributed=group).fit() over two ranks: same optimum and predictions as the
+    single-GPU fit, identical parameters on both ranks."""
+    results = pool.run(_fit_task, 2, 400, 2, None)
+    for rank, err_th, err_mu, err_var, n_d, n_s, corr, sig, _ in results:
+        assert err_th < 1e-5 and err_mu < 1e-6 and err_var < 1e-6
+    assert results[0][-1] == results[1][-1]
+
+
+def test_distributed_map_fit_at_n_8k_finds_the_function(pool):
+    """``GP(distributed=group).fit(ls_bounds=...)`` at N = 8192, d = 4 over two ranks (64 block columns, 8 panels,
+    two chunks of the row-partitioned inverse, ~25 lock-step L-BFGS-B evaluations): the optimiser must arrive
+    where the single-GPU fit arrives, both ranks with identical bits, and the fit must be a FIT -- posterior
+    mean correlated > 0.95 with the generator's noise-free function, sigma-hat within 10 % of the generator's."""
+    results = pool.run(_fit_task, 2, 8192, 4, 0.5, timeout=900)
+    for rank, err_th, err_mu, err_var, n_d, n_s, corr, sig, _ in results:
+        assert err_th < 2e-2 and err_mu < 1e-3 and err_var < 1e-3, (err_th, err_mu, err_var)
+        assert 10 <= n_d <= 80 and corr > 0.95 and abs(sig - 1.0) < 0.1, (n_d, corr, sig)
+    assert results[0][-1] == results[1][-1]
+
+
+def _cv_task(rank, world, group, out):
+    import pandas as pd
+
+    import gumbi_amd as gmb
+    from oracle import gp_oracle as O
+
+    X, y, _ = O.synthetic_table(300, 2, seed=4)
+    df = pd.DataFrame(X, columns=["a", "b"])
+    df["y"] = y
+    gp = gmb.GP(gmb.DataSet(df, outputs=["y"]), outputs=["y"])
+    gp.specify_model(continuous_dims=["a", "b"])
+    gp.build_model()
+    res = gp.cross_validate_replicas([11, 12, 13], group=group, pct_train=0.7)
+    out.put((rank, [float(r["test"]["NLPDs"].mean()) for r in res], [len(r["train"]["data"].wide) for r in res]))
+
+
+def test_cross_validation_replicas_over_ranks(pool):
+    """Three independent splits dealt over two ranks: both ranks end up with all three results, equal
+    to what one process computes alone."""
+    import pandas as pd
+
+    import gumbi_amd as gmb
+    from oracle import gp_oracle as O
+
+    results = pool.run(_cv_task, 2)
     assert results[0][1:] == results[1][1:]
     X, y, _ = O.synthetic_table(300, 2, seed=4)
     df = pd.DataFrame(X, columns=["a", "b"])
@@ -394,7 +463,6 @@ def test_cross_validation_replicas_over_ranks(gpu):
     gp.specify_model(continuous_dims=["a", "b"])
     gp.build_model()
     alone = gp.cross_validate_replicas([11, 12, 13], pct_train=0.7)
-    # (MAP optima agree to the optimiser's tolerance, not bitwise: the trace reductions use atomics)
     assert np.allclose([float(r["test"]["NLPDs"].mean()) for r in alone], results[0][1], rtol=1e-4)
     assert [len(r["train"]["data"].wide) for r in alone] == results[0][2] == [210, 210, 210]
 
