@@ -35,15 +35,19 @@ def needs_build() -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not needs_build():
+    """The product library.  ``GUMBI_BUILD_TUNING=1`` builds ``libgumbi_hip_tuning.so`` beside it instead, with
+    ``-DGMB_TUNING`` (the environment switches of the tuning tools, tools/README.md; load it with GUMBI_HIP_LIB)."""
+    tuning = os.environ.get("GUMBI_BUILD_TUNING") == "1"
+    target = LIB.with_name("libgumbi_hip_tuning.so") if tuning else LIB
+    if not force and not tuning and not needs_build():
         return LIB
     LIB.parent.mkdir(parents=True, exist_ok=True)
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
+           "-Wno-unused-function", *(["-DGMB_TUNING"] if tuning else []), *[str(CSRC / s) for s in SOURCES], "-o", str(target)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

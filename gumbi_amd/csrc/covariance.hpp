@@ -697,10 +697,15 @@ __global__ void predict_final_kernel(const double* part_mu, const double* part_s
   var[m] = kss[m] - as;
 }
 
-// v[i] = L[n + i*ld] (the y row of the factor), and |v|^2
+// v[i] = L[n + i*ld] (the y row of the factor), and |v|^2 -- summed in a fixed order (run to run, the same bits):
+// workgroup b leaves its partial sum in scal[1 + b]; the workgroup that finishes LAST (a counter in scal[40], zeroed
+// with the rest of the scalars at the start of every factorisation) adds the partials in index order into scal[0].
+// Launch with EXTRACT_V_BLOCKS workgroups; scal = the engine's scalar block + 1 ([0] |v|^2, [1..] partials).
+constexpr int EXTRACT_V_BLOCKS = 32;
 __global__ __launch_bounds__(256) void extract_v_kernel(const double* L, int64_t ld, int64_t n,
-                                                        double* v, double* vnorm2) {
+                                                        double* v, double* scal) {
   __shared__ double red[4];
+  __shared__ int last;
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const double x = L[n + i * ld];
@@ -711,7 +716,18 @@ __global__ __launch_bounds__(256) void extract_v_kernel(const double* L, int64_t
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(vnorm2, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    atomicExch((unsigned long long*)&scal[1 + blockIdx.x], (unsigned long long)__double_as_longlong((red[0] + red[1]) + (red[2] + red[3])));
+    __threadfence();
+    last = atomicAdd((unsigned int*)&scal[40], 1u) == gridDim.x - 1;
+    if (last) {
+      __threadfence();
+      double s = 0.0;
+      for (unsigned b = 0; b < gridDim.x; ++b)
+        s += __longlong_as_double((long long)atomicAdd((unsigned long long*)&scal[1 + b], 0ull));  // read at the L2
+      scal[0] = s;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -122,8 +122,12 @@ struct gmb_engine {
   int64_t cap_W = 0;
   double* dalpha = nullptr;
   int64_t cap_pts_alpha = 0;
-  double* dgpart = nullptr;
+  double* dgpart = nullptr;   // accumulators of the trace reductions (GACC_DOUBLES) + 64 doubles of scratch
   int64_t cap_gpart = 0;
+  double* dgred = nullptr;    // per-workgroup partial vectors of grad_tile_kernel (two-stage, fixed-order sums)
+  int64_t cap_gred = 0;
+  double* dgbig = nullptr;    // per-wave copies of coregion tables with more than 8 levels
+  int64_t cap_gbig = 0;
 
   // cached launch plan of the batched levels of the triangular inverse (static per data set)
   struct InvLevelPlan {
@@ -1164,7 +1168,7 @@ int grad_workspace(gmb_engine* e) {
     if ((rc = alloc(e, &e->dalpha, e->Np))) return rc;
     e->cap_pts_alpha = e->Np;
   }
-  if (!e->dgpart && (rc = alloc(e, &e->dgpart, (int64_t)GACC_DOUBLES))) return rc;
+  if (!e->dgpart && (rc = alloc(e, &e->dgpart, (int64_t)GACC_DOUBLES + 64))) return rc;
   return GMB_OK;
 }
 
@@ -1197,10 +1201,16 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
   const gmb_kernel_spec& s = e->spec;
   const int nt = (int)(e->Np / TILE);
   int rc;
-  HIP_TRY(e, hipMemsetAsync(e->dgpart, 0, GACC_DOUBLES * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->dgpart, 0, (GACC_DOUBLES + 64) * sizeof(double), e->stream));
   const int n_ls = s.ard ? s.n_cont : 1;
-  int nblocks = 0;
-  for (int i = shard; i < nt; i += nshards) nblocks += i + 1;
+  long long total = 0;
+  for (int i = shard; i < nt; i += nshards) total += i + 1;
+  // persistent workgroups: four per compute unit, each reduces a contiguous run of `per` tiles in registers / LDS
+  // and writes ONE partial vector; a second launch adds the vectors in a fixed order (bit-reproducible results)
+  const long long want = std::max<long long>(1, 2 * e->wg_slots);
+  const int per = (int)std::max<long long>(1, (total + want - 1) / want);
+  const int grid = (int)((total + per - 1) / per);
+  const int ncp = e->nc_pad;
   for (size_t t = 0; t < e->terms.size(); ++t) {
     const gmb_engine::Term& tr = e->terms[t];
     if (t > 0 && (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &tr.pa))) return rc;
@@ -1216,25 +1226,72 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
     a.nc_real = s.n_cont;
     for (int k = 0; k < 16; ++k) a.inv_ls[k] = k < s.n_cont ? tr.pa.inv_ls[k] : 0.0;
     a.eta = tr.eta;
-    a.acc = e->dgpart + (int64_t)t * GACC_REGION;
     a.row_first = shard;
     a.row_stride = nshards;
-    int off = 64;
+    a.total_tiles = total;
+    a.per = per;
+    const int n_small = ncp + 2 + tr.cp.n_lin;
+    a.part_stride = n_small + tr.cp.n_tab * 64;
+    double* acc = e->dgpart + (int64_t)t * GACC_REGION;
+    int tab_acc_off[MAX_TABS] = {0};
+    int off = 64, big = 0;
     for (int j = 0; j < tr.cp.n_tab; ++j) {
-      a.tab_acc_off[j] = off;
-      off += tr.cp.tab_levels[j] * tr.cp.tab_levels[j];
+      tab_acc_off[j] = off;
+      const int LL = tr.cp.tab_levels[j] * tr.cp.tab_levels[j];
+      off += LL;
+      a.big_off[j] = big;
+      if (tr.cp.tab_levels[j] > 8) big += LL;
     }
-    if (nblocks > 0) switch (tr.cp.kind) {
-      case GMB_EXPQUAD: rc = launch_grad_nc<0>(e, a, nblocks); break;
-      case GMB_MATERN52: rc = launch_grad_nc<1>(e, a, nblocks); break;
-      case GMB_MATERN32: rc = launch_grad_nc<2>(e, a, nblocks); break;
-      case GMB_MATERN12: rc = launch_grad_nc<3>(e, a, nblocks); break;
-      default: rc = launch_grad_nc<4>(e, a, nblocks); break;
+    a.big_stride = big;
+    if (grid > 0) {
+      if ((rc = ensure(e, &e->dgred, &e->cap_gred, (int64_t)grid * a.part_stride))) return rc;
+      a.part = e->dgred;
+      if (big > 0) {
+        if ((rc = ensure(e, &e->dgbig, &e->cap_gbig, (int64_t)grid * 4 * big))) return rc;
+        HIP_TRY(e, hipMemsetAsync(e->dgbig, 0, (size_t)grid * 4 * big * sizeof(double), e->stream));
+        a.big = e->dgbig;
+      }
+      switch (tr.cp.kind) {
+        case GMB_EXPQUAD: rc = launch_grad_nc<0>(e, a, grid); break;
+        case GMB_MATERN52: rc = launch_grad_nc<1>(e, a, grid); break;
+        case GMB_MATERN32: rc = launch_grad_nc<2>(e, a, grid); break;
+        case GMB_MATERN12: rc = launch_grad_nc<3>(e, a, grid); break;
+        default: rc = launch_grad_nc<4>(e, a, grid); break;
+      }
+      if (rc) return rc;
+      // second stage: dense slots of the partial vectors -> the term's accumulator region
+      GradRanges r{};
+      auto add = [&](int dense, int count, int dst) {
+        r.dense[r.n] = dense;
+        r.count[r.n] = count;
+        r.dst[r.n] = dst;
+        ++r.n;
+      };
+      double* tmp = e->dgpart + GACC_DOUBLES;  // scratch behind the accumulators
+      if (s.ard) add(0, s.n_cont, 0);
+      else add(0, s.n_cont, (int)(tmp - acc));               // per-dimension sums, folded into the one parameter below
+      add(ncp, 2 + tr.cp.n_lin, n_ls);                        // eta | tau | c..
+      for (int j = 0; j < tr.cp.n_tab; ++j)
+        if (tr.cp.tab_levels[j] <= 8) add(n_small + j * 64, tr.cp.tab_levels[j] * tr.cp.tab_levels[j], tab_acc_off[j]);
+      hipLaunchKernelGGL(grad_sum_partials_kernel, dim3(a.part_stride), dim3(256), 0, e->stream, e->dgred, grid,
+                         (int64_t)a.part_stride, r, acc);
+      if (!s.ard) hipLaunchKernelGGL(grad_fold_ls_kernel, dim3(1), dim3(64), 0, e->stream, acc, s.n_cont, tmp);
+      if (big > 0) {
+        GradRanges rb{};
+        for (int j = 0; j < tr.cp.n_tab; ++j)
+          if (tr.cp.tab_levels[j] > 8) {
+            rb.dense[rb.n] = a.big_off[j];
+            rb.count[rb.n] = tr.cp.tab_levels[j] * tr.cp.tab_levels[j];
+            rb.dst[rb.n] = tab_acc_off[j];
+            ++rb.n;
+          }
+        hipLaunchKernelGGL(grad_sum_partials_kernel, dim3(big), dim3(256), 0, e->stream, e->dgbig, grid * 4, (int64_t)big, rb, acc);
+      }
+      HIP_TRY(e, hipGetLastError());
     }
-    if (rc) return rc;
     if (t == 0) {  // diagonal terms (sigma, noise table) with the global term's categories in place
       const double sigma = e->theta[n_ls + 1];
-      hipLaunchKernelGGL(grad_diag_kernel, dim3(64), dim3(256), 0, e->stream, Z, ldz, e->dalpha, train_set(e),
+      hipLaunchKernelGGL(grad_diag_kernel, dim3(1), dim3(1024), 0, e->stream, Z, ldz, e->dalpha, train_set(e),
                          tr.cp, sigma, e->dgpart + off, shard, nshards, packed ? 1 : 0);
       HIP_TRY(e, hipGetLastError());
     }
@@ -1460,10 +1517,18 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
     const char* v = getenv(name);
     return v && v[0] ? v[0] != '0' : dflt;
   };
-  // Tuning / debugging switches (none changes results beyond rounding; the defaults are what the tests and
-  // the bench run): the reference leaf kernel, tile-shape pinning, the two fallbacks of the look-ahead
-  // Cholesky (plain recursion, unmasked schedule), the inverse's launch structure.
+  // Environment switches of the PRODUCT library: only the ones a test or a documented tools/ A-B uses.
+  //   GMB_LEAF_NAIVE=1   the reference diagonal-block kernel (tests/test_gpu_parity.py::test_potrf_leaf_block)
+  //   GMB_CHOL_SCHEME    0 = plain recursion, 2 = masked look-ahead for every size (tests/test_gpu_parity.py::
+  //                      test_cholesky_schedules_agree; tools/gpu_ab_env.py); default: by size
+  //   GMB_TRACE_FILE     per-launch event log while profiling (tools/gpu_trace_run.py, tools/gpu_bulk_trace.py)
+  // Everything else is compiled in only with -DGMB_TUNING (GUMBI_BUILD_TUNING=1 python -m gumbi_amd.build writes
+  // gumbi_amd/lib/libgumbi_hip_tuning.so; tools/README.md).
   e->naive_leaf = flag("GMB_LEAF_NAIVE", false);
+  const char* cs = getenv("GMB_CHOL_SCHEME");
+  if (cs) e->chol_scheme = atoi(cs);
+  int part = 32;  // compute units the masked bulk stream leaves to the panel chain
+#ifdef GMB_TUNING
   e->small_tiles = flag("GMB_SMALL_TILES", true);
   const char* gv = getenv("GMB_GEMM_VARIANT");  // pins the tile shape of every out-of-place GEMM: 0 .. 3
   if (gv && gv[0] >= '0' && gv[0] <= '3') {
@@ -1483,20 +1548,19 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
     e->panel_blocks = atoi(pb);
     e->panel_auto = false;
   }
-  const char* cs = getenv("GMB_CHOL_SCHEME");  // 0 = plain recursion, 2 = masked look-ahead, default by size
-  if (cs) e->chol_scheme = atoi(cs);
   const char* mb = getenv("GMB_MASKED_MAX_BLOCKS");
   if (mb) e->masked_max_blocks = atoi(mb);
+  const char* pc = getenv("GMB_PART_CUS");
+  if (pc) part = atoi(pc);
+#endif
   e->cur = e->stream;
   // Exactly four streams per engine (beyond four hardware queues the runtime multiplexes streams and every
   // kernel of the process slows down -- measured): the caller's, aux[0] / aux[1] at the highest queue
   // priority (panel chain of the unmasked look-ahead; independent merges of the triangular inverse), and
   // aux[2] = the bulk stream of the trailing updates: the process-wide CU-masked stream (GMB_PART_CUS
-  // compute units left free, default 32; 0 = an ordinary lowest-priority stream, unmasked schedules only).
+  // compute units left free, default 32; tuning builds: 0 = an ordinary lowest-priority stream).
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  const char* pc = getenv("GMB_PART_CUS");
-  const int part = pc ? atoi(pc) : 32;
   for (int a = 0; a < 3 && peer; ++a) {  // sibling: the peer's streams (its engines work one after the other)
     e->aux[a] = peer->aux[a];
     e->aux_borrowed = true;
@@ -1564,7 +1628,7 @@ void gmb_destroy(gmb_engine* e) {
     if (e->aux[a]) (void)hipStreamSynchronize(e->aux[a]);
   void* ptrs[] = {e->dstat, e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv, e->dV, e->dXs, e->txs, e->txl,
-                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart};
+                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart, e->dgred, e->dgbig};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int a = 0; a < 3; ++a)
@@ -1742,7 +1806,7 @@ int gmb_factorize(gmb_engine* e) {
                       (e->chol_scheme == 2 || (e->chol_scheme < 0 && e->Np / TILE <= e->masked_max_blocks));
   if ((rc = masked ? chol_lookahead_masked(e) : chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) return rc;
   // 3. v = L^-1 y is row N of the factor
-  hipLaunchKernelGGL(extract_v_kernel, dim3(64), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
+  hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
                      e->dscal + 1);
   tc.stop();
   HIP_TRY(e, hipGetLastError());
@@ -2123,7 +2187,11 @@ int gmb_blk_potrf(gmb_engine* e, double* Akk, int64_t lda, int32_t nvalid, doubl
   a.logdet = logdet_accum;
   a.info = info ? info : e->dinfo;
   a.row0 = 0;
-  a.dbg = getenv("GMB_LEAF_DBG") ? logdet_accum + 1 : nullptr;  // tuning: stamps after the log-det slot
+#ifdef GMB_TUNING
+  a.dbg = getenv("GMB_LEAF_DBG") ? logdet_accum + 1 : nullptr;  // stamps after the log-det slot (tools/gpu_leaf_timing.py)
+#else
+  a.dbg = nullptr;
+#endif
   return launch_leaf(e, a);
 }
 

@@ -34,8 +34,19 @@ struct GradArgs {
   int32_t nc_real;
   double inv_ls[16];
   double eta;
-  double* acc;      // global accumulators (atomicAdd)
-  int32_t tab_acc_off[MAX_TABS];
+  // Deterministic two-stage reduction (no floating-point atomics whose order depends on scheduling): workgroup
+  // b reduces the tiles [b * per, (b + 1) * per) of the launch's enumeration and WRITES its sums densely to
+  // part[b * part_stride + q]; grad_sum_partials_kernel adds the workgroups' vectors in a fixed order.
+  //   q in [0, NC + 2 + n_lin): ls.. | eta | tau | c..      then the tables with <= 8 levels, 64 slots each
+  double* part;
+  int32_t part_stride;
+  int64_t total_tiles;  // tiles of this launch
+  int32_t per;          // tiles per workgroup
+  // tables with more than 8 levels do not fit the LDS copies: every WAVE adds into a private global copy
+  // big[(b * 4 + wave) * big_stride + big_off[t] + ca * L + cb] (zeroed by the caller, summed afterwards)
+  double* big;
+  int32_t big_stride;
+  int32_t big_off[MAX_TABS];
   // shard of the lower triangle this launch reduces: block rows row_first, row_first + row_stride, ...
   // (0, 1 = everything; a rank of the multi-GPU gradient passes (rank, world))
   int32_t row_first, row_stride;
@@ -43,7 +54,8 @@ struct GradArgs {
   int32_t z_packed;
 };
 
-constexpr int GRAD_MAX_LDS_ACC = 16 + 2 + MAX_LIN + MAX_TABS * 64;  // tables up to 8 levels in LDS
+constexpr int GRAD_SMALL = 16 + 2 + MAX_LIN;                 // ls.. | eta | tau | c..
+constexpr int GRAD_MAX_LDS_ACC = GRAD_SMALL + MAX_TABS * 64;  // + tables up to 8 levels
 
 template <int KIND, int NC>
 __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
@@ -53,187 +65,236 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
   __shared__ int32_t cj[MAX_TABS][TILE];
   __shared__ int32_t ci[MAX_TABS][TILE];
   __shared__ double aj[TILE];
-  __shared__ double sacc[GRAD_MAX_LDS_ACC];
+  __shared__ double swave[4][GRAD_SMALL];       // per-wave sums of the register accumulators
+  __shared__ double stab[4][MAX_TABS * 64];     // per-wave copies of the small coregion-table accumulators
 
-  // lower-triangle tile pair (ti >= tj), enumerated block row by owned block row
-  // (closed form: owned row m = (tix - row_first) / row_stride is preceded by m (row_first + 1) + row_stride m (m - 1) / 2
-  // tiles; a linear search cost the late rows of a large matrix thousands of scalar cycles per workgroup)
-  const double sd = (double)a.row_stride, f1 = (double)a.row_first + 1.0 - 0.5 * sd;
-  int m = (int)((__builtin_sqrt(f1 * f1 + 2.0 * sd * (double)blockIdx.x) - f1) / sd);
-  auto before = [&](int q) -> long long { return (long long)q * (a.row_first + 1) + (long long)a.row_stride * q * (q - 1) / 2; };
-  m = m < 0 ? 0 : m;
-  while (before(m) > (long long)blockIdx.x) --m;
-  while (before(m + 1) <= (long long)blockIdx.x) ++m;
-  const int tix = a.row_first + m * a.row_stride;
-  if (tix >= a.tiles) return;
-  const int tjx = (int)((long long)blockIdx.x - before(m));
-  const int64_t gi0 = (int64_t)tix * TILE, gj0 = (int64_t)tjx * TILE;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6;
   const int il = tid & (TILE - 1), jh = tid >> 7;
-  const int64_t gi = gi0 + il;
   const CovParams& p = a.p;
   const int n_acc_small = NC + 2 + p.n_lin;
-
-  for (int idx = tid; idx < GRAD_MAX_LDS_ACC; idx += 256) sacc[idx] = 0.0;
-  for (int idx = tid; idx < NC * TILE; idx += 256) {
-    const int k = idx / TILE, j = idx - k * TILE;
-    xj[k][j] = a.pts.xs[(int64_t)k * a.pts.npad + gj0 + j];
-  }
-  for (int idx = tid; idx < p.n_lin * TILE; idx += 256) {
-    const int k = idx / TILE, j = idx - k * TILE;
-    lj[k][j] = a.pts.xl[(int64_t)k * a.pts.npad + gj0 + j];
-    li[k][j] = a.pts.xl[(int64_t)k * a.pts.npad + gi0 + j];
-  }
-  for (int idx = tid; idx < p.n_tab * TILE; idx += 256) {
-    const int t = idx / TILE, j = idx - t * TILE;
-    cj[t][j] = a.pts.cat[(int64_t)t * a.pts.npad + gj0 + j];
-    ci[t][j] = a.pts.cat[(int64_t)t * a.pts.npad + gi0 + j];
-  }
-  if (tid < TILE) aj[tid] = (gj0 + tid < a.pts.n) ? a.alpha[gj0 + tid] : 0.0;
-  double xi[NC];
-#pragma unroll
-  for (int k = 0; k < NC; ++k) xi[k] = a.pts.xs[(int64_t)k * a.pts.npad + gi];
-  const bool row_real = gi < a.pts.n;
-  const double ai = row_real ? a.alpha[gi] : 0.0;
-  __syncthreads();
+  for (int idx = tid; idx < 4 * MAX_TABS * 64; idx += 256) (&stab[0][0])[idx] = 0.0;
 
   double g_ls[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) g_ls[k] = 0.0;
   double g_eta = 0.0, g_tau = 0.0;
+  double g_c[MAX_LIN];
+#pragma unroll
+  for (int k = 0; k < MAX_LIN; ++k) g_c[k] = 0.0;
 
-  const int64_t zrow = a.z_packed ? (int64_t)((tix - a.row_first) / a.row_stride) * TILE + il : gi;
-  const double* zp = a.Z + zrow + (gj0 + jh * (TILE / 2)) * a.ldz;
-  // Fast path (almost every tile): stationary term only, tile strictly below the diagonal, every
-  // row and column real -- each entry stands for (i,j) and (j,i), no per-entry conditionals.
-  const bool fast = p.n_lin == 0 && p.n_tab == 0 && tix > tjx && gi0 + TILE <= a.pts.n && gj0 + TILE <= a.pts.n;
-  if (fast) {
-    const int jb = jh * (TILE / 2);
+  // this workgroup's run of lower-triangle tile pairs (ti >= tj), enumerated block row by owned block row
+  // (closed form: owned row m = (tix - row_first) / row_stride is preceded by m (row_first + 1) + row_stride m (m - 1) / 2 tiles)
+  const long long t_begin = (long long)blockIdx.x * a.per;
+  long long t_end = t_begin + a.per;
+  t_end = t_end < a.total_tiles ? t_end : a.total_tiles;
+  auto before = [&](int q) -> long long { return (long long)q * (a.row_first + 1) + (long long)a.row_stride * q * (q - 1) / 2; };
+  int m = 0;
+  if (t_begin < t_end) {
+    const double sd = (double)a.row_stride, f1 = (double)a.row_first + 1.0 - 0.5 * sd;
+    m = (int)((__builtin_sqrt(f1 * f1 + 2.0 * sd * (double)t_begin) - f1) / sd);
+    m = m < 0 ? 0 : m;
+    while (before(m) > t_begin) --m;
+    while (before(m + 1) <= t_begin) ++m;
+  }
+  int tix = a.row_first + m * a.row_stride;
+  int tjx = (int)(t_begin - before(m));
+
+  for (long long tile = t_begin; tile < t_end; ++tile) {
+    const int64_t gi0 = (int64_t)tix * TILE, gj0 = (int64_t)tjx * TILE;
+    const int64_t gi = gi0 + il;
+    __syncthreads();  // the previous tile's readers are done with the staged coordinates
+    for (int idx = tid; idx < NC * TILE; idx += 256) {
+      const int k = idx / TILE, j = idx - k * TILE;
+      xj[k][j] = a.pts.xs[(int64_t)k * a.pts.npad + gj0 + j];
+    }
+    for (int idx = tid; idx < p.n_lin * TILE; idx += 256) {
+      const int k = idx / TILE, j = idx - k * TILE;
+      lj[k][j] = a.pts.xl[(int64_t)k * a.pts.npad + gj0 + j];
+      li[k][j] = a.pts.xl[(int64_t)k * a.pts.npad + gi0 + j];
+    }
+    for (int idx = tid; idx < p.n_tab * TILE; idx += 256) {
+      const int t = idx / TILE, j = idx - t * TILE;
+      cj[t][j] = a.pts.cat[(int64_t)t * a.pts.npad + gj0 + j];
+      ci[t][j] = a.pts.cat[(int64_t)t * a.pts.npad + gi0 + j];
+    }
+    if (tid < TILE) aj[tid] = (gj0 + tid < a.pts.n) ? a.alpha[gj0 + tid] : 0.0;
+    double xi[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) xi[k] = a.pts.xs[(int64_t)k * a.pts.npad + gi];
+    const bool row_real = gi < a.pts.n;
+    const double ai = row_real ? a.alpha[gi] : 0.0;
+    __syncthreads();
+
+    const int64_t zrow = a.z_packed ? (int64_t)((tix - a.row_first) / a.row_stride) * TILE + il : gi;
+    const double* zp = a.Z + zrow + (gj0 + jh * (TILE / 2)) * a.ldz;
+    // Fast path (almost every tile): stationary term only, tile strictly below the diagonal, every
+    // row and column real -- each entry stands for (i,j) and (j,i), no per-entry conditionals.
+    const bool fast = p.n_lin == 0 && p.n_tab == 0 && tix > tjx && gi0 + TILE <= a.pts.n && gj0 + TILE <= a.pts.n;
+    if (fast) {
+      const int jb = jh * (TILE / 2);
 #pragma unroll 4
-    for (int jj = 0; jj < TILE / 2; ++jj) {
-      const double m = zp[(int64_t)jj * a.ldz] - ai * aj[jb + jj];  // 2 * M_ij
+      for (int jj = 0; jj < TILE / 2; ++jj) {
+        const double mm = zp[(int64_t)jj * a.ldz] - ai * aj[jb + jj];  // 2 * M_ij
+        double d2[NC];
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const double d = xi[k] - xj[k][jb + jj];
+          d2[k] = d * d;
+          r2 += d2[k];
+        }
+        const double ks = stationary<KIND>(r2);
+        const double mdk = mm * (p.eta2 * stationary_dr2<KIND>(r2));
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g_ls[k] = fma(mdk, -2.0 * d2[k] * a.inv_ls[k], g_ls[k]);
+        g_eta = fma(mm, 2.0 * a.eta * ks, g_eta);
+      }
+    }
+    for (int jj = fast ? TILE / 2 : 0; jj < TILE / 2; ++jj) {
+      const int j = jh * (TILE / 2) + jj;
+      const int64_t gj = gj0 + j;
+      if (!row_real || gj >= a.pts.n || gj > gi) continue;
+      const double mfull = 0.5 * (zp[(int64_t)jj * a.ldz] - ai * aj[j]);  // M_ij
+      const double mm = (gi == gj) ? mfull : 2.0 * mfull;                  // (i,j) and (j,i)
       double d2[NC];
       double r2 = 0.0;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
-        const double d = xi[k] - xj[k][jb + jj];
+        const double d = xi[k] - xj[k][j];
         d2[k] = d * d;
         r2 += d2[k];
       }
       const double ks = stationary<KIND>(r2);
-      const double mdk = m * (p.eta2 * stationary_dr2<KIND>(r2));
+      const double dk = p.eta2 * stationary_dr2<KIND>(r2);
+      double lin = 0.0;
+      for (int k = 0; k < p.n_lin; ++k) lin = fma(li[k][il], lj[k][j], lin);
+      double F = 1.0;
+      for (int t = 0; t < p.n_tab; ++t)
+        F *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
+      const double mF = mm * F;
+      // d r2 / d ls_k = -2 d2_k / ls_k   (d2 already in scaled units)
 #pragma unroll
-      for (int k = 0; k < NC; ++k) g_ls[k] = fma(mdk, -2.0 * d2[k] * a.inv_ls[k], g_ls[k]);
-      g_eta = fma(m, 2.0 * a.eta * ks, g_eta);
-    }
-  }
-  for (int jj = fast ? TILE / 2 : 0; jj < TILE / 2; ++jj) {
-    const int j = jh * (TILE / 2) + jj;
-    const int64_t gj = gj0 + j;
-    if (!row_real || gj >= a.pts.n || gj > gi) continue;
-    const double mfull = 0.5 * (zp[(int64_t)jj * a.ldz] - ai * aj[j]);  // M_ij
-    const double m = (gi == gj) ? mfull : 2.0 * mfull;                   // (i,j) and (j,i)
-    double d2[NC];
-    double r2 = 0.0;
+      for (int k = 0; k < NC; ++k) g_ls[k] = fma(mF * dk, -2.0 * d2[k] * a.inv_ls[k], g_ls[k]);
+      g_eta = fma(mF, 2.0 * a.eta * ks, g_eta);
+      if (p.n_lin > 0) {
+        g_tau = fma(mF, lin, g_tau);
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      const double d = xi[k] - xj[k][j];
-      d2[k] = d * d;
-      r2 += d2[k];
-    }
-    const double ks = stationary<KIND>(r2);
-    const double dk = p.eta2 * stationary_dr2<KIND>(r2);
-    double lin = 0.0;
-    for (int k = 0; k < p.n_lin; ++k) lin = fma(li[k][il], lj[k][j], lin);
-    double F = 1.0;
-    for (int t = 0; t < p.n_tab; ++t)
-      F *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
-    const double mF = m * F;
-    // d r2 / d ls_k = -2 d2_k / ls_k   (d2 already in scaled units)
-#pragma unroll
-    for (int k = 0; k < NC; ++k) g_ls[k] = fma(mF * dk, -2.0 * d2[k] * a.inv_ls[k], g_ls[k]);
-    g_eta = fma(mF, 2.0 * a.eta * ks, g_eta);
-    if (p.n_lin > 0) {
-      g_tau = fma(mF, lin, g_tau);
-      for (int k = 0; k < p.n_lin; ++k)
-        atomicAdd(&sacc[NC + 2 + k], -mF * p.tau * (li[k][il] + lj[k][j]));
-    }
-    if (p.n_tab > 0) {
-      const double base = p.eta2 * ks + p.tau * lin;
-      for (int t = 0; t < p.n_tab; ++t) {
-        double others = 1.0;
-        for (int t2 = 0; t2 < p.n_tab; ++t2)
-          if (t2 != t) others *= p.tabs[p.tab_off[t2] + ci[t2][il] * p.tab_levels[t2] + cj[t2][j]];
-        const int L = p.tab_levels[t];
-        const double val = mfull * base * others;
-        // ordered pair (i,j) feeds G[a][b]; its mirror (j,i) feeds G[b][a] (off-diagonal only)
-        const int ca = ci[t][il], cb = cj[t][j];
-        const bool off = gi != gj;
-        if (L <= 8) {
-          atomicAdd(&sacc[n_acc_small + t * 64 + ca * L + cb], val);
-          if (off) atomicAdd(&sacc[n_acc_small + t * 64 + cb * L + ca], val);
-        } else {
-          atomicAdd(&a.acc[a.tab_acc_off[t] + ca * L + cb], val);
-          if (off) atomicAdd(&a.acc[a.tab_acc_off[t] + cb * L + ca], val);
+        for (int k = 0; k < MAX_LIN; ++k)
+          if (k < p.n_lin) g_c[k] = fma(-mF * p.tau, li[k][il] + lj[k][j], g_c[k]);
+      }
+      if (p.n_tab > 0) {
+        const double base = p.eta2 * ks + p.tau * lin;
+        for (int t = 0; t < p.n_tab; ++t) {
+          double others = 1.0;
+          for (int t2 = 0; t2 < p.n_tab; ++t2)
+            if (t2 != t) others *= p.tabs[p.tab_off[t2] + ci[t2][il] * p.tab_levels[t2] + cj[t2][j]];
+          const int L = p.tab_levels[t];
+          const double val = mfull * base * others;
+          // ordered pair (i,j) feeds G[a][b]; its mirror (j,i) feeds G[b][a] (off-diagonal only).  The copies
+          // are private to this wave: lanes of one instruction that hit the same entry are served in the
+          // hardware's fixed lane order, and no other wave ever adds into them.
+          const int ca = ci[t][il], cb = cj[t][j];
+          const bool off = gi != gj;
+          if (L <= 8) {
+            atomicAdd(&stab[wave][t * 64 + ca * L + cb], val);
+            if (off) atomicAdd(&stab[wave][t * 64 + cb * L + ca], val);
+          } else {
+            double* bt = a.big + ((int64_t)blockIdx.x * 4 + wave) * a.big_stride + a.big_off[t];
+            atomicAdd(&bt[ca * L + cb], val);
+            if (off) atomicAdd(&bt[cb * L + ca], val);
+          }
         }
       }
     }
+    // next tile of the enumeration
+    if (++tjx > tix) {
+      tix += a.row_stride;
+      tjx = 0;
+    }
   }
-  // block reduction of the register accumulators
-#pragma unroll
-  for (int k = 0; k < NC; ++k) {
-    double v = g_ls[k];
+
+  // wave sums of the register accumulators (fixed shuffle tree), then the four waves in wave order
+  auto wave_sum = [&](double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((tid & 63) == 0) atomicAdd(&sacc[k], v);
+    return v;
+  };
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const double v = wave_sum(g_ls[k]);
+    if ((tid & 63) == 0) swave[wave][k] = v;
   }
   {
-    double v = g_eta, u = g_tau;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      v += __shfl_down(v, off);
-      u += __shfl_down(u, off);
-    }
+    const double v = wave_sum(g_eta), u = wave_sum(g_tau);
     if ((tid & 63) == 0) {
-      atomicAdd(&sacc[NC], v);
-      atomicAdd(&sacc[NC + 1], u);
+      swave[wave][NC] = v;
+      swave[wave][NC + 1] = u;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAX_LIN; ++k) {
+    if (k < p.n_lin) {
+      const double v = wave_sum(g_c[k]);
+      if ((tid & 63) == 0) swave[wave][NC + 2 + k] = v;
     }
   }
   __syncthreads();
-  // flush: ARD keeps one slot per dim; shared lengthscale sums all dims into slot 0
-  if (tid < NC) {
-    if (a.ard) {
-      if (tid < a.nc_real) atomicAdd(&a.acc[tid], sacc[tid]);
-    } else if (tid == 0) {
-      double s = 0.0;
-      for (int k = 0; k < NC; ++k) s += sacc[k];
-      atomicAdd(&a.acc[0], s);
+  double* out = a.part + (int64_t)blockIdx.x * a.part_stride;
+  if (tid < n_acc_small) out[tid] = (swave[0][tid] + swave[1][tid]) + (swave[2][tid] + swave[3][tid]);
+  for (int idx = tid; idx < p.n_tab * 64; idx += 256)
+    out[n_acc_small + idx] = (stab[0][idx] + stab[1][idx]) + (stab[2][idx] + stab[3][idx]);
+}
+
+// Second stage: out[dst(q)] = sum over the nparts partial vectors of slot q, in a FIXED order (thread t adds parts
+// t, t + 256, ...; then a fixed LDS tree) -- run to run, the same bits.  Dense slot q of the partial vectors maps
+// to out[dst[r] + (q - dense[r])] for the range r that contains it; slots outside every range are dropped (the
+// zero-padded coordinates of the compile-time dimension count).
+struct GradRanges {
+  int32_t n;
+  int32_t dense[MAX_TABS + 2], count[MAX_TABS + 2], dst[MAX_TABS + 2];
+};
+__global__ __launch_bounds__(256) void grad_sum_partials_kernel(const double* __restrict__ part, int nparts, int64_t stride,
+                                                                GradRanges r, double* __restrict__ acc) {
+  __shared__ double red[256];
+  const int q = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += 256) s += part[(int64_t)b * stride + q];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < r.n; ++i)
+    if (q >= r.dense[i] && q < r.dense[i] + r.count[i]) {
+      acc[r.dst[i] + (q - r.dense[i])] = red[0];
+      return;
     }
-  }
-  const int n_ls_out = a.ard ? a.nc_real : 1;
-  if (tid == 0) {
-    atomicAdd(&a.acc[n_ls_out], sacc[NC]);
-    atomicAdd(&a.acc[n_ls_out + 1], sacc[NC + 1]);
-  }
-  if (tid < p.n_lin) atomicAdd(&a.acc[n_ls_out + 2 + tid], sacc[NC + 2 + tid]);
-  for (int t = 0; t < p.n_tab; ++t) {
-    const int L = p.tab_levels[t];
-    if (L <= 8 && tid < L * L) {
-      const double v = sacc[n_acc_small + t * 64 + tid];
-      if (v != 0.0) atomicAdd(&a.acc[a.tab_acc_off[t] + tid], v);
-    }
-  }
+}
+// shared lengthscale: every dimension's partial belongs to the one parameter -- acc[0] = sum_k tmp[k], fixed order
+__global__ void grad_fold_ls_kernel(double* acc, int n, const double* tmp) {
+  if (threadIdx.x || blockIdx.x) return;
+  double s = 0.0;
+  for (int k = 0; k < n; ++k) s += tmp[k];
+  acc[0] = s;
 }
 
 // Diagonal-only terms: d/d sigma and the noise-table partials.
-//   out[0] += sum_i M_ii * 2 sigma * nmult_i ;  out[1 + a] += sum_{i: out(i) = a} M_ii * sigma^2
-__global__ __launch_bounds__(256) void grad_diag_kernel(const double* Z, int64_t ldz,
-                                                        const double* alpha, PointSet pts,
-                                                        CovParams p, double sigma, double* out, int row_first,
-                                                        int row_stride, int z_packed = 0) {
-  __shared__ double red[4];
+//   out[0] = sum_i M_ii * 2 sigma * nmult_i ;  out[1 + a] = sum_{i: out(i) = a} M_ii * sigma^2
+// One workgroup, fixed order: thread t takes rows t, t + 1024, ...; the noise-table partials go through per-wave
+// LDS copies (lanes of one instruction are served in lane order), summed wave by wave.
+__global__ __launch_bounds__(1024) void grad_diag_kernel(const double* Z, int64_t ldz,
+                                                         const double* alpha, PointSet pts,
+                                                         CovParams p, double sigma, double* out, int row_first,
+                                                         int row_stride, int z_packed = 0) {
+  __shared__ double red[16];
+  __shared__ double tab[16][32];
+  const int wave = threadIdx.x >> 6;
+  for (int idx = threadIdx.x; idx < 16 * 32; idx += 1024) (&tab[0][0])[idx] = 0.0;
+  __syncthreads();
   double gs = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pts.n; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = threadIdx.x; i < pts.n; i += 1024) {
     if ((int)((i >> 7) % row_stride) != row_first) continue;  // block rows of this shard only
     const double a = alpha[i];
     const int64_t zr = z_packed ? (((i >> 7) - row_first) / row_stride) * TILE + (i & 127) : i;
@@ -242,15 +303,24 @@ __global__ __launch_bounds__(256) void grad_diag_kernel(const double* Z, int64_t
     if (p.noise_tab >= 0) {
       const int c = pts.cat[(int64_t)p.noise_tab * pts.npad + i];
       mult = p.noise_mult[c];
-      atomicAdd(&out[1 + c], m * sigma * sigma);
+      atomicAdd(&tab[wave][c], m * sigma * sigma);
     }
     gs = fma(m, 2.0 * sigma * mult, gs);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gs += __shfl_down(gs, off);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gs;
+  if ((threadIdx.x & 63) == 0) red[wave] = gs;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&out[0], red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    out[0] = s;
+  }
+  if (p.noise_tab >= 0 && threadIdx.x < 32) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += tab[w][threadIdx.x];
+    out[1 + threadIdx.x] = s;
+  }
 }
 
 // The factor buffer carries y (later v) in row N, so the block inversion leaves -v^T L^-1 in the

@@ -429,3 +429,129 @@ def test_additive_model_matches_oracle(gpu, two_outputs, lin, hetero, n):
     val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
     assert np.isclose(val, val_r, rtol=1e-10)
     assert np.max(np.abs(g - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
+
+
+# ----------------------------------------------------------------------------------------------
+# device tests of the composite gradient and of the pairwise-distance reduction (restored: ADVICE r02)
+# ----------------------------------------------------------------------------------------------
+def test_composite_model_gradient_and_prediction(gpu):
+    """Linear x coregion x two outputs x heteroskedastic noise on ONE GPU: every accumulator class of the fused
+    trace reductions (lengthscales, eta, tau, c, coregion tables, sigma, noise table) against the golden gradient."""
+    case = "composite_N140"
+    spec = golden_spec(case)
+    X, y, Xs, theta = (GOLD[f"{case}/{k}"] for k in ("X", "y", "Xs", "theta"))
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    val, g = eng.nlml(grad=True)
+    assert np.isclose(val, float(GOLD[f"{case}/nlml"]), rtol=1e-10)
+    g_r = GOLD[f"{case}/grad"]
+    assert np.max(np.abs(g - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
+    mu, var = eng.predict(Xs, with_noise=True)  # the factor survives the gradient
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, with_noise=True, dist_mode="direct")
+    assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-9
+    eng.close()
+
+
+def test_ls_limits_joint_matches_oracle(gpu):
+    """``gmb_ls_limits`` (ls_limits_kernel): the joint d-dimensional pairwise extrema of ``parse_ls_limits(ARD=False)``
+    (gp_utils.py:34-46) and the per-column ones, against scipy's pdist; N not a multiple of the tile, a coinciding pair."""
+    from scipy.spatial.distance import pdist
+
+    from gumbi_amd.engine import ls_limits
+    from gumbi_amd.utils.gp_utils import parse_ls_limits
+
+    rng = np.random.default_rng(4)
+    for n, d in ((700, 4), (1031, 3), (129, 8)):
+        X = rng.standard_normal((n, d))
+        X[10] = X[3]
+        lo, hi = ls_limits(X, ard=False)
+        dd = pdist(X)
+        assert np.isclose(lo[0], dd[dd != 0].min(), rtol=1e-13) and np.isclose(hi[0], dd.max(), rtol=1e-13)
+        lo, hi = ls_limits(X, ard=True)  # raw extrema (the 0.01 floor is applied by parse_ls_limits)
+        for j in range(d):
+            dj = pdist(X[:, [j]])
+            assert np.isclose(lo[j], dj[dj != 0].min(), rtol=1e-13) and np.isclose(hi[j], dj.max(), rtol=1e-13)
+        lo2, hi2 = parse_ls_limits(X, ARD=False)
+        assert np.isclose(lo2[0], max(dd[dd != 0].min(), 0.01)) and np.isclose(hi2[0], dd.max())
+    lo, hi = ls_limits(np.ones((5, 2)), ard=False)
+    assert lo[0] == -1.0  # every pair coincides
+
+
+# ----------------------------------------------------------------------------------------------
+# bit-reproducibility (SURVEY.md section 5: deterministic reductions)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["matern_ard", "expquad_shared", "composite"])
+def test_evaluations_are_bit_reproducible(gpu, model):
+    """No floating-point atomics whose order depends on scheduling: |v|^2, the log-determinant and every partial
+    of the fused trace reductions are summed in a fixed order (two-stage sums), so two evaluations at one theta --
+    on one engine and on a fresh one -- give the SAME BITS for the NLML, its gradient and the predictions."""
+    if model == "composite":
+        case = "composite_N140"
+        spec = golden_spec(case)
+        X, y, Xs, theta = (GOLD[f"{case}/{k}"] for k in ("X", "y", "Xs", "theta"))
+        reps = 9
+        rng = np.random.default_rng(1)
+        X = np.concatenate([X] * reps)
+        X[:, spec["idx_cont"]] += 0.05 * rng.standard_normal((len(X), len(spec["idx_cont"])))
+        y = np.concatenate([y] * reps) + 0.1 * rng.standard_normal(len(X))
+    else:
+        N, d = 3000, 6
+        X, y, ls = O.synthetic_table(N, d, seed=3)
+        ard = model == "matern_ard"
+        spec = O.make_spec(d, range(d), kind="Matern52" if ard else "ExpQuad", ard=ard)
+        theta = O.pack_theta(spec, ls if ard else [1.3], 1.2, 0.25)
+        Xs = np.random.default_rng(2).standard_normal((300, d))
+    runs = []
+    for fresh in range(2):
+        eng = make_engine(spec, theta, X, y)
+        for _ in range(2):
+            eng.factorize()
+            val, g = eng.nlml(grad=True)
+            mu, var = eng.predict(Xs)
+            runs.append((np.float64(val).tobytes(), g.tobytes(), mu.tobytes(), var.tobytes()))
+        eng.close()
+    assert all(r == runs[0] for r in runs[1:])
+
+
+def test_map_fits_are_bit_reproducible(gpu):
+    """Two ``find_MAP`` runs of the same model trace the same objective values bit for bit and end at the same theta."""
+    import pandas as pd
+
+    import gumbi_amd as gmb
+
+    X, y, _ = O.synthetic_table(2500, 3, seed=6)
+    df = pd.DataFrame(X, columns=["a", "b", "c"])
+    df["y"] = y
+    traces = []
+    for _ in range(2):
+        gp = gmb.GP(gmb.DataSet(df, outputs=["y"]), outputs=["y"])
+        gp.fit(continuous_dims=["a", "b", "c"], continuous_kernel="Matern32")
+        traces.append((np.array(gp.nlml_trace).tobytes(), gp._theta_fitted.tobytes(), gp.n_eval))
+        gp.engine.close()
+    assert traces[0] == traces[1] and traces[0][2] > 5
+
+
+@pytest.mark.parametrize("N", [2100, 5000])
+def test_cholesky_schedules_agree(gpu, N):
+    """``GMB_CHOL_SCHEME`` -- one of the three environment switches the product library keeps (plain recursion
+    on one stream / masked look-ahead with the panel chain beside the CU-masked trailing updates): the two
+    schedules order the same trailing updates differently, so factor, v and NLML agree to rounding, and both
+    with the oracle."""
+    d = 5
+    X, y, ls = O.synthetic_table(N, d, seed=12)
+    spec = O.make_spec(d, range(d), kind="Matern32")
+    theta = O.pack_theta(spec, ls, 0.9, 0.2)
+    got = {}
+    try:
+        for scheme in ("0", "2"):
+            os.environ["GMB_CHOL_SCHEME"] = scheme
+            eng = make_engine(spec, theta, X, y)
+            eng.factorize()
+            got[scheme] = (np.tril(eng.copy_factor()), eng.copy_v(), eng.nlml())
+            eng.close()
+    finally:
+        os.environ.pop("GMB_CHOL_SCHEME", None)
+    L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
+    for scheme in got:
+        assert rel(got[scheme][0], L_ref) < 1e-10 and rel(got[scheme][1], v_ref) < 1e-10
+    assert rel(got["0"][0], got["2"][0]) < 1e-12 and abs(got["0"][2] - got["2"][2]) < 1e-9 * abs(got["2"][2])
