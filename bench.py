@@ -524,7 +524,7 @@ def end_to_end_fit(cfg, local_rank, map_evals):
 # -----------------------------------------------------------------------------------------------------
 COMM_KEYS = ("dist_world", "dist_chol_collectives", "dist_chol_comm_bytes", "dist_chol_comm_ms", "dist_chol_comm_exposed_ms",
              "dist_chol_main_wait_ms", "dist_chol_bulk_wait_ms", "dist_grad_collectives", "dist_grad_comm_bytes",
-             "dist_grad_comm_ms", "dist_grad_comm_exposed_ms")
+             "dist_grad_comm_ms", "dist_grad_comm_exposed_ms", "dist_lockstep_repairs")
 
 
 def comm_block(tm, eng, transport, clock):
@@ -544,6 +544,8 @@ def comm_block(tm, eng, transport, clock):
         "comm_ms_total": round(tm["dist_chol_comm_ms"] + tm["dist_grad_comm_ms"], 3),
         "comm_ms_exposed": round(tm["dist_chol_comm_exposed_ms"] + tm["dist_grad_comm_exposed_ms"], 3),
         "per": "one factorisation + one gradient evaluation (the last of the run), rank 0; *_max = maximum over the ranks",
+        # ranks whose redundantly computed (failure index, log-det, |v|^2) differed from rank 0's and were overwritten: 0 expected
+        "lockstep_repairs": int(tm["dist_lockstep_repairs"]),
         "factorize": {"collectives": int(tm["dist_chol_collectives"]), "received_GB": round(tm["dist_chol_comm_bytes"] / 1e9, 3),
                       "comm_ms": round(tm["dist_chol_comm_ms"], 3), "comm_ms_exposed": round(tm["dist_chol_comm_exposed_ms"], 3),
                       "comm_ms_max": round(chol_ms, 3), "comm_ms_exposed_max": round(chol_exp, 3),

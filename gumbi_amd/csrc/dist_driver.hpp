@@ -203,15 +203,27 @@ int dist_check_comm(gmb_engine* e, const gmb_comm* comm) {
 // the collective sequence: a failing rank keeps issuing the remaining all-gathers of the plan (on whatever its
 // buffers hold) and (iii) agree on the outcome once more at the end, so that every rank returns an error when
 // any rank failed.
-int dist_agree(gmb_engine* e, const gmb_comm* comm, int mine, const char* where) {
+// `payload` (optional, npayload <= DIST_MAX_PAYLOAD doubles): scalars every rank computed REDUNDANTLY and on which
+// the callers' control flow depends (the factorisation's failure index, log-determinant, |v|^2 -> the NLML an
+// optimiser compares between steps).  They are bit-identical by construction -- the same deterministic kernels on
+// the same gathered bits -- but an optimiser running in lock step on every rank must never depend on that: all
+// ranks leave with RANK 0's copy, and *repairs counts the ranks whose own copy differed (0 unless something
+// -- a cosmic ray, a driver bug -- broke the redundancy; reported as gmb_timings.dist_lockstep_repairs).
+int dist_agree(gmb_engine* e, const gmb_comm* comm, int mine, const char* where, double* payload = nullptr,
+               int npayload = 0, int64_t* repairs = nullptr) {
   if (comm->world == 1) return mine;
-  const double v = (double)mine;
-  double all[DIST_MAX_WORLD];
-  hipError_t st = hipMemcpyAsync(e->dstat, &v, sizeof(double), hipMemcpyHostToDevice, e->stream);
-  if (st == hipSuccess) st = hipStreamSynchronize(e->stream);  // v lives on this frame
-  int32_t tr = comm->all_gather(comm->ctx, e->dstat, e->dstat + 8, 1, (void*)e->stream);
+  if (npayload > DIST_MAX_PAYLOAD) npayload = DIST_MAX_PAYLOAD;
+  const int w = 1 + npayload;  // words per rank: [status | payload]
+  std::vector<double> mineb((size_t)w), all((size_t)w * comm->world);
+  mineb[0] = (double)mine;
+  for (int i = 0; i < npayload; ++i) mineb[1 + i] = payload[i];
+  double* dsend = e->dstat;
+  double* drecv = e->dstat + (1 + DIST_MAX_PAYLOAD);
+  hipError_t st = hipMemcpyAsync(dsend, mineb.data(), w * sizeof(double), hipMemcpyHostToDevice, e->stream);
+  if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+  int32_t tr = comm->all_gather(comm->ctx, dsend, drecv, w, (void*)e->stream);
   if (st == hipSuccess && tr == 0)
-    st = hipMemcpyAsync(all, e->dstat + 8, comm->world * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    st = hipMemcpyAsync(all.data(), drecv, all.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream);
   if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
   if (st != hipSuccess || tr != 0) {
     (void)hipGetLastError();
@@ -220,12 +232,19 @@ int dist_agree(gmb_engine* e, const gmb_comm* comm, int mine, const char* where)
                 hipGetErrorString(st));
   }
   for (int q = 0; q < comm->world; ++q)
-    if (all[q] != 0.0) {
-      const int code = (int)all[q];
+    if (all[(size_t)q * w] != 0.0) {
+      const int code = (int)all[(size_t)q * w];
       if (q == comm->rank) return mine;  // this rank's own message is already in e->err
       return fail(e, code, "%s: rank %d of %d failed with status %d; no rank has a usable result", where, q, comm->world,
                   code);
     }
+  if (npayload > 0) {
+    int64_t differ = 0;
+    for (int q = 1; q < comm->world; ++q)
+      if (std::memcmp(&all[(size_t)q * w + 1], &all[1], npayload * sizeof(double)) != 0) ++differ;
+    for (int i = 0; i < npayload; ++i) payload[i] = all[1 + i];
+    if (repairs) *repairs += differ;
+  }
   return GMB_OK;
 }
 
@@ -386,7 +405,11 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   } else if (tc) {
     tc->stop();
   }
-  rc = dist_agree(e, comm, bad.give(e), "gmb_dist_factorize");  // synchronises the main stream
+  double shared[3] = {(double)info, hs[0], hs[1]};  // every rank factored every square itself: identical by construction
+  rc = dist_agree(e, comm, bad.give(e), "gmb_dist_factorize", shared, 3, &tm.dist_lockstep_repairs);  // synchronises the main stream
+  info = (int32_t)shared[0];
+  hs[0] = shared[1];
+  hs[1] = shared[2];
   if (rc) {
     (void)hipStreamSynchronize(bulkS);
     e->evs.clear();  // (their events leak on this path; the engine is unusable anyway)

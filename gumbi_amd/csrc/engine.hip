@@ -38,7 +38,8 @@ using namespace gmb;
 
 namespace {
 
-constexpr int DIST_MAX_WORLD = 64;  // ranks one GP can be spread over (status words of gmb_dist_*)
+constexpr int DIST_MAX_WORLD = 64;   // ranks one GP can be spread over (status words of gmb_dist_*)
+constexpr int DIST_MAX_PAYLOAD = 7;  // scalars that travel with a status word (dist_agree)
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -183,7 +184,7 @@ struct gmb_engine {
   int64_t cap_send = 0, cap_recv = 0;
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
-  double* dstat = nullptr;  // status words the ranks exchange: [0] this rank's, [8 .. 8 + world) everybody's
+  double* dstat = nullptr;  // status words (+ payload) the ranks exchange: this rank's, then everybody's (dist_agree)
   std::vector<hipEvent_t> time_pool;  // timing events of the multi-GPU driver's communication probes
   size_t time_next = 0;
 };
@@ -415,7 +416,12 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
       }
     }
   }
-  static const int BMs[4] = {128, 64, 128, 128}, BNs[4] = {128, 64, 64, 32};
+#ifdef GMB_TUNING
+  // A/B only: variant 4 = a 256 x 128 macro-tile, eight waves (4 x 2), ONE workgroup per compute
+  // unit -- the same two waves per SIMD, half the B-panel traffic per flop; m-tile counts must be even
+  if (e->force_variant && e->gemm_variant == 4 && !in_place) variant = (g_in.mt % 2 == 0) ? 4 : 0;
+#endif
+  static const int BMs[5] = {128, 64, 128, 128, 256}, BNs[5] = {128, 64, 64, 32, 128};
   const int bm = BMs[variant], bn = BNs[variant];
   g.mt = g_in.mt * TILE / bm;
   g.nt = g_in.nt * TILE / bn;
@@ -434,6 +440,9 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   const bool pfc = g.beta != 0.0 && g.k <= 1024 && !in_place;
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, g); break;
+#ifdef GMB_TUNING
+    case 4: hipLaunchKernelGGL((gemm_f64_kernel<4, 2, 4, 4, 1>), grid, dim3(512), 0, e->cur, g); break;
+#endif
     // small tiles with a short contraction and beta != 0: the C-prefetching instantiations (gemm_f64.hpp)
     case 1:
       if (pfc) hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 2, 2, 2, true>), grid, dim3(256), 0, e->cur, g);
@@ -1531,7 +1540,7 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
 #ifdef GMB_TUNING
   e->small_tiles = flag("GMB_SMALL_TILES", true);
   const char* gv = getenv("GMB_GEMM_VARIANT");  // pins the tile shape of every out-of-place GEMM: 0 .. 3
-  if (gv && gv[0] >= '0' && gv[0] <= '3') {
+  if (gv && gv[0] >= '0' && gv[0] <= '4') {
     e->gemm_variant = gv[0] - '0';
     e->force_variant = true;
   }
@@ -1586,7 +1595,7 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->wg_slots = 2LL * prop.multiProcessorCount;
   if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&e->dstat, (8 + DIST_MAX_WORLD) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&e->dstat, (size_t)(1 + DIST_MAX_PAYLOAD) * (1 + DIST_MAX_WORLD) * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
     gmb_destroy(e);
     return GMB_ENOMEM;
@@ -2079,7 +2088,9 @@ static int mfma_f64_run(int32_t device, double seconds, int iters, double* mean_
     }
     sum_ms += ms;
     worst_ms = std::max(worst_ms, (double)ms);
-    sum_mhz += hsink[1] / ((double)ms * 1e3);  // block 0's loop spans (almost) the whole launch
+    // block 0's loop spans (almost) the whole launch.  s_memtime ticks once per TWO shader cycles on gfx950
+    // (measured: 1187 MHz of counter beside 77.8 TFLOP/s, i.e. 2375 MHz of matrix-pipe issue at 64 cycles per MFMA)
+    sum_mhz += 2.0 * hsink[1] / ((double)ms * 1e3);
     sum_cyc += hsink[1] / ((double)iters * 16.0);
     ++n;
   } while (sum_ms < seconds * 1e3);

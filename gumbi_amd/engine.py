@@ -94,6 +94,7 @@ class Timings(C.Structure):
         ("dist_grad_comm_bytes", C.c_double),
         ("dist_grad_comm_ms", C.c_double),
         ("dist_grad_comm_exposed_ms", C.c_double),
+        ("dist_lockstep_repairs", C.c_int64),
     ]
 
     def as_dict(self):

@@ -148,6 +148,10 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
   double dist_grad_comm_bytes;
   double dist_grad_comm_ms;
   double dist_grad_comm_exposed_ms;
+  /* Every rank computes the factorisation's failure index, log-determinant and |v|^2 redundantly (bit-identical by
+     construction); all ranks nevertheless LEAVE gmb_dist_factorize with rank 0's copy, so that optimisers running in
+     lock step on every rank can never part company.  Cumulative count of ranks whose own copy differed (expected 0). */
+  int64_t dist_lockstep_repairs;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;
@@ -231,7 +235,8 @@ int gmb_timings_get(const gmb_engine* e, gmb_timings* out);
  * cycles one wave spends per MFMA (64 = the datasheet issue rate; wall rate / this = clock). */
 int gmb_mfma_f64_peak(int32_t device, double* tflops, double* cycles_per_mfma);
 /* The same register-only loop launched back to back for `seconds` (<= 60; 37 ms per launch): mean and worst
- * per-launch rate and the shader clock in MHz the loop ran at (s_memtime span / launch duration) -- the sustained
+ * per-launch rate and the shader clock in MHz the loop ran at (2 x s_memtime span / launch duration: the counter
+ * ticks every second shader cycle on gfx950) -- the sustained
  * ceiling under the box's power management, to be sampled before AND after a timed region. */
 int gmb_mfma_f64_sustained(int32_t device, double seconds, double* mean_tflops, double* min_tflops,
                            double* shader_mhz, int64_t* launches);

@@ -394,6 +394,20 @@ def _fit_task(rank, world, group, out, N, d, ls_lower):
     def fit(distributed):
         ds = gmb.DataSet(df, outputs=["y"])
         gp = gmb.GP(ds, outputs=["y"], distributed=distributed)
+        trace_dir = os.environ.get("GUMBI_TEST_TRACE")
+        if trace_dir and distributed is not None:  # debugging aid: what every rank was given and returned, per evaluation
+            import hashlib
+
+            fh = open(os.path.join(trace_dir, f"fit_N{N}_rank{rank}.log"), "w")
+            orig = gp._objective
+
+            def traced(u, pos):
+                f, g = orig(u, pos)
+                fh.write(f"{hashlib.sha1(np.asarray(u).tobytes()).hexdigest()[:10]} {float(f)!r} {hashlib.sha1(np.asarray(g).tobytes()).hexdigest()[:10]}\n")
+                fh.flush()
+                return f, g
+
+            gp._objective = traced
         lsb = gmb.make_deltas_parray(stdzr=ds.stdzr, scale="standardized", **{c: [ls_lower, None] for c in cols}) if ls_lower else None
         gp.fit(continuous_dims=cols, ls_bounds=lsb)  # the user-level call: specify_model + build_model + find_MAP
         pred = gp.predict_points(gp.parray(**{c: grid[:, k] for k, c in enumerate(cols)}))
