@@ -141,35 +141,36 @@ __device__ __forceinline__ double exp_interior(double x) {
   const double k = t - magic;
   double r = fma(-k, 6.93147180369123816490e-01, x);
   r = fma(-k, 1.90821492927058770002e-10, r);
-  // degree-11 minimax polynomial of exp on |r| <= 0.34665 (relative error 3.1e-18 before rounding; Remez in
-  // 80-digit arithmetic, coefficients rounded to double; against long-double exp over 3e7 arguments in [-700, 0]
-  // the whole function stays below 0.98 ulp -- the degree-13 Taylor form of exp_nonpos: 0.89 ulp)
-  double p = 0x1.ad65ffe4d4e0dp-26;
-  p = fma(p, r, 0x1.28b328f7eba37p-22);
-  p = fma(p, r, 0x1.71df455cd7abcp-19);
-  p = fma(p, r, 0x1.a01992b813c66p-16);
-  p = fma(p, r, 0x1.a01a011026885p-13);
-  p = fma(p, r, 0x1.6c16c1878a4f7p-10);
-  p = fma(p, r, 0x1.1111111130ebcp-7);
-  p = fma(p, r, 0x1.555555554f344p-5);
-  p = fma(p, r, 0x1.55555555554a2p-3);
-  p = fma(p, r, 0x1.0000000000010p-1);
+  // degree-10 minimax polynomial of exp on |r| <= 0.34665 with p(0) = p'(0) = 1 (weighted Remez in 60-digit arithmetic,
+  // coefficients rounded to double): 2.9e-16 relative before rounding, <= 4 ulp in double Horner form against long-double
+  // exp.  Interior tiles only: their r^2 comes from the expansion |x|^2 + |x'|^2 - 2 x.x', whose own rounding
+  // (~eps |x/ls|^2 absolute in r^2, i.e. tens of ulp in k) is what bounds the entry -- the degree-11 polynomial that kept
+  // exp itself below 0.98 ulp (round 2) bought nothing there and cost one more issue slot per entry.  The direct-form
+  // tiles (diagonal, boundary, kinked kernels) keep exp_nonpos.
+  double p = 0x1.2707a770dc38cp-22;
+  p = fma(p, r, 0x1.72e91aefc6956p-19);
+  p = fma(p, r, 0x1.a01b7c4deaf70p-16);
+  p = fma(p, r, 0x1.a0198d585c94ap-13);
+  p = fma(p, r, 0x1.6c16c0c831ce8p-10);
+  p = fma(p, r, 0x1.11111125b3e47p-7);
+  p = fma(p, r, 0x1.55555555890bfp-5);
+  p = fma(p, r, 0x1.55555555507c5p-3);
+  p = fma(p, r, 0x1.ffffffffffed2p-2);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   const int hi = __double2hiint(p) + (__double2loint(t) << 20);
   return __hiloint2double(hi, __double2loint(p));
 }
 
-// sqrt(p), p >= 1e-12 finite: sqrt_pos without the refinement of h (its error enters the last correction
-// only to second order)
+// sqrt(p), p >= 1e-12 finite: hardware rsq estimate (~26 bits) and ONE coupled Goldschmidt step -- ~2 ulp.  The residual
+// correction of sqrt_pos (two more slots) would bring it to <= 1 ulp; on interior tiles p already carries the
+// expansion's rounding (see exp_interior), which is an order of magnitude above that.
 __device__ __forceinline__ double sqrt_interior(double p) {
   const double y = __builtin_amdgcn_rsq(p);
-  double g = p * y;
+  const double g = p * y;
   const double h = 0.5 * y;
   const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  const double d = fma(-g, g, p);
-  return fma(d, h, g);
+  return fma(g, r, g);
 }
 
 // eta2 * k(r2) from the contraction's output q: q = -r2/2 for ExpQuad (the -1/2 rides in the operands),
@@ -180,8 +181,8 @@ __device__ __forceinline__ double stationary_interior(double q, double eta2) {
   if constexpr (KIND == 0) {
     return eta2 * exp_interior(fmin(q, 0.0));
   } else {
-    const double p = fmax(q + 1e-12, 1e-12);  // = max(q, 0) + 1e-12; the sum first, so that fmax sees an arithmetic
-                                              // result and needs no canonicalising v_max of its own
+    const double p = fmax(q, 1e-12);  // q = r^2 + 1e-12 already (the offset rides in the accumulator's row norm), so this
+                                      // is max(r^2, 0) + 1e-12: PyMC's clip and its sqrt(r^2 + 1e-12) in one slot
     const double r = sqrt_interior(p);
     if constexpr (KIND == 1) {
       const double s5 = 2.23606797749978969641;
@@ -320,6 +321,7 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
   const int r16 = lane & 15, kq = lane >> 4;
   constexpr double sc = KIND == 0 ? 1.0 : -2.0;  // scale of the column point's coordinates
   constexpr double sn = KIND == 0 ? -0.5 : 1.0;  // scale of both squared norms
+  constexpr double off12 = KIND == 0 ? 0.0 : 1e-12;  // PyMC's sqrt(r^2 + 1e-12): the offset enters with the row norm
   double brow[2][NG], nrow[2];
 #pragma unroll
   for (int ib = 0; ib < 2; ++ib) {
@@ -328,11 +330,11 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
     for (int g = 0; g < NG; ++g) {
       const int k = 4 * g + kq;
       double v = k < (NORM_IN_C ? NC : NC + 1) ? src[(int64_t)k * a.rows.npad] : 0.0;
-      if (!NORM_IN_C && k == NC) v *= sn;
+      if (!NORM_IN_C && k == NC) v = fma(v, sn, off12);  // the row norm's slot meets the column operand's constant 1
       if (!NORM_IN_C && k == NC + 1) v = 1.0;
       brow[ib][g] = v;
     }
-    nrow[ib] = NORM_IN_C ? sn * src[(int64_t)NC * a.rows.npad] : 0.0;  // this lane's row (r16 of block ib)
+    nrow[ib] = NORM_IN_C ? fma(sn, src[(int64_t)NC * a.rows.npad], off12) : 0.0;  // this lane's row (r16 of block ib)
   }
   // column operand of one 16-column block: coordinate k of the column point (augmented form: slot NC is the
   // constant 1, slot NC + 1 the norm, row NC of xs); NORM_IN_C: the norms of the lane's 4 columns kq + 4 r

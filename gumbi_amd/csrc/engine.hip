@@ -1150,12 +1150,13 @@ int winv_level_batched(gmb_engine* e, const gmb_engine::InvLevelPlan& lp) {
 template <int KIND>
 int launch_grad_nc(gmb_engine* e, const GradArgs& a, int nblocks) {
   const dim3 grid(nblocks), block(256);
+  const size_t lds = grad_lds_bytes(e->nc_pad, a.p.n_lin, a.p.n_tab);
   switch (e->nc_pad) {
-    case 1: hipLaunchKernelGGL((grad_tile_kernel<KIND, 1>), grid, block, 0, e->stream, a); break;
-    case 2: hipLaunchKernelGGL((grad_tile_kernel<KIND, 2>), grid, block, 0, e->stream, a); break;
-    case 4: hipLaunchKernelGGL((grad_tile_kernel<KIND, 4>), grid, block, 0, e->stream, a); break;
-    case 8: hipLaunchKernelGGL((grad_tile_kernel<KIND, 8>), grid, block, 0, e->stream, a); break;
-    default: hipLaunchKernelGGL((grad_tile_kernel<KIND, 16>), grid, block, 0, e->stream, a); break;
+    case 1: hipLaunchKernelGGL((grad_tile_kernel<KIND, 1>), grid, block, lds, e->stream, a); break;
+    case 2: hipLaunchKernelGGL((grad_tile_kernel<KIND, 2>), grid, block, lds, e->stream, a); break;
+    case 4: hipLaunchKernelGGL((grad_tile_kernel<KIND, 4>), grid, block, lds, e->stream, a); break;
+    case 8: hipLaunchKernelGGL((grad_tile_kernel<KIND, 8>), grid, block, lds, e->stream, a); break;
+    default: hipLaunchKernelGGL((grad_tile_kernel<KIND, 16>), grid, block, lds, e->stream, a); break;
   }
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -1214,9 +1215,9 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
   const int n_ls = s.ard ? s.n_cont : 1;
   long long total = 0;
   for (int i = shard; i < nt; i += nshards) total += i + 1;
-  // persistent workgroups: four per compute unit, each reduces a contiguous run of `per` tiles in registers / LDS
+  // persistent workgroups: six per compute unit, each reduces a contiguous run of `per` tiles in registers / LDS
   // and writes ONE partial vector; a second launch adds the vectors in a fixed order (bit-reproducible results)
-  const long long want = std::max<long long>(1, 2 * e->wg_slots);
+  const long long want = std::max<long long>(1, 3 * e->wg_slots);  // 6 workgroups per compute unit: one resident round
   const int per = (int)std::max<long long>(1, (total + want - 1) / want);
   const int grid = (int)((total + per - 1) / per);
   const int ncp = e->nc_pad;

@@ -56,23 +56,32 @@ struct GradArgs {
 
 constexpr int GRAD_SMALL = 16 + 2 + MAX_LIN;                 // ls.. | eta | tau | c..
 constexpr int GRAD_MAX_LDS_ACC = GRAD_SMALL + MAX_TABS * 64;  // + tables up to 8 levels
+// dynamic LDS of grad_tile_kernel<KIND, NC> for a model with n_lin linear dims and n_tab coregion tables
+inline size_t grad_lds_bytes(int nc, int n_lin, int n_tab) {
+  return sizeof(double) * ((size_t)nc * TILE + TILE + 4 * GRAD_SMALL + 2 * (size_t)n_lin * TILE + 4 * (size_t)n_tab * 64) +
+         sizeof(int32_t) * 2 * (size_t)n_tab * TILE;
+}
 
 template <int KIND, int NC>
 __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
-  __shared__ double xj[NC][TILE];
-  __shared__ double lj[MAX_LIN][TILE];
-  __shared__ double li[MAX_LIN][TILE];
-  __shared__ int32_t cj[MAX_TABS][TILE];
-  __shared__ int32_t ci[MAX_TABS][TILE];
-  __shared__ double aj[TILE];
-  __shared__ double swave[4][GRAD_SMALL];       // per-wave sums of the register accumulators
-  __shared__ double stab[4][MAX_TABS * 64];     // per-wave copies of the small coregion-table accumulators
+  // LDS sized by the model (grad_lds_bytes): the plain stationary case keeps 8 workgroups per compute unit
+  // (10 KB each at d = 8); static arrays for the largest model cost 41 KB and two thirds of the occupancy
+  extern __shared__ double grad_dsm[];
+  const CovParams& p = a.p;
+  double* const xj = grad_dsm;                             // [NC][TILE]
+  double* const aj = xj + NC * TILE;                       // [TILE]
+  double* const swave = aj + TILE;                         // [4][GRAD_SMALL]  per-wave sums of the register accumulators
+  double* const lj = swave + 4 * GRAD_SMALL;               // [n_lin][TILE]
+  double* const li = lj + p.n_lin * TILE;                  // [n_lin][TILE]
+  double* const stab = li + p.n_lin * TILE;                // [4][n_tab * 64]  per-wave copies of the small coregion tables
+  int32_t* const cj = reinterpret_cast<int32_t*>(stab + 4 * p.n_tab * 64);  // [n_tab][TILE]
+  int32_t* const ci = cj + p.n_tab * TILE;                 // [n_tab][TILE]
 
   const int tid = threadIdx.x, wave = tid >> 6;
   const int il = tid & (TILE - 1), jh = tid >> 7;
-  const CovParams& p = a.p;
   const int n_acc_small = NC + 2 + p.n_lin;
-  for (int idx = tid; idx < 4 * MAX_TABS * 64; idx += 256) (&stab[0][0])[idx] = 0.0;
+  const int tabw = p.n_tab * 64;
+  for (int idx = tid; idx < 4 * tabw; idx += 256) stab[idx] = 0.0;
 
   double g_ls[NC];
 #pragma unroll
@@ -105,17 +114,17 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
     __syncthreads();  // the previous tile's readers are done with the staged coordinates
     for (int idx = tid; idx < NC * TILE; idx += 256) {
       const int k = idx / TILE, j = idx - k * TILE;
-      xj[k][j] = a.pts.xs[(int64_t)k * a.pts.npad + gj0 + j];
+      xj[k * TILE + j] = a.pts.xs[(int64_t)k * a.pts.npad + gj0 + j];
     }
     for (int idx = tid; idx < p.n_lin * TILE; idx += 256) {
       const int k = idx / TILE, j = idx - k * TILE;
-      lj[k][j] = a.pts.xl[(int64_t)k * a.pts.npad + gj0 + j];
-      li[k][j] = a.pts.xl[(int64_t)k * a.pts.npad + gi0 + j];
+      lj[k * TILE + j] = a.pts.xl[(int64_t)k * a.pts.npad + gj0 + j];
+      li[k * TILE + j] = a.pts.xl[(int64_t)k * a.pts.npad + gi0 + j];
     }
     for (int idx = tid; idx < p.n_tab * TILE; idx += 256) {
       const int t = idx / TILE, j = idx - t * TILE;
-      cj[t][j] = a.pts.cat[(int64_t)t * a.pts.npad + gj0 + j];
-      ci[t][j] = a.pts.cat[(int64_t)t * a.pts.npad + gi0 + j];
+      cj[t * TILE + j] = a.pts.cat[(int64_t)t * a.pts.npad + gj0 + j];
+      ci[t * TILE + j] = a.pts.cat[(int64_t)t * a.pts.npad + gi0 + j];
     }
     if (tid < TILE) aj[tid] = (gj0 + tid < a.pts.n) ? a.alpha[gj0 + tid] : 0.0;
     double xi[NC];
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
         double r2 = 0.0;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-          const double d = xi[k] - xj[k][jb + jj];
+          const double d = xi[k] - xj[k * TILE + jb + jj];
           d2[k] = d * d;
           r2 += d2[k];
         }
@@ -160,17 +169,17 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
       double r2 = 0.0;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
-        const double d = xi[k] - xj[k][j];
+        const double d = xi[k] - xj[k * TILE + j];
         d2[k] = d * d;
         r2 += d2[k];
       }
       const double ks = stationary<KIND>(r2);
       const double dk = p.eta2 * stationary_dr2<KIND>(r2);
       double lin = 0.0;
-      for (int k = 0; k < p.n_lin; ++k) lin = fma(li[k][il], lj[k][j], lin);
+      for (int k = 0; k < p.n_lin; ++k) lin = fma(li[k * TILE + il], lj[k * TILE + j], lin);
       double F = 1.0;
       for (int t = 0; t < p.n_tab; ++t)
-        F *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
+        F *= p.tabs[p.tab_off[t] + ci[t * TILE + il] * p.tab_levels[t] + cj[t * TILE + j]];
       const double mF = mm * F;
       // d r2 / d ls_k = -2 d2_k / ls_k   (d2 already in scaled units)
 #pragma unroll
@@ -180,24 +189,24 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
         g_tau = fma(mF, lin, g_tau);
 #pragma unroll
         for (int k = 0; k < MAX_LIN; ++k)
-          if (k < p.n_lin) g_c[k] = fma(-mF * p.tau, li[k][il] + lj[k][j], g_c[k]);
+          if (k < p.n_lin) g_c[k] = fma(-mF * p.tau, li[k * TILE + il] + lj[k * TILE + j], g_c[k]);
       }
       if (p.n_tab > 0) {
         const double base = p.eta2 * ks + p.tau * lin;
         for (int t = 0; t < p.n_tab; ++t) {
           double others = 1.0;
           for (int t2 = 0; t2 < p.n_tab; ++t2)
-            if (t2 != t) others *= p.tabs[p.tab_off[t2] + ci[t2][il] * p.tab_levels[t2] + cj[t2][j]];
+            if (t2 != t) others *= p.tabs[p.tab_off[t2] + ci[t2 * TILE + il] * p.tab_levels[t2] + cj[t2 * TILE + j]];
           const int L = p.tab_levels[t];
           const double val = mfull * base * others;
           // ordered pair (i,j) feeds G[a][b]; its mirror (j,i) feeds G[b][a] (off-diagonal only).  The copies
           // are private to this wave: lanes of one instruction that hit the same entry are served in the
           // hardware's fixed lane order, and no other wave ever adds into them.
-          const int ca = ci[t][il], cb = cj[t][j];
+          const int ca = ci[t * TILE + il], cb = cj[t * TILE + j];
           const bool off = gi != gj;
           if (L <= 8) {
-            atomicAdd(&stab[wave][t * 64 + ca * L + cb], val);
-            if (off) atomicAdd(&stab[wave][t * 64 + cb * L + ca], val);
+            atomicAdd(&stab[wave * tabw + t * 64 + ca * L + cb], val);
+            if (off) atomicAdd(&stab[wave * tabw + t * 64 + cb * L + ca], val);
           } else {
             double* bt = a.big + ((int64_t)blockIdx.x * 4 + wave) * a.big_stride + a.big_off[t];
             atomicAdd(&bt[ca * L + cb], val);
@@ -222,27 +231,27 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const double v = wave_sum(g_ls[k]);
-    if ((tid & 63) == 0) swave[wave][k] = v;
+    if ((tid & 63) == 0) swave[wave * GRAD_SMALL + k] = v;
   }
   {
     const double v = wave_sum(g_eta), u = wave_sum(g_tau);
     if ((tid & 63) == 0) {
-      swave[wave][NC] = v;
-      swave[wave][NC + 1] = u;
+      swave[wave * GRAD_SMALL + NC] = v;
+      swave[wave * GRAD_SMALL + NC + 1] = u;
     }
   }
 #pragma unroll
   for (int k = 0; k < MAX_LIN; ++k) {
     if (k < p.n_lin) {
       const double v = wave_sum(g_c[k]);
-      if ((tid & 63) == 0) swave[wave][NC + 2 + k] = v;
+      if ((tid & 63) == 0) swave[wave * GRAD_SMALL + NC + 2 + k] = v;
     }
   }
   __syncthreads();
   double* out = a.part + (int64_t)blockIdx.x * a.part_stride;
-  if (tid < n_acc_small) out[tid] = (swave[0][tid] + swave[1][tid]) + (swave[2][tid] + swave[3][tid]);
-  for (int idx = tid; idx < p.n_tab * 64; idx += 256)
-    out[n_acc_small + idx] = (stab[0][idx] + stab[1][idx]) + (stab[2][idx] + stab[3][idx]);
+  if (tid < n_acc_small) out[tid] = (swave[tid] + swave[GRAD_SMALL + tid]) + (swave[2 * GRAD_SMALL + tid] + swave[3 * GRAD_SMALL + tid]);
+  for (int idx = tid; idx < tabw; idx += 256)
+    out[n_acc_small + idx] = (stab[idx] + stab[tabw + idx]) + (stab[2 * tabw + idx] + stab[3 * tabw + idx]);
 }
 
 // Second stage: out[dst(q)] = sum over the nparts partial vectors of slot q, in a FIXED order (thread t adds parts

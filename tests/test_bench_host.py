@@ -82,3 +82,62 @@ def test_configs_name_the_baseline_workloads():
     assert bench.CONFIGS["c3"]["N"] == 50_000 and bench.CONFIGS["c3"]["d"] == 8 and bench.CONFIGS["c3"]["kernel"] == "Matern52"
     assert bench.CONFIGS["c2"]["N"] == 10_000 and bench.CONFIGS["c2"]["d"] == 4
     assert bench.CONFIGS["c5"]["d"] == 8 and bench.CONFIGS["c5"]["kernel"] == "ExpQuad"
+
+
+def test_truth_matches_the_table_and_fit_quality_sees_a_fit(monkeypatch):
+    """``fit_quality`` -- what the bench line says about the fit it timed -- on the numpy oracle behind the same host
+    code: the declared model (``ls_bounds`` through ``make_deltas_parray``) converges to the generator's function and
+    noise level on a small table; the PyMC-default declaration on the same table is reported for what it is."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from gumbi_amd.regression import hip_gp
+    from oracle_engine import OracleEngine
+
+    bench = load_bench()
+    monkeypatch.setattr(hip_gp, "Engine", OracleEngine)
+    cfg = dict(bench.CONFIGS["c2"], N=400, d=2, res=20)
+    # the truth is the generator's noise-free function in the z-scored units of the table's y
+    X, y, ls = bench.synthetic_table(cfg["N"], cfg["d"])
+    f_grid, sigma_z = bench.synthetic_truth(cfg)
+    assert f_grid.shape == (400,) and 0.2 < sigma_z < 0.45
+    resid = y - (np.sum(np.sin(X / ls), axis=1) / np.sqrt(cfg["d"]) - 0.0) / (0.2 / sigma_z)
+    assert abs(np.std(resid - resid.mean(), ddof=1) - sigma_z) < 0.03  # what is left of y after f is the declared noise
+    gp = bench.build_gp(cfg, device=0)  # ls_bounds lower = LS_LOWER_Z
+    assert np.all(gp._initial_theta()[:2] > 1.0)
+    gp.find_MAP()
+    mu, _ = gp.predict(bench.synthetic_grid(cfg["d"], cfg["res"]))
+    q = bench.fit_quality(gp, mu, cfg)
+    assert q["converged"] and q["corr"] > 0.95 and q["sigma_rel_err"] < 0.15 and q["rmse"] < 0.5 * q["rmse_of_predicting_zero"], q
+    assert q["n_eval"] == gp.n_eval and len(q["ls"]) == 2
+    # a mean that ignores the data is reported as such
+    q0 = bench.fit_quality(gp, np.zeros_like(mu), cfg)
+    assert q0["corr"] == 0.0 and abs(q0["rmse"] - q0["rmse_of_predicting_zero"]) < 1e-12
+
+
+def test_time_budget_skips_side_sections_but_says_so(monkeypatch):
+    bench = load_bench()
+    monkeypatch.setenv("GUMBI_BENCH_BUDGET_S", "100")
+    b = bench.Budget()
+    monkeypatch.setattr(bench, "T_PROCESS_START", time.perf_counter() - 70.0)
+    assert b.allows(20.0) and not b.allows(40.0)
+    msg = b.skipped(40.0)["skipped"]
+    assert "time budget" in msg and "100" in msg and "GUMBI_BENCH_BUDGET_S" in msg
+
+
+def test_pmc_traffic_is_marked_stale_when_the_kernels_changed(tmp_path, monkeypatch):
+    """``roofline.traffic`` comes from a committed counter summary; the summary carries the hash of the kernel sources it
+    was taken on (tools/gpu_pmc_bench.sh) and the bench says when that is not the tree's."""
+    bench = load_bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (tmp_path / "gumbi_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "gumbi_amd" / "csrc" / "k.hpp").write_text("kernel v1")
+    (prof / "r99_pmc_bench_cx_summary.csv").write_text(
+        "Kernel,Launches,TotalMs(pass1),MfmaUtil%,MFMA_F64_TFLOPs,FetchGB(x2 corrected),FetchGB/s,WriteGB(raw),WriteGB/s\n"
+        '"void gmb::gemm_f64_kernel<2, 2, 4, 4, 2, false>(gmb::GemmArgs)",10,100.0,90.0,70.0,50.0,500.0,10.0,100.0\n')
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    now = bench.kernel_sources_sha16()
+    (prof / "r99_pmc_bench_cx_summary.meta.json").write_text('{"kernel_sources_sha16": "%s"}' % now)
+    pt = bench.pmc_traffic("cx", "gemm_f64_kernel<2, 2, 4, 4")
+    assert pt["launches"] == 10 and abs(pt["bytes_per_launch"] - 6.0e9) < 1 and pt["stale"] is False
+    (tmp_path / "gumbi_amd" / "csrc" / "k.hpp").write_text("kernel v2")
+    assert bench.pmc_traffic("cx", "gemm_f64_kernel<2, 2, 4, 4")["stale"] is True

@@ -500,6 +500,7 @@ def _rccl_worker(out):
         theta = O.pack_theta(spec, ls, 1.0, 0.25)
         eng = DistributedEngine(0, panel_blocks=2)
         kind = eng.comm.kind
+        assert eng.comm.ranks == 1  # ncclCommCount of the library's own communicator
         eng.set_data(X, y)
         eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d))))
         eng.set_theta(theta)
@@ -510,6 +511,8 @@ def _rccl_worker(out):
         Xs = np.random.default_rng(3).standard_normal((200, d))
         mu, var = eng.predict(Xs)
         mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+        tm = eng.timings()
+        assert tm["dist_world"] == 1 and tm["dist_chol_collectives"] > 0 and tm["dist_lockstep_repairs"] == 0
         out.put((dist.get_backend() + "/" + kind, abs(val - val_r) / abs(val_r), float(np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r)))),
                  float(np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))), float(np.max(np.abs(var - var_r)))))
         eng.close()
