@@ -543,10 +543,13 @@ def test_driver_on_the_rccl_backend_with_one_rank(gpu):
     assert e_val < 1e-10 and e_g < 1e-8 and e_mu < 1e-8 and e_var < 1e-9
 
 
-def test_bench_contract_with_two_ranks_on_one_gpu(gpu):
+@pytest.mark.parametrize("map_evals", [0, 3])
+def test_bench_contract_with_two_ranks_on_one_gpu(gpu, map_evals):
     """bench.py as the driver launches it for N > 1 (``python -m torch.distributed.run --nproc-per-node N
     bench.py --gpus N ...``), with both ranks on the test box's one GPU over gloo: rank 0 prints exactly ONE
-    JSON line with the contract's keys, n_gpus = 2, and the workload is ONE GP partitioned over the ranks."""
+    JSON line with the contract's keys, n_gpus = 2, the workload is ONE GP partitioned over the ranks (fixed
+    hyper-parameters, or a distributed ``find_MAP(maxeval=k)`` with ``--map-evals k``), and the line says what the
+    collectives cost (``comm``) and what the same step does on ONE GPU (``strong_scaling_base_gflops``)."""
     import json
     import subprocess
     import sys
@@ -557,7 +560,7 @@ def test_bench_contract_with_two_ranks_on_one_gpu(gpu):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1"]
+           "--warmup", "1"] + (["--map-evals", str(map_evals)] if map_evals else [])
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -565,18 +568,35 @@ def test_bench_contract_with_two_ranks_on_one_gpu(gpu):
     d = json.loads(lines[0])
     assert "error" not in d, d
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "comm", "transport", "rccl_ranks", "comm_ms_total",
+                "comm_ms_exposed", "strong_scaling_base_gflops", "speedup_over_one_gpu"):
         assert key in d, key
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
     assert d["value"] > 0 and d["results_finite"] and "cpu_baseline" not in d
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert "ONE GP" in d["config"]["workload"] and "over 2 GPUs" in d["config"]["parallelism"]
     assert "torch-gloo" in d["config"]["parallelism"] and d["config"]["N"] == 3000
+    # communication of the last factorisation + gradient: counted, timed, and never more exposed than spent
+    c = d["comm"]
+    assert c["transport"] == d["transport"] == "torch-gloo" and c["world"] == 2 and c["rccl_ranks"] is None
+    assert c["factorize"]["collectives"] > 0 and c["factorize"]["received_GB"] > 0 and c["gradient"]["collectives"] >= 3
+    assert 0 <= c["comm_ms_exposed"] <= c["comm_ms_total"] * (1 + 1e-9) and c["lockstep_repairs"] == 0
+    assert d["comm_ms_total"] == c["comm_ms_total"]
+    # the same step on one GPU, by rank 0 after the timed region
+    base = d["strong_scaling_base"]
+    assert "error" not in base and base["results_finite"] and base["value"] == d["strong_scaling_base_gflops"] > 0
+    assert abs(d["speedup_over_one_gpu"] - d["value"] / base["value"]) < 2e-3
     ph = d["phases"]
-    assert ph["map_eval_s"] > 0 and ph["fit_fixed_theta_s"] > 0 and ph["predict_s"] > 0 and np.isfinite(ph["nlml"])
-    # whole-job value = algorithmic flops of the steps / max-over-ranks wall time
     N, M = 3000, 10_000
-    flops = 2 * (float(N) ** 3 + float(N) ** 3 / 3 + float(N) ** 2 * M + 4.0 * N * M)
+    if map_evals:
+        assert "find_MAP(maxeval=3)" in d["metric"]
+        assert ph["find_map_s"] > 0 and ph["predict_s"] > 0 and all(1 <= n <= 8 for n in ph["map_evals_per_step"])
+        assert ph["refactorizations_at_the_map_per_step"] == [1, 1]  # the distributed gradient consumes the factor
+        flops = sum(n * float(N) ** 3 + float(N) ** 3 / 3 + float(N) ** 2 * M + 4.0 * N * M for n in ph["map_evals_per_step"])
+    else:
+        assert ph["map_eval_s"] > 0 and ph["fit_fixed_theta_s"] > 0 and ph["predict_s"] > 0 and np.isfinite(ph["nlml"])
+        flops = 2 * (float(N) ** 3 + float(N) ** 3 / 3 + float(N) ** 2 * M + 4.0 * N * M)
+    # whole-job value = algorithmic flops of the steps / max-over-ranks wall time
     assert abs(d["value"] - flops / (d["ms_per_step"] * 2e-3) / 1e9) / d["value"] < 1e-3
 
 
@@ -612,6 +632,16 @@ def test_bench_contract_single_process(gpu):
     side = d["c5_single_gpu"]
     assert "error" not in side, side
     assert side["results_finite"] and side["value"] > 0 and "N=2304" in side["workload"]
+    assert d["strong_scaling_base_gflops"] == side["value"]
+    # what the timed fit found (capped at 4 evaluations here, so no quality bar -- only that it is reported)
+    q = d["fit_quality"]
+    assert set(q) >= {"corr", "rmse", "sigma_hat", "sigma_true", "nlml_final", "n_eval", "converged"} and q["n_eval"] == d["config"]["map_evals_per_step"][0]
+    assert "ls_bounds" in d["config"] and "lower = 0.5" in d["config"]["ls_bounds"]
+    ce = r["mfma_only_ceiling"]
+    assert ce["before_timed_region"]["tflops_mean"] > 50 and ce["after_timed_region"]["tflops_mean"] > 50
+    assert ce["before_timed_region"]["seconds"] >= 1.0 and 1500 < ce["after_timed_region"]["shader_mhz"] < 2600
+    assert r["achieved_le_ceiling"] is True
+    assert d["default_start"]["fit_quality"]["n_eval"] >= 1 and d["bench_wall_s"] > 0
 
 
 def test_bench_default_config_is_the_largest_single_gpu_one():

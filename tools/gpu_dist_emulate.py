@@ -86,6 +86,11 @@ for w in widths:
     print(f"  rank {rank} of {G}, panel_blocks={w}: {t * 1e3:.1f} ms = {single / G / t:.2f} of ideal "
           f"({N**3 / 3 / G / t / 1e12:.1f} TF/s per GPU); {comm.calls} all-gathers, {comm.bytes / 1e9:.1f} GB received "
           f"(= {comm.bytes / 1e9 / 300:.3f} s at 300 GB/s if not hidden)", flush=True)
+    tm = eng.timings()  # communication probes of the last (unprofiled) run: what the streams waited for
+    print(f"    probes: {int(tm['dist_chol_collectives'])} collectives, {tm['dist_chol_comm_bytes'] / 1e9:.1f} GB, in collectives "
+          f"{tm['dist_chol_comm_ms']:.1f} ms (device copies here), of it exposed {tm['dist_chol_comm_exposed_ms']:.1f} ms; main stream "
+          f"waited {tm['dist_chol_main_wait_ms']:.1f} ms for U2 at the JOINs, bulk stream waited {tm['dist_chol_bulk_wait_ms']:.1f} ms for the "
+          f"panel chain at the FORKs (chain-bound time); Cholesky {tm['chol_ms']:.1f} ms", flush=True)
     eng.set_profiling(True)  # one more run with an event pair around every launch: where the time goes
     try:
         eng.dist_factorize(comm, w)
@@ -115,6 +120,9 @@ for rep in range(2):
     torch.cuda.synchronize()
     times.append(time.perf_counter() - t0)
 t = min(times)
+tm = eng.timings()
+print(f"    probes: {int(tm['dist_grad_collectives'])} collectives, {tm['dist_grad_comm_bytes'] / 1e9:.1f} GB, in collectives "
+      f"{tm['dist_grad_comm_ms']:.1f} ms (device copies here), of it exposed {tm['dist_grad_comm_exposed_ms']:.1f} ms; gradient {tm['grad_ms']:.1f} ms")
 print(f"  gradient: single engine {single_g * 1e3:.1f} ms; rank {rank} of {G}: {t * 1e3:.1f} ms = {single_g / G / t:.2f} of ideal; "
       f"{comm.calls} all-gathers, {comm.bytes / 1e9:.1f} GB received (= {comm.bytes / 1e9 / 300:.3f} s at 300 GB/s if not hidden)", flush=True)
 eng.close()
