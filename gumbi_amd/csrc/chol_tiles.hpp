@@ -1,0 +1,374 @@
+// chol_tiles.hpp -- the whole Cholesky factorisation of a SMALL matrix (N <= ~20k) as ONE persistent launch.
+//
+// Why: at C2's size (N = 10k, 79 block columns) the multi-kernel schedules of engine.hip are bound by their
+// latency chain (leaf -> strip solve -> rank-128 update, 79 times) and by what the stream model can overlap with it:
+// 8.8 ms where the flops alone need 4.7 ms.  Here the factorisation is a list of TILE TASKS served
+// by resident workgroups from one ticket counter; dependencies are per-tile flags in global memory, so bulk work
+// and the chain interleave at tile granularity without any kernel boundary.
+//
+// Task (I, J), I >= J, owns the 128 x 128 tile (block row I, block column J) and is LEFT-LOOKING:
+//   1. T = A(I,J) - sum_{k < J} L(I,k) L(J,k)^T   -- one long-k MFMA contraction (the k loop of gemm_f64.hpp),
+//      which walks the k-blocks in order and waits for the flags of L(I,k), L(J,k) only when it reaches a block
+//      that is not final yet: everything that CAN be accumulated early is;
+//   2. I == J:  L(J,J) = chol(T) with the leaf of potrf_leaf.hpp (in this workgroup's LDS), sub-block inverses
+//      and log-det as in the stand-alone leaf kernel;
+//      I >  J:  wait for L(J,J), then L(I,J) = T L(J,J)^-T with the strip solve of trsm_strip.hpp (two 16-row
+//      slabs per wavefront);
+//   3. publish the tile (agent-scope release, then its flag).
+// Tickets are handed out in column-major order (J outer, I = J first), which is a topological order of the
+// dependency graph: a task only ever waits for tasks with smaller tickets, which are finished or held by a running
+// workgroup -- the launch cannot deadlock whatever the residency or placement of its workgroups.  Every tile is
+// written once by its owner and read by others only after its flag, and each contraction runs in k order in one
+// accumulator, so the factor is bit-reproducible from run to run (it does differ in the last bits from the
+// recursive schedule, which groups the same sums differently).
+//
+// Inter-workgroup visibility follows the gfx950 recipe (per-XCD L2s are not coherent, L1 is per CU): producer =
+// every wave drains its stores, barrier, ONE lane agent-scope release + drain, relaxed agent-scope flag store;
+// consumer = ONE wave polls relaxed, ONE agent-scope acquire, barrier, plain loads.  Every wait is bounded: a wave
+// that waits longer than `timeout_us` raises the abort word, every waiter sees it and the launch drains
+// (the host reports GMB_EHIP) -- a lost flag can cost a factorisation, never the GPU.
+//
+// Replaces the per-evaluation dpotrf of pm.gp.Marginal (gumbi/regression/pymc/GP.py:811, 845-847) for the sizes
+// Gumbi users actually fit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f64.hpp"
+#include "potrf_leaf.hpp"
+#include "trsm_strip.hpp"
+
+namespace gmb {
+
+constexpr int CT_STAGE_DOUBLES = 2 * KT * (2 * PITCH);  // the GEMM's two LDS stages (73,728 B)
+constexpr int CT_LDS_DOUBLES = LEAF_LDS_DOUBLES > CT_STAGE_DOUBLES ? LEAF_LDS_DOUBLES : CT_STAGE_DOUBLES;
+
+struct CholTilesArgs {
+  double* A;        // factor buffer: lower triangle of Sigma in, L out (column-major, leading dimension ld)
+  int64_t ld;
+  int32_t nct, nrt; // block columns / block rows (nrt >= nct: the rows below the square ride along, e.g. the y row)
+  int64_t N;        // order of the matrix (ragged last diagonal block)
+  double* dinv16;   // nct x 8 x 256 sub-block inverses (out)
+  double* logdet;   // += sum log L_cc
+  int32_t* info;    // first non-positive pivot (global row + 1), 0 = ok
+  uint32_t* flags;  // nrt * nct words, zeroed by the host before the launch; tile (I, J) is final when [I * nct + J] != 0
+  uint32_t* ctl;    // [0] ticket counter, [1] abort word (zeroed with the flags)
+  int32_t ntasks;
+  uint32_t timeout_us;
+  unsigned long long* dbg;  // optional, 4 x ntasks: wall-clock stamps (100 MHz) taken / contraction done / solve input ready / published
+};
+
+__host__ __device__ inline int64_t ct_col_start(int J, int nrt) { return (int64_t)J * nrt - (int64_t)J * (J - 1) / 2; }
+__host__ __device__ inline int ct_task_count(int nct, int nrt) { return (int)ct_col_start(nct, nrt); }
+// ticket -> tile, column-major over the lower block triangle (column J holds I = J .. nrt-1)
+__host__ __device__ inline void ct_decode(int t, int nct, int nrt, int& I, int& J) {
+  const double b = 2.0 * nrt + 1.0;
+  double disc = b * b - 8.0 * (double)t;
+  if (disc < 0.0) disc = 0.0;
+  int j = (int)((b - sqrt(disc)) * 0.5);
+  if (j < 0) j = 0;
+  if (j > nct - 1) j = nct - 1;
+  while (j > 0 && ct_col_start(j, nrt) > t) --j;
+  while (j + 1 < nct && ct_col_start(j + 1, nrt) <= t) ++j;
+  J = j;
+  I = j + (t - (int)ct_col_start(j, nrt));
+}
+
+#define CT_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// wave-uniform: true when the wait must be abandoned (somebody raised the abort word, or this wave has waited
+// longer than the time-out and raises it itself)
+__device__ __forceinline__ bool ct_give_up(const CholTilesArgs& g, unsigned& spins, unsigned long long& t0) {
+  if ((++spins & 63u) != 0u) return false;
+  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(g.ctl + 1, CT_RLX_AGENT)) != 0u) return true;
+  const unsigned long long now = wall_clock64();
+  if (t0 == 0ull) {
+    t0 = now;
+    return false;
+  }
+  if (now - t0 > (unsigned long long)g.timeout_us * 100ull) {
+    __hip_atomic_store(g.ctl + 1, 1u, CT_RLX_AGENT);
+    return true;
+  }
+  return false;
+}
+
+// Called by ONE wave (all 64 lanes).  Waits until k-block kb0 of block rows I and J is final, then returns the end
+// of the run of final k-blocks that starts there (<= kb_end; at most 32 blocks further), after ONE agent-scope
+// acquire.  -1: the launch is being abandoned.
+__device__ __forceinline__ int ct_wait_rows(const CholTilesArgs& g, const int I, const int J, const int kb0, const int kb_end) {
+  const int lane = threadIdx.x & 63;
+  const int idx = kb0 + (lane & 31);
+  const bool mine = idx < kb_end;
+  const uint32_t* p = g.flags + (int64_t)(lane < 32 ? I : J) * g.nct + (mine ? idx : kb0);
+  unsigned spins = 0;
+  unsigned long long t0 = 0ull;
+  for (;;) {
+    const uint32_t v = __hip_atomic_load(p, CT_RLX_AGENT);
+    const unsigned long long m = __ballot(v != 0u || !mine);
+    const uint32_t both = (uint32_t)m & (uint32_t)(m >> 32);
+    const int n = both == 0xffffffffu ? 32 : __builtin_ctz(~both);
+    if (n > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const int e = kb0 + n;
+      return e < kb_end ? e : kb_end;
+    }
+    if (ct_give_up(g, spins, t0)) return -1;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// ONE wave: wait for a single flag; 0 = final (acquired), -1 = abandoned
+__device__ __forceinline__ int ct_wait_one(const CholTilesArgs& g, const uint32_t* p) {
+  unsigned spins = 0;
+  unsigned long long t0 = 0ull;
+  for (;;) {
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, CT_RLX_AGENT)) != 0u) {  // every lane reads the same word
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return 0;
+    }
+    if (ct_give_up(g, spins, t0)) return -1;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// T = A(I,J) - sum_{k < 128 J} L(I,k) L(J,k)^T, written over A(I,J).  The k loop of gemm_f64_body<2,2,4,4>
+// (same staging, same pinned instruction order), cut into segments at the k-blocks whose tiles were not final yet.
+// Every thread of the workgroup calls it; false = the launch is being abandoned (uniform).
+__device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, const int J, double* __restrict__ lds,
+                                        int* s_i) {
+  constexpr int WT = 4;                    // 4 x 4 MFMA tiles per wave, 2 x 2 waves
+  constexpr int PA = PITCH;                // LDS row pitch (doubles)
+  constexpr int LA = TILE / 2, RA = 256 / LA, NA = KT / RA;  // 64 lanes per k-row, 4 k-rows per pass, 4 passes
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int s_row = tid / LA, s_col = 2 * (tid % LA);
+  const double* __restrict__ Ag = g.A + (int64_t)J * TILE + s_col;  // "m" operand: rows of block row J = columns of the tile
+  const double* __restrict__ Bg = g.A + (int64_t)I * TILE + s_col;  // "n" operand: rows of block row I = rows of the tile
+
+  d4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  d2 ra[NA], rb[NA];
+
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const d2*>(Ag + ((int64_t)kt * KT + s_row + RA * p) * g.ld);
+#pragma unroll
+    for (int p = 0; p < NA; ++p) rb[p] = *reinterpret_cast<const d2*>(Bg + ((int64_t)kt * KT + s_row + RA * p) * g.ld);
+  };
+  auto lstore = [&](int st) {
+    double* As = lds + st * (KT * 2 * PA);
+    double* Bs = As + KT * PA;
+#pragma unroll
+    for (int p = 0; p < NA; ++p) *reinterpret_cast<d2*>(&As[(s_row + RA * p) * PA + s_col]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < NA; ++p) *reinterpret_cast<d2*>(&Bs[(s_row + RA * p) * PA + s_col]) = rb[p];
+  };
+  auto compute = [&](int st) {
+    const double* As = lds + st * (KT * 2 * PA);
+    const double* Bs = As + KT * PA;
+#pragma unroll
+    for (int k4 = 0; k4 < KT; k4 += 4) {
+      double a[WT], b[WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) a[i] = As[(k4 + kq) * PA + wm * 64 + i * 16 + r16];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) b[j] = Bs[(k4 + kq) * PA + wn * 64 + j * 16 + r16];
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  int kb = 0;
+  while (kb < J) {
+    if (wave == 0) s_i[1] = ct_wait_rows(g, I, J, kb, J);  // (every lane of wave 0 stores the same value)
+    __syncthreads();
+    const int kb1 = __builtin_amdgcn_readfirstlane(s_i[1]);  // workgroup-uniform: keep the control flow scalar
+    if (kb1 < 0) return false;
+    const int kt0 = kb * (TILE / KT), kt1 = kb1 * (TILE / KT);
+    gload(kt0);
+    lstore(0);
+    __syncthreads();
+    int st = 0;
+    constexpr int NMFMA = WT * WT * (KT / 4), NMEM = 2 * NA;
+    constexpr int SLOT = NMFMA / (4 * NMEM);
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
+      gload(kt + 1);
+      compute(st);
+      lstore(st ^ 1);
+#pragma unroll
+      for (int q = 0; q < NMEM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * SLOT * NMEM, 0);
+#pragma unroll
+      for (int q = 0; q < NMEM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+      }
+      __syncthreads();
+      st ^= 1;
+    }
+    compute(st);
+    __syncthreads();  // the next segment's first stage store (and the next wait's s_i) must not overtake slow waves
+    kb = kb1;
+  }
+
+  // epilogue: T = A(I,J) - acc.  D layout of v_mfma_f64_16x16x4_f64: n = lane & 15, m = (lane >> 4) + 4 reg.
+  double* __restrict__ Cg = g.A + (int64_t)I * TILE + wn * 64 + r16;
+  const int64_t m0 = (int64_t)J * TILE + wm * 64 + kq;
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* row = Cg + (m0 + i * 16 + 4 * r) * g.ld;
+      double c[WT];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) c[j] = row[j * 16];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) row[j * 16] = c[j] - acc[i][j][r];
+    }
+  return true;
+}
+
+// The three phases of a task are compiled as separate functions: inlined into one persistent loop the register
+// allocator kept the loop-invariant state of all three live everywhere (474 SGPR + 418 VGPR spills); apart they
+// need 227 / 256 / 256 VGPRs and spill next to nothing.  The LDS pointer travels as an address_space(3) pointer so
+// that the bodies keep their ds_* instructions.
+typedef __attribute__((address_space(3))) double ct_lds_double;
+typedef __attribute__((address_space(3))) int ct_lds_int;
+
+// (pointers inside an argument struct reach a non-inlined function as GENERIC pointers and the bodies would fall back
+// to flat_* loads, which count against lgkmcnt and stall the LDS pipeline of the contraction: the pointers travel as
+// address_space(1) parameters instead and are put back into the structs inside)
+typedef __attribute__((address_space(1))) double ct_g_double;
+typedef __attribute__((address_space(1))) uint32_t ct_g_u32;
+typedef __attribute__((address_space(1))) int32_t ct_g_i32;
+
+__device__ __noinline__ bool ct_ksum_call(const CholTilesArgs g_in, ct_g_double* A, ct_g_u32* flags, ct_g_u32* ctl, const int I,
+                                          const int J, ct_lds_double* l3, ct_lds_int* s3) {
+  CholTilesArgs g = g_in;
+  g.A = (double*)A;
+  g.flags = (uint32_t*)flags;
+  g.ctl = (uint32_t*)ctl;
+  return ct_ksum(g, I, J, (double*)l3, (int*)s3);
+}
+__device__ __noinline__ void ct_leaf_call(const LeafArgs a_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
+                                          ct_g_i32* info, ct_lds_double* l3) {
+  LeafArgs a = a_in;
+  a.A = (double*)A;
+  a.dinv16 = (double*)dinv16;
+  a.logdet = (double*)logdet;
+  a.info = (int32_t*)info;
+  potrf_leaf_core<4>(a, (double*)l3);
+  __builtin_amdgcn_s_setprio(0);
+}
+__device__ __noinline__ void ct_strip_call(const TrsmArgs t_in, ct_g_double* B, const ct_g_double* L, const ct_g_double* dinv16) {
+  TrsmArgs ta = t_in;
+  ta.B = (double*)B;
+  ta.L = (const double*)L;
+  ta.dinv16 = (const double*)dinv16;
+  const int wave = threadIdx.x >> 6;
+  trsm_strip_slab(ta, 16 * wave);
+  trsm_strip_slab(ta, 16 * (wave + 4));
+}
+
+// MODE (probes only): 1 = no arithmetic at all (tickets, flags); 2 = leaf and strip inlined instead of called
+template <int MODE>
+__device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
+  __shared__ __attribute__((aligned(16))) double lds[CT_LDS_DOUBLES];
+  __shared__ int s_i[4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Everything one thread would do for the workgroup -- draw a ticket, release and publish a tile -- is done by ALL
+  // 64 lanes of wave 0 with identical operands, under a wave-uniform (scalar) branch: no lane-divergent control flow
+  // anywhere near a barrier.  Written as `if (tid == 0)` at the top and bottom of the loop, the compiler fused the two
+  // regions across the back edge and let the other 63 lanes of wave 0 run ahead to the next barrier while lane 0 was
+  // parked: the barrier completed without the new ticket and the workgroup span on the old one for ever (first
+  // hardware contact, r03).
+  auto draw_ticket = [&]() {  // wave 0, all lanes: ONE add of 1 (the compiler folds the lanes' adds into one), lane 0's view
+    const unsigned old = atomicAdd(g.ctl, lane == 0 ? 1u : 0u);
+    s_i[0] = __builtin_amdgcn_readfirstlane((int)old);
+  };
+  if (wave == 0) draw_ticket();
+  __syncthreads();
+  for (;;) {
+    const int t = __builtin_amdgcn_readfirstlane(s_i[0]);  // workgroup-uniform: keep the control flow scalar
+    if (t >= g.ntasks) return;
+    int I, J;
+    ct_decode(t, g.nct, g.nrt, I, J);
+    if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 0] = wall_clock64();
+    if (J > 0 && MODE != 1) {
+      const bool ok = ct_ksum_call(g, (ct_g_double*)g.A, (ct_g_u32*)g.flags, (ct_g_u32*)g.ctl, I, J, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+      if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
+    }
+    if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
+    const int nvalid = (int)(g.N - (int64_t)J * TILE < TILE ? g.N - (int64_t)J * TILE : TILE);
+    double* const Ljj = g.A + (int64_t)J * TILE * (g.ld + 1);
+    double* const dinv = g.dinv16 + (int64_t)J * 8 * 256;
+    if (I == J) {
+      // this workgroup's own epilogue stores are read back by other lanes: drain, then barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+      LeafArgs a;
+      a.A = Ljj;
+      a.lda = g.ld;
+      a.nvalid = nvalid;
+      a.dinv16 = dinv;
+      a.logdet = g.logdet;
+      a.info = g.info;
+      a.row0 = (int64_t)J * TILE;
+      a.dbg = nullptr;
+      if constexpr (MODE == 0) ct_leaf_call(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
+      if constexpr (MODE == 2) {
+        potrf_leaf_core<4>(a, lds);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
+      if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return;
+      if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+      TrsmArgs ta;
+      ta.B = g.A + (int64_t)I * TILE + (int64_t)J * TILE * g.ld;
+      ta.ldb = g.ld;
+      ta.nrows = TILE;
+      ta.L = Ljj;
+      ta.ldl = g.ld;
+      ta.dinv16 = dinv;
+      ta.nvalid = nvalid;
+      if constexpr (MODE == 0) ct_strip_call(ta, (ct_g_double*)ta.B, (const ct_g_double*)ta.L, (const ct_g_double*)ta.dinv16);
+      if constexpr (MODE == 2) {
+        trsm_strip_slab(ta, 16 * wave);
+        trsm_strip_slab(ta, 16 * (wave + 4));
+      }
+    }
+    // publish the tile: every wave drains its stores, ONE lane releases at agent scope, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(g.flags + (int64_t)I * g.nct + J, 1u, CT_RLX_AGENT);
+      if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
+      draw_ticket();  // the next one
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void chol_tiles_kernel(CholTilesArgs g) { chol_tiles_body<0>(g); }
+
+}  // namespace gmb

@@ -33,6 +33,7 @@
 #include "gradient.hpp"
 #include "potrf_leaf.hpp"
 #include "trsm_strip.hpp"
+#include "chol_tiles.hpp"
 
 using namespace gmb;
 
@@ -169,7 +170,17 @@ struct gmb_engine {
   // event kind of the updates chol_cols issues: 7 (bulk trailing update) for the plain recursion over the whole
   // matrix, 0 (in-panel product of the latency-bound chain) inside the look-ahead schedules' panels
   int chol_update_kind = 7;
-  int chol_scheme = -1;  // -1 = by size (masked look-ahead for small matrices, else the plain recursion); 0 = plain recursion; 2 = masked look-ahead
+  // -1 = by size; 0 = plain recursion; 2 = masked look-ahead; 3 = persistent tile kernel (chol_tiles.hpp)
+  int chol_scheme = -1;
+  // persistent tile Cholesky: control words + per-tile flags (zeroed before every launch), optional task trace
+  uint32_t* dct = nullptr;
+  int64_t cap_ct = 0;
+  unsigned long long* dct_trace = nullptr;
+  int64_t cap_ct_trace = 0;
+  bool ct_trace = false;
+  bool ct_used = false;      // the last factorisation ran on the tile kernel (its abort word has to be read back)
+  int ct_ntasks = 0;
+  int tiles_min_blocks = 1 << 30, tiles_max_blocks = 160;  // matrices (in 128-blocks) the tile kernel factors by default
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
   std::vector<hipEvent_t> sync_pool;
   size_t sync_next = 0;
@@ -315,7 +326,7 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
     float t = 0.f;
     (void)hipEventElapsedTime(&t, p.a, p.b);
     if (trace) fprintf(trace, "%d %d %d %d %d %.5f %.1f\n", p.kind, p.mt, p.nt, p.k, p.flags, t, p.flops / 1e9);
-    if (p.kind == 0 || p.kind == 7 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
+    if (p.kind == 0 || p.kind == 7 || p.kind == 8 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
       e->tm.total_gemm_ms += t;
       e->tm.total_gemm_flops += p.flops;
       e->tm.total_gemm_launches += 1;
@@ -327,6 +338,7 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
     switch (p.kind) {
       case 0:
       case 7:
+      case 8:  // the persistent tile kernel: contraction, leaves and strip solves of the whole factorisation in one launch
         e->tm.chol_gemm_ms += t;
         e->tm.chol_gemm_flops += p.flops;
         e->tm.chol_gemm_launches += 1;
@@ -791,6 +803,45 @@ int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
   rc = launch_gemm(e, g, e->chol_update_kind);
   if (rc) return rc;
   return chol_cols(e, mid, c1, rend);
+}
+
+// ---- persistent tile Cholesky (chol_tiles.hpp): the whole factorisation in one launch --------------------
+int chol_tiles(gmb_engine* e) {
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  const int ntasks = ct_task_count(nct, nrt);
+  const int64_t words = 4 + (int64_t)nrt * nct;
+  int rc;
+  if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
+  CholTilesArgs a{};
+  a.A = e->dA;
+  a.ld = e->ld;
+  a.nct = nct;
+  a.nrt = nrt;
+  a.N = e->N;
+  a.dinv16 = e->dDinv16;
+  a.logdet = e->dscal;
+  a.info = e->dinfo;
+  a.ctl = e->dct;
+  a.flags = e->dct + 4;
+  a.ntasks = ntasks;
+  a.timeout_us = 4000000u;  // a wait of 4 s means a lost flag: give the factorisation up, never the GPU
+  a.dbg = nullptr;
+  if (e->ct_trace) {
+    if ((rc = ensure(e, &e->dct_trace, &e->cap_ct_trace, 4 * (int64_t)ntasks))) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->dct_trace, 0, (size_t)ntasks * 4 * sizeof(unsigned long long), e->cur));
+    a.dbg = e->dct_trace;
+  }
+  double flops = 0.0;
+  for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (double)(nrt - j);
+  const int grid = (int)std::min<long long>(ntasks, e->wg_slots);
+  ev_begin(e, 8, flops, nct, nrt, (int)e->Np, 0);
+  hipLaunchKernelGGL(chol_tiles_kernel, dim3(grid), dim3(256), 0, e->cur, a);
+  ev_end(e);
+  HIP_TRY(e, hipGetLastError());
+  e->ct_used = true;
+  e->ct_ntasks = ntasks;
+  return GMB_OK;
 }
 
 // ---- cross-stream ordering helpers -----------------------------------------------------------
@@ -1529,8 +1580,8 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   };
   // Environment switches of the PRODUCT library: only the ones a test or a documented tools/ A-B uses.
   //   GMB_LEAF_NAIVE=1   the reference diagonal-block kernel (tests/test_gpu_parity.py::test_potrf_leaf_block)
-  //   GMB_CHOL_SCHEME    0 = plain recursion, 2 = masked look-ahead for every size (tests/test_gpu_parity.py::
-  //                      test_cholesky_schedules_agree; tools/gpu_ab_env.py); default: by size
+  //   GMB_CHOL_SCHEME    0 = plain recursion, 2 = masked look-ahead, 3 = persistent tile kernel, for every size
+  //                      (tests/test_gpu_parity.py::test_cholesky_schedules_agree; tools/gpu_ab_env.py); default: by size
   //   GMB_TRACE_FILE     per-launch event log while profiling (tools/gpu_trace_run.py, tools/gpu_bulk_trace.py)
   // Everything else is compiled in only with -DGMB_TUNING (GUMBI_BUILD_TUNING=1 python -m gumbi_amd.build writes
   // gumbi_amd/lib/libgumbi_hip_tuning.so; tools/README.md).
@@ -1636,7 +1687,7 @@ void gmb_destroy(gmb_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (int a = 0; a < 3; ++a)
     if (e->aux[a]) (void)hipStreamSynchronize(e->aux[a]);
-  void* ptrs[] = {e->dstat, e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
+  void* ptrs[] = {e->dct, e->dct_trace, e->dstat, e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv, e->dV, e->dXs, e->txs, e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart, e->dgred, e->dgbig};
   for (void* p : ptrs)
@@ -1812,9 +1863,14 @@ int gmb_factorize(gmb_engine* e) {
     const int nct = (int)(e->Np / TILE);
     e->panel_blocks = std::max(8, ((nct / 16 + 4) / 8) * 8);
   }
-  const bool masked = e->lookahead && e->aux_shared && e->Np / TILE > e->panel_blocks &&
+  const int nblocks = (int)(e->Np / TILE);
+  const bool tiles = !e->naive_leaf && (e->chol_scheme == 3 || (e->chol_scheme < 0 && nblocks >= e->tiles_min_blocks &&
+                                                                 nblocks <= e->tiles_max_blocks));
+  const bool masked = !tiles && e->lookahead && e->aux_shared && e->Np / TILE > e->panel_blocks &&
                       (e->chol_scheme == 2 || (e->chol_scheme < 0 && e->Np / TILE <= e->masked_max_blocks));
-  if ((rc = masked ? chol_lookahead_masked(e) : chol_cols(e, 0, (int)(e->Np / TILE), (int)(e->Nr / TILE)))) return rc;
+  e->ct_used = false;
+  e->cur = e->stream;
+  if ((rc = tiles ? chol_tiles(e) : masked ? chol_lookahead_masked(e) : chol_cols(e, 0, nblocks, (int)(e->Nr / TILE)))) return rc;
   // 3. v = L^-1 y is row N of the factor
   hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
                      e->dscal + 1);
@@ -1824,7 +1880,13 @@ int gmb_factorize(gmb_engine* e) {
   int32_t info = 0;
   HIP_TRY(e, hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  uint32_t ct_abort = 0;
+  if (e->ct_used) HIP_TRY(e, hipMemcpyAsync(&ct_abort, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (ct_abort != 0) {
+    ev_collect(e);
+    return fail(e, GMB_EHIP, "tile Cholesky: a workgroup waited longer than its time-out for a tile (launch abandoned)");
+  }
   tm.kbuild_ms = tk.ms();
   tm.chol_ms = tc.ms();
   tm.kbuild_bytes = 8.0 * (double)e->N * (double)(e->N + 1) / 2.0 +
@@ -2175,6 +2237,35 @@ int64_t gmb_debug_cov_grid(int32_t ti, int32_t tj, int32_t strip, int32_t tri_gr
     }
   }
   return n;
+}
+
+int64_t gmb_debug_chol_task(int32_t t, int32_t nct, int32_t nrt, int32_t* I, int32_t* J) {
+  if (nct < 1 || nrt < nct) return GMB_EINVAL;
+  const int n = ct_task_count(nct, nrt);
+  int i = -1, j = -1;
+  if (t >= 0 && t < n) ct_decode(t, nct, nrt, i, j);
+  if (I) *I = i;
+  if (J) *J = j;
+  return n;
+}
+
+int64_t gmb_chol_task_trace(gmb_engine* e, int32_t enable, uint64_t* out, int64_t cap_tasks) {
+  if (!e) return GMB_EINVAL;
+  if (enable >= 0) e->ct_trace = enable != 0;
+  const int64_t n = (e->ct_used && e->dct_trace && e->cap_ct_trace >= 4 * (int64_t)e->ct_ntasks) ? e->ct_ntasks : 0;
+  if (out && n > 0) {
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(out, e->dct_trace, (size_t)std::min<int64_t>(n, cap_tasks) * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  return n;
+}
+
+int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme) {
+  if (!e) return GMB_EINVAL;
+  const int old = e->chol_scheme;
+  e->chol_scheme = scheme;
+  return old;
 }
 
 int gmb_blk_covariance(gmb_engine* e, double* out, int64_t ldo) {

@@ -285,13 +285,19 @@ __device__ __forceinline__ int pk(int r, int c) {
 // NW = wavefronts of the calling workgroup (4: the stand-alone kernel; 8: the whole-CU workgroups of
 // panel_chain_kernel -- the extra waves take update tiles and write-back).  Every thread of the
 // workgroup must call it (workgroup barriers inside).
+// LDS of the leaf, in doubles: S[PK_SIZE] (75,776 B) | dinv[256] (dense X_ss of the current sub-panel, column-major)
+// | rdiag[LB + 1] (1 / L_cc = X_cc; [LB] is a write-only spare slot) | red[8]
+constexpr int LEAF_LDS_DOUBLES = PK_SIZE + SB * SB + (LB + 1) + 8;  // 9873 doubles = 78,984 B
+
+// The leaf on LDS the caller provides (`lds`: LEAF_LDS_DOUBLES doubles, 16-byte aligned): the stand-alone kernel
+// below declares its own; the persistent tile Cholesky (chol_tiles.hpp) hands in the region its GEMM staging uses.
 template <int NW>
-__device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
+__device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __restrict__ lds) {
   constexpr int NTH = 64 * NW;
-  __shared__ double S[PK_SIZE];        //  75,776 B
-  __shared__ double dinv[SB * SB];     //   2,048 B  dense X_ss of the current sub-panel, column-major
-  __shared__ double rdiag[LB + 1];     //   1,032 B  1 / L_cc  (= X_cc); [LB] is a write-only spare slot
-  __shared__ double red[NW];
+  double* const S = lds;
+  double* const dinv = lds + PK_SIZE;
+  double* const rdiag = dinv + SB * SB;
+  double* const red = rdiag + (LB + 1);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -489,6 +495,12 @@ __device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
   }
   LEAF_STAMP(4);
   __syncthreads();
+}
+
+template <int NW>
+__device__ __forceinline__ void potrf_leaf_body(const LeafArgs& g) {
+  __shared__ __attribute__((aligned(16))) double lds[LEAF_LDS_DOUBLES];
+  potrf_leaf_core<NW>(g, lds);
 }
 
 // 8 wavefronts: wave 0 carries the dependent diagonal chain, the other seven share the rank-16

@@ -242,6 +242,9 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_int32]),
     "gmb_debug_cov_grid": (C.c_int64, [C.c_int32] * 7 + [C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
     "gmb_debug_tile_list": (C.c_int64, [C.c_int32] * 12 + [C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32)]),
+    "gmb_debug_chol_task": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gmb_chol_task_trace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "gmb_set_chol_scheme": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gmb_blk_covariance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "gmb_blk_trsm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
@@ -283,7 +286,7 @@ def _preload_hip_runtime():
 #: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3; version 4 replaced the block-level
 #: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``, ``gmb_set_y`` and ``gmb_create_sibling``;
 #: version 6 the communication fields of ``gmb_timings`` and ``gmb_rccl_comm_ranks``)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def load_library():
@@ -462,6 +465,29 @@ class Engine:
         self._check(self._lib.gmb_timings_get(self._h, C.byref(t)), "gmb_timings_get")
         return t.as_dict()
 
+    #: schedules of the Cholesky (``set_chol_scheme``): by size / plain recursion / masked look-ahead / persistent tile kernel
+    CHOL_BY_SIZE, CHOL_RECURSION, CHOL_LOOKAHEAD, CHOL_TILES = -1, 0, 2, 3
+
+    def set_chol_scheme(self, scheme: int) -> int:
+        """Schedule of the following factorisations; returns the previous setting."""
+        return int(self._lib.gmb_set_chol_scheme(self._h, int(scheme)))
+
+    def chol_task_trace(self, enable: int = -1):
+        """Per-task stamps of the last persistent tile factorisation: ``(tiles, stamps)`` with ``tiles`` the (I, J) of every
+        ticket and ``stamps`` (ntasks, 4) seconds since the first ticket (taken / contraction done / solve input ready /
+        published); ``None`` when the last factorisation recorded nothing.  ``enable`` = 1 / 0 switches the stamps of the
+        FOLLOWING factorisations on / off."""
+        n = int(self._lib.gmb_chol_task_trace(self._h, int(enable), None, 0))
+        if n <= 0:
+            return None
+        raw = np.zeros((n, 4), dtype=np.uint64)
+        self._check(min(0, int(self._lib.gmb_chol_task_trace(self._h, -1, _ptr(raw), n))), "gmb_chol_task_trace")
+        nct = (self.N + 127) // 128
+        nrt = (self.N + 1 + 127) // 128
+        tiles = np.array([chol_task(t, nct, nrt) for t in range(n)], dtype=np.int32)
+        t0 = raw[raw > 0].min() if (raw > 0).any() else 0
+        return tiles, (raw.astype(np.int64) - int(t0)) * 1e-8
+
     def copy_factor(self, r0=0, nr=None, c0=0, nc=None):
         nr = self.N if nr is None else nr
         nc = self.N if nc is None else nc
@@ -531,6 +557,20 @@ class Engine:
         self._check(self._lib.gmb_blk_gemm_nt(self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda,
                                               C.c_void_p(b_ptr), ldb, m, n, k, alpha, beta, tri, tri_shift),
                     "gmb_blk_gemm_nt")
+
+
+def chol_task(t: int, nct: int, nrt: int):
+    """Ticket ``t`` of the persistent tile Cholesky -> its tile (I, J) (host-side enumeration shared with the kernel)."""
+    lib = load_library()
+    i, j = C.c_int32(), C.c_int32()
+    n = lib.gmb_debug_chol_task(int(t), int(nct), int(nrt), C.byref(i), C.byref(j))
+    if n < 0:
+        raise ValueError("gmb_debug_chol_task: bad arguments")
+    return i.value, j.value
+
+
+def chol_task_count(nct: int, nrt: int) -> int:
+    return int(load_library().gmb_debug_chol_task(-1, int(nct), int(nrt), None, None))
 
 
 def gemm_tile_list(mt, nt, bm=128, bn=128, k=1024, tri=0, tri_off=0, nblk_stride=1, klo_n=0, khi_n=0, order=0, strip=0):

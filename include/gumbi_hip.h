@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 6
+#define GMB_ABI_VERSION 7
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -267,6 +267,18 @@ int64_t gmb_debug_tile_list(int32_t mt, int32_t nt, int32_t bm, int32_t bn, int3
  * keep_order); out = (block, tile row, tile column) triples, *grid = the launch's grid size; returns the count. */
 int64_t gmb_debug_cov_grid(int32_t ti, int32_t tj, int32_t strip, int32_t tri_grid, int32_t row_first,
                            int32_t row_stride, int32_t keep_order, int32_t* out, int64_t cap, int64_t* grid);
+/* Host-only: ticket t of the persistent tile Cholesky (csrc/chol_tiles.hpp; column-major over the lower block triangle of
+ * an nrt x nct block grid) -> its tile (*I, *J); returns the number of tasks of that grid (t out of range: I = J = -1). */
+int64_t gmb_debug_chol_task(int32_t t, int32_t nct, int32_t nrt, int32_t* I, int32_t* J);
+/* Persistent tile Cholesky: switch the per-task wall-clock stamps of the FOLLOWING factorisations on (1) / off (0) / leave
+ * them (-1) and, when `out` is not NULL, copy the stamps of the last one: 4 uint64 per task -- ticks of the 100 MHz wall
+ * clock at: ticket taken / contraction done / solve input ready / tile published -- tasks in ticket order, at most
+ * cap_tasks of them.  Returns the number of tasks of the last tile factorisation (0: the last factorisation used another
+ * schedule or recorded nothing), or a negative gmb_status. */
+int64_t gmb_chol_task_trace(gmb_engine* e, int32_t enable, uint64_t* out, int64_t cap_tasks);
+/* Schedule of the Cholesky for the following factorisations: -1 = by size (default), 0 = plain recursion, 2 = masked
+ * look-ahead, 3 = persistent tile kernel.  Returns the previous setting. */
+int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme);
 /* The covariance build alone: what gmb_factorize factors -- the lower-triangle 128 x 128 tiles of
  * Sigma = K + noise + jitter (pymc/GP.py:580), row N = y, identity padding -- written column-major into `out`
  * (device memory; ceil((N+1)/128)*128 rows x ceil(N/128)*128 columns, leading dimension ldo >= the row count).
