@@ -114,12 +114,15 @@ __device__ __forceinline__ int ct_wait_rows(const CholTilesArgs& g, const int I,
       return e < kb_end ? e : kb_end;
     }
     if (ct_give_up(g, spins, t0)) return -1;
-    __builtin_amdgcn_s_sleep(2);
+    // only the tiles next to the diagonal are on the critical chain: everybody else polls gently (hundreds of
+    // workgroups wait at the start and the end of a factorisation, and their polls share the fabric with the chain)
+    if (I <= J + 1) __builtin_amdgcn_s_sleep(2);
+    else __builtin_amdgcn_s_sleep(40);
   }
 }
 
 // ONE wave: wait for a single flag; 0 = final (acquired), -1 = abandoned
-__device__ __forceinline__ int ct_wait_one(const CholTilesArgs& g, const uint32_t* p) {
+__device__ __forceinline__ int ct_wait_one(const CholTilesArgs& g, const uint32_t* p, const bool urgent) {
   unsigned spins = 0;
   unsigned long long t0 = 0ull;
   for (;;) {
@@ -128,32 +131,37 @@ __device__ __forceinline__ int ct_wait_one(const CholTilesArgs& g, const uint32_
       return 0;
     }
     if (ct_give_up(g, spins, t0)) return -1;
-    __builtin_amdgcn_s_sleep(1);
+    if (urgent) __builtin_amdgcn_s_sleep(1);
+    else __builtin_amdgcn_s_sleep(40);
   }
 }
 
-// T = A(I,J) - sum_{k < 128 J} L(I,k) L(J,k)^T, written over A(I,J).  The k loop of gemm_f64_body<2,2,4,4>
-// (same staging, same pinned instruction order), cut into segments at the k-blocks whose tiles were not final yet.
-// Every thread of the workgroup calls it; false = the launch is being abandoned (uniform).
+// T = A(I,J) - sum_{k < 128 J} L(I,k) L(J,k)^T, written over A(I,J).  The k loop of gemm_f64_body (same staging,
+// same pinned instruction order) on a 128 x 128 tile, cut into segments at the k-blocks whose tiles were not final
+// yet.  NW = 4: 2 x 2 waves of 4 x 4 MFMA tiles (two workgroups per compute unit); NW = 8: 4 x 2 waves of 2 x 4 MFMA
+// tiles (one workgroup per compute unit).  Every thread of the workgroup calls it; false = the launch is being
+// abandoned (uniform).
+template <int NW>
 __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, const int J, double* __restrict__ lds,
                                         int* s_i) {
-  constexpr int WT = 4;                    // 4 x 4 MFMA tiles per wave, 2 x 2 waves
+  constexpr int WGN = 2, WGM = NW / WGN;           // waves along n (rows) and m (columns)
+  constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);  // MFMA tiles per wave
   constexpr int PA = PITCH;                // LDS row pitch (doubles)
-  constexpr int LA = TILE / 2, RA = 256 / LA, NA = KT / RA;  // 64 lanes per k-row, 4 k-rows per pass, 4 passes
+  constexpr int LA = TILE / 2, RA = 64 * NW / LA, NA = KT / RA;  // 64 lanes per k-row, RA k-rows per pass, NA passes
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int r16 = lane & 15, kq = lane >> 4;
   const int s_row = tid / LA, s_col = 2 * (tid % LA);
   const double* __restrict__ Ag = g.A + (int64_t)J * TILE + s_col;  // "m" operand: rows of block row J = columns of the tile
   const double* __restrict__ Bg = g.A + (int64_t)I * TILE + s_col;  // "n" operand: rows of block row I = rows of the tile
 
-  d4 acc[WT][WT];
+  d4 acc[WTM][WTN];
 #pragma unroll
-  for (int i = 0; i < WT; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < WT; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < WTN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
   d2 ra[NA], rb[NA];
 
   auto gload = [&](int kt) {
@@ -175,15 +183,15 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
     const double* Bs = As + KT * PA;
 #pragma unroll
     for (int k4 = 0; k4 < KT; k4 += 4) {
-      double a[WT], b[WT];
+      double a[WTM], b[WTN];
 #pragma unroll
-      for (int i = 0; i < WT; ++i) a[i] = As[(k4 + kq) * PA + wm * 64 + i * 16 + r16];
+      for (int i = 0; i < WTM; ++i) a[i] = As[(k4 + kq) * PA + wm * (16 * WTM) + i * 16 + r16];
 #pragma unroll
-      for (int j = 0; j < WT; ++j) b[j] = Bs[(k4 + kq) * PA + wn * 64 + j * 16 + r16];
+      for (int j = 0; j < WTN; ++j) b[j] = Bs[(k4 + kq) * PA + wn * (16 * WTN) + j * 16 + r16];
 #pragma unroll
-      for (int i = 0; i < WT; ++i)
+      for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -198,8 +206,9 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
     lstore(0);
     __syncthreads();
     int st = 0;
-    constexpr int NMFMA = WT * WT * (KT / 4), NMEM = 2 * NA;
+    constexpr int NMFMA = WTM * WTN * (KT / 4), NMEM = 2 * NA;
     constexpr int SLOT = NMFMA / (4 * NMEM);
+    static_assert(SLOT >= 1 && 2 * SLOT * NMEM <= NMFMA, "not enough MFMAs to interleave the staging with");
     for (int kt = kt0; kt + 1 < kt1; ++kt) {
       gload(kt + 1);
       compute(st);
@@ -224,18 +233,18 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
   }
 
   // epilogue: T = A(I,J) - acc.  D layout of v_mfma_f64_16x16x4_f64: n = lane & 15, m = (lane >> 4) + 4 reg.
-  double* __restrict__ Cg = g.A + (int64_t)I * TILE + wn * 64 + r16;
-  const int64_t m0 = (int64_t)J * TILE + wm * 64 + kq;
+  double* __restrict__ Cg = g.A + (int64_t)I * TILE + wn * (16 * WTN) + r16;
+  const int64_t m0 = (int64_t)J * TILE + wm * (16 * WTM) + kq;
 #pragma unroll
-  for (int i = 0; i < WT; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double* row = Cg + (m0 + i * 16 + 4 * r) * g.ld;
-      double c[WT];
+      double c[WTN];
 #pragma unroll
-      for (int j = 0; j < WT; ++j) c[j] = row[j * 16];
+      for (int j = 0; j < WTN; ++j) c[j] = row[j * 16];
 #pragma unroll
-      for (int j = 0; j < WT; ++j) row[j * 16] = c[j] - acc[i][j][r];
+      for (int j = 0; j < WTN; ++j) row[j * 16] = c[j] - acc[i][j][r];
     }
   return true;
 }
@@ -254,14 +263,16 @@ typedef __attribute__((address_space(1))) double ct_g_double;
 typedef __attribute__((address_space(1))) uint32_t ct_g_u32;
 typedef __attribute__((address_space(1))) int32_t ct_g_i32;
 
+template <int NW>
 __device__ __noinline__ bool ct_ksum_call(const CholTilesArgs g_in, ct_g_double* A, ct_g_u32* flags, ct_g_u32* ctl, const int I,
                                           const int J, ct_lds_double* l3, ct_lds_int* s3) {
   CholTilesArgs g = g_in;
   g.A = (double*)A;
   g.flags = (uint32_t*)flags;
   g.ctl = (uint32_t*)ctl;
-  return ct_ksum(g, I, J, (double*)l3, (int*)s3);
+  return ct_ksum<NW>(g, I, J, (double*)l3, (int*)s3);
 }
+template <int NW>
 __device__ __noinline__ void ct_leaf_call(const LeafArgs a_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
                                           ct_g_i32* info, ct_lds_double* l3) {
   LeafArgs a = a_in;
@@ -269,21 +280,40 @@ __device__ __noinline__ void ct_leaf_call(const LeafArgs a_in, ct_g_double* A, c
   a.dinv16 = (double*)dinv16;
   a.logdet = (double*)logdet;
   a.info = (int32_t*)info;
-  potrf_leaf_core<4>(a, (double*)l3);
+  potrf_leaf_core<NW, true>(a, (double*)l3);
   __builtin_amdgcn_s_setprio(0);
 }
-__device__ __noinline__ void ct_strip_call(const TrsmArgs t_in, ct_g_double* B, const ct_g_double* L, const ct_g_double* dinv16) {
+// Strip solve of an off-diagonal tile: the slab's own data is requested BEFORE the wait for the diagonal block (it does not
+// depend on it), the solved slab is stored write-through.  Returns false when the launch is being abandoned.
+template <int NW>
+__device__ __noinline__ bool ct_strip_call(const CholTilesArgs g_in, ct_g_u32* flags, ct_g_u32* ctl, const TrsmArgs t_in, ct_g_double* B,
+                                           const ct_g_double* L, const ct_g_double* dinv16, const int J, const bool urgent,
+                                           ct_lds_int* s3) {
+  CholTilesArgs g = g_in;
+  g.flags = (uint32_t*)flags;
+  g.ctl = (uint32_t*)ctl;
   TrsmArgs ta = t_in;
   ta.B = (double*)B;
   ta.L = (const double*)L;
   ta.dinv16 = (const double*)dinv16;
-  const int wave = threadIdx.x >> 6;
-  trsm_strip_slab(ta, 16 * wave);
-  trsm_strip_slab(ta, 16 * (wave + 4));
+  int* s_i = (int*)s3;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // own epilogue stores of this tile are read back by other lanes: drain, barrier, then load
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  strip_d4 X0[8], X1[8];
+  trsm_strip_load(ta, 16 * wave, X0);
+  if constexpr (NW == 4) trsm_strip_load(ta, 16 * (wave + 4), X1);
+  if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J, urgent);
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)s_i[0] + 2] = wall_clock64();
+  trsm_strip_solve_store<true>(ta, 16 * wave, X0);
+  if constexpr (NW == 4) trsm_strip_solve_store<true>(ta, 16 * (wave + 4), X1);
+  return true;
 }
 
-// MODE (probes only): 1 = no arithmetic at all (tickets, flags); 2 = leaf and strip inlined instead of called
-template <int MODE>
+template <int NW>
 __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
   __shared__ __attribute__((aligned(16))) double lds[CT_LDS_DOUBLES];
   __shared__ int s_i[4];
@@ -308,8 +338,8 @@ __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
     int I, J;
     ct_decode(t, g.nct, g.nrt, I, J);
     if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 0] = wall_clock64();
-    if (J > 0 && MODE != 1) {
-      const bool ok = ct_ksum_call(g, (ct_g_double*)g.A, (ct_g_u32*)g.flags, (ct_g_u32*)g.ctl, I, J, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+    if (J > 0) {
+      const bool ok = ct_ksum_call<NW>(g, (ct_g_double*)g.A, (ct_g_u32*)g.flags, (ct_g_u32*)g.ctl, I, J, (ct_lds_double*)lds, (ct_lds_int*)s_i);
       if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
     }
     if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
@@ -330,17 +360,8 @@ __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
       a.info = g.info;
       a.row0 = (int64_t)J * TILE;
       a.dbg = nullptr;
-      if constexpr (MODE == 0) ct_leaf_call(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
-      if constexpr (MODE == 2) {
-        potrf_leaf_core<4>(a, lds);
-        __builtin_amdgcn_s_setprio(0);
-      }
+      ct_leaf_call<NW>(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
     } else {
-      if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return;
-      if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
       TrsmArgs ta;
       ta.B = g.A + (int64_t)I * TILE + (int64_t)J * TILE * g.ld;
       ta.ldb = g.ld;
@@ -349,18 +370,15 @@ __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
       ta.ldl = g.ld;
       ta.dinv16 = dinv;
       ta.nvalid = nvalid;
-      if constexpr (MODE == 0) ct_strip_call(ta, (ct_g_double*)ta.B, (const ct_g_double*)ta.L, (const ct_g_double*)ta.dinv16);
-      if constexpr (MODE == 2) {
-        trsm_strip_slab(ta, 16 * wave);
-        trsm_strip_slab(ta, 16 * (wave + 4));
-      }
+      const bool ok = ct_strip_call<NW>(g, (ct_g_u32*)g.flags, (ct_g_u32*)g.ctl, ta, (ct_g_double*)ta.B, (const ct_g_double*)ta.L,
+                                        (const ct_g_double*)ta.dinv16, J, I == J + 1, (ct_lds_int*)s_i);
+      if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
     }
-    // publish the tile: every wave drains its stores, ONE lane releases at agent scope, then the flag
+    // publish the tile: its final values were stored write-through (sc1), so there is no release fence -- every wave
+    // drains its stores, barrier, then the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(g.flags + (int64_t)I * g.nct + J, 1u, CT_RLX_AGENT);
       if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
       draw_ticket();  // the next one
@@ -369,6 +387,11 @@ __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
   }
 }
 
-__global__ __launch_bounds__(256, 2) void chol_tiles_kernel(CholTilesArgs g) { chol_tiles_body<0>(g); }
+// NW = 4: 256 threads, two workgroups per compute unit; NW = 8: 512 threads, one per compute unit (every phase of the
+// latency chain -- leaf, strip solve, last k-block of the diagonal tile -- has the whole compute unit)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void chol_tiles_kernel(CholTilesArgs g) {
+  chol_tiles_body<NW>(g);
+}
 
 }  // namespace gmb

@@ -834,9 +834,13 @@ int chol_tiles(gmb_engine* e) {
   }
   double flops = 0.0;
   for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (double)(nrt - j);
-  const int grid = (int)std::min<long long>(ntasks, e->wg_slots);
+  int nw = 8;
+  if (const char* cw = getenv("GMB_CT_WAVES")) nw = atoi(cw) == 4 ? 4 : 8;  // TEMP probe
+  int grid = (int)std::min<long long>(ntasks, nw == 8 ? e->wg_slots / 2 : e->wg_slots);
+  if (const char* cg = getenv("GMB_CT_GRID")) grid = std::max(1, std::min(grid, atoi(cg)));  // TEMP probe
   ev_begin(e, 8, flops, nct, nrt, (int)e->Np, 0);
-  hipLaunchKernelGGL(chol_tiles_kernel, dim3(grid), dim3(256), 0, e->cur, a);
+  if (nw == 8) hipLaunchKernelGGL(chol_tiles_kernel<8>, dim3(grid), dim3(512), 0, e->cur, a);
+  else hipLaunchKernelGGL(chol_tiles_kernel<4>, dim3(grid), dim3(256), 0, e->cur, a);
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
   e->ct_used = true;

@@ -126,10 +126,21 @@ __device__ __forceinline__ double rl_sgpr(double v, int lane_const) {
   return u.d;
 }
 
+// Global store of a result another workgroup of the SAME launch will read (persistent tile Cholesky, chol_tiles.hpp):
+// WT = write-through (sc1) -- the bytes leave this XCD's L2 at once, so the publisher needs no agent-scope release fence
+// (a fence writes back every dirty line of the L2: ~8 us behind a freshly written 128 KB tile, 3 us with write-through
+// stores); plain otherwise.
+template <bool WT>
+__device__ __forceinline__ void leaf_store(double* p, double v) {
+  if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
 // `Sd` / `pitch`: the block column that holds the sub-block (its first row is the sub-block's
 // first row, see the packed layout below).
 // `gdinv` (may be null): global copy of the dense inverse, for the solves of later kernels.
 #define D16_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (double)__builtin_readcyclecounter(); } while (0)
+template <bool WT = false>
 __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double* dinv_s, double* gdinv,
                                                    double* rdiag, int c0, int nv, int32_t* info, int64_t row0,
                                                    double* dbg = nullptr) {
@@ -263,7 +274,7 @@ __device__ __forceinline__ void factor_diag16_mfma(double* Sd, int pitch, double
   }
   if (gdinv) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gdinv[r16 * SB + 4 * q + kq] = Xrow[q];
+    for (int q = 0; q < 4; ++q) leaf_store<WT>(&gdinv[r16 * SB + 4 * q + kq], Xrow[q]);
   }
   D16_STAMP(10);
 }
@@ -291,7 +302,7 @@ constexpr int LEAF_LDS_DOUBLES = PK_SIZE + SB * SB + (LB + 1) + 8;  // 9873 doub
 
 // The leaf on LDS the caller provides (`lds`: LEAF_LDS_DOUBLES doubles, 16-byte aligned): the stand-alone kernel
 // below declares its own; the persistent tile Cholesky (chol_tiles.hpp) hands in the region its GEMM staging uses.
-template <int NW>
+template <int NW, bool WT = false>
 __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __restrict__ lds) {
   constexpr int NTH = 64 * NW;
   double* const S = lds;
@@ -340,7 +351,7 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    factor_diag16_mfma(&S[0], pk_pitch(0), dinv, gd, rdiag, 0, nv, g.info, g.row0, g.dbg ? g.dbg + 40 : nullptr);
+    factor_diag16_mfma<WT>(&S[0], pk_pitch(0), dinv, gd, rdiag, 0, nv, g.info, g.row0, g.dbg ? g.dbg + 40 : nullptr);
   } else {
     // all 16-byte loads of a thread are issued before the first use (one latency, not 19)
     constexpr int NO = NTH - 64;
@@ -370,7 +381,7 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
     const int pitch = pk_pitch(s);
     for (int idx = first; idx < SB * h; idx += nthreads) {
       const int cl = idx / h, rl = idx - cl * h;
-      if (c0 + cl < nv && rl >= cl) g.A[c0 + rl + (int64_t)(c0 + cl) * g.lda] = Sd[cl * pitch + rl];
+      if (c0 + cl < nv && rl >= cl) leaf_store<WT>(&g.A[c0 + rl + (int64_t)(c0 + cl) * g.lda], Sd[cl * pitch + rl]);
     }
   };
 
@@ -408,7 +419,7 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
         for (int r = 0; r < 4; ++r) Sn[(kq + 4 * r) * pn + r16] -= acc[r];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        factor_diag16_mfma(Sn, pn, dinv, gd ? gd + (s + 1) * SB * SB : nullptr, rdiag, c0 + SB, nv, g.info, g.row0);
+        factor_diag16_mfma<WT>(Sn, pn, dinv, gd ? gd + (s + 1) * SB * SB : nullptr, rdiag, c0 + SB, nv, g.info, g.row0);
       } else {
         const int ntile = n * (n + 1) / 2;
         // Tiles 1 .. ntile-1 (t = 0 is the diagonal tile wave 0 owns) are dealt in rounds of 2 (NW - 2) + 1
@@ -490,7 +501,7 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
         xc[a] = (a < j) ? 0.0 : t * rdiag[s * SB + a];
       }
 #pragma unroll
-      for (int a = 0; a < SB; ++a) g.dinv16[s * SB * SB + j * SB + a] = xc[a];
+      for (int a = 0; a < SB; ++a) leaf_store<WT>(&g.dinv16[s * SB * SB + j * SB + a], xc[a]);
     }
   }
   LEAF_STAMP(4);

@@ -48,6 +48,9 @@ __device__ __forceinline__ void trsm_strip_load(const TrsmArgs& g, const int64_t
     for (int q = 0; q < 4; ++q) X[s][q] = Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb];
 }
 
+// WT: write-through (sc1) stores of the solved slab -- a result another workgroup of the same launch will read
+// (chol_tiles.hpp; see leaf_store in potrf_leaf.hpp)
+template <bool WT = false>
 __device__ __forceinline__ void trsm_strip_solve_store(const TrsmArgs& g, const int64_t r0, strip_d4 (&X)[8]) {
   typedef strip_d4 d4;
   const int lane = threadIdx.x & 63;
@@ -77,7 +80,10 @@ __device__ __forceinline__ void trsm_strip_solve_store(const TrsmArgs& g, const 
 #pragma unroll
   for (int s = 0; s < 8; ++s)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb] = X[s][q];
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (WT) __hip_atomic_store(&Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb], X[s][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb] = X[s][q];
+    }
 }
 
 // one 16-row slab (rows r0 .. r0+15) by the calling wavefront

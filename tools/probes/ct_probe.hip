@@ -1,7 +1,6 @@
 // Stand-alone probe of the persistent tile Cholesky's pieces (first hardware contact / debugging):
 //   ct_probe <test> [N]   test 0: leaf core<4> inlined in a 256-thread kernel; 1: the same through the non-inlined call;
-//                         2: chol_tiles_kernel on an N x N matrix (default 128); 3: its ticket / flag skeleton without
-//                         arithmetic; 4: leaf and strip inlined; prints max |L - L_ref|.
+//                         2: chol_tiles_kernel on an N x N matrix (default 128); 6: the same with 8 waves; prints max |L - L_ref|.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/ct_probe.hip -o tools/probes/bin/ct_probe
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -20,10 +19,8 @@ __global__ __launch_bounds__(256, 2) void k_leaf_inline(LeafArgs a) {
 }
 __global__ __launch_bounds__(256, 2) void k_leaf_call(LeafArgs a) {
   __shared__ __attribute__((aligned(16))) double lds[CT_LDS_DOUBLES];
-  ct_leaf_call(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
+  ct_leaf_call<4>(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
 }
-__global__ __launch_bounds__(256, 2) void k_tiles_noarith(CholTilesArgs g) { chol_tiles_body<1>(g); }
-__global__ __launch_bounds__(256, 2) void k_tiles_inline(CholTilesArgs g) { chol_tiles_body<2>(g); }
 #define CK(x) do { hipError_t s_ = (x); if (s_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(s_)); return 2; } } while (0)
 
 int main(int argc, char** argv) {
@@ -62,17 +59,42 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemset(dscal, 0, 64 * 8)); CK(hipMemset(dinfo, 0, 4)); CK(hipMemset(dct, 0, (4 + (size_t)nrt * nct) * 4)); CK(hipMemset(dtr, 0, (size_t)ntasks * 32));
   hipStream_t st; CK(hipStreamCreate(&st));
-  if (test < 2) {
+  if (test < 2 || test == 5) {
     LeafArgs a{}; a.A = dA; a.lda = ld; a.nvalid = N < 128 ? N : 128; a.dinv16 = dinv; a.logdet = dscal; a.info = dinfo; a.row0 = 0; a.dbg = nullptr;
+    // timing: the same block factored 50 times from a fresh copy each (copy kernel + leaf, events around the leaves only would
+    // need one pair each: the mean of (copy + leaf) minus the mean of copy alone is close enough for a comparison)
+    double* dA0; CK(hipMalloc(&dA0, A.size() * 8)); CK(hipMemcpy(dA0, dA, A.size() * 8, hipMemcpyDeviceToDevice));
+    double* ddbg; CK(hipMalloc(&ddbg, 64 * 8)); CK(hipMemset(ddbg, 0, 64 * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float tot = 0.f;
+    for (int rep = 0; rep < 52; ++rep) {
+      CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
+      a.dbg = rep == 51 ? ddbg : nullptr;
+      CK(hipEventRecord(e0, st));
+      if (test == 0) hipLaunchKernelGGL(k_leaf_inline, dim3(1), dim3(256), 0, st, a);
+      else if (test == 1) hipLaunchKernelGGL(k_leaf_call, dim3(1), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(512), 0, st, a);
+      CK(hipEventRecord(e1, st));
+      CK(hipStreamSynchronize(st));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep >= 2 && rep < 51) tot += ms;
+    }
+    double hd[64]; CK(hipMemcpy(hd, ddbg, 64 * 8, hipMemcpyDeviceToHost));
+    printf("test %d: leaf launch %.2f us (events, mean of 49); stamps (us from entry): loaded %.2f", test, tot / 49 * 1e3, (hd[1] - hd[0]) * 0.01);
+    for (int s2 = 0; s2 < 7; ++s2) printf(" | s%d solve %.2f bar %.2f upd %.2f", s2, (hd[8 + 3 * s2] - hd[0]) * 0.01, (hd[9 + 3 * s2] - hd[0]) * 0.01, (hd[10 + 3 * s2] - hd[0]) * 0.01);
+    printf(" | loop end %.2f logdet %.2f end %.2f\n", (hd[2] - hd[0]) * 0.01, (hd[3] - hd[0]) * 0.01, (hd[4] - hd[0]) * 0.01);
+    CK(hipMemset(dscal, 0, 64 * 8));
+    CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
+    a.dbg = nullptr;
     if (test == 0) hipLaunchKernelGGL(k_leaf_inline, dim3(1), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_leaf_call, dim3(1), dim3(256), 0, st, a);
+    else if (test == 1) hipLaunchKernelGGL(k_leaf_call, dim3(1), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(512), 0, st, a);
   } else {
     CholTilesArgs g{}; g.A = dA; g.ld = ld; g.nct = nct; g.nrt = nrt; g.N = N; g.dinv16 = dinv; g.logdet = dscal; g.info = dinfo;
     g.ctl = dct; g.flags = dct + 4; g.ntasks = ntasks; g.timeout_us = 2000000u; g.dbg = dtr;
     const int grid = ntasks < 512 ? ntasks : 512;
-    if (test == 2) hipLaunchKernelGGL(chol_tiles_kernel, dim3(grid), dim3(256), 0, st, g);
-    if (test == 3) hipLaunchKernelGGL(k_tiles_noarith, dim3(grid), dim3(256), 0, st, g);
-    if (test == 4) hipLaunchKernelGGL(k_tiles_inline, dim3(grid), dim3(256), 0, st, g);
+    if (test == 2) hipLaunchKernelGGL(chol_tiles_kernel<4>, dim3(grid), dim3(256), 0, st, g);
+    if (test == 6) hipLaunchKernelGGL(chol_tiles_kernel<8>, dim3(grid < 256 ? grid : 256), dim3(512), 0, st, g);
   }
   CK(hipGetLastError());
   auto t0 = std::chrono::steady_clock::now();
@@ -89,7 +111,8 @@ int main(int argc, char** argv) {
   double hs[2]; CK(hipMemcpy(hs, dscal, 16, hipMemcpyDeviceToHost));
   int32_t info; CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
   double err = 0.0, ld_ref = 0.0;
-  const int cmax = test < 2 ? (N < 128 ? N : 128) : N, rmax = test < 2 ? 128 : (int)Nr;
+  const bool leaf_only = test < 2 || test == 5;
+  const int cmax = leaf_only ? (N < 128 ? N : 128) : N, rmax = leaf_only ? 128 : (int)Nr;
   for (int c = 0; c < cmax; ++c) {
     ld_ref += std::log(R[c + (size_t)c * ld]);
     for (int r = c; r < rmax && r <= N; ++r) err = std::fmax(err, std::fabs(A[r + (size_t)c * ld] - R[r + (size_t)c * ld]));
