@@ -328,6 +328,23 @@ def roofline_block(tm, config):
             "achieved": round(mtf, 3),
             "frac_of_their_share_of_peak": round(mtf / (FP64_MFMA_PEAK_TFLOPS * tm["masked_cus"] / ncu), 4),
         }
+    if int(tm.get("total_chol_tile_launches", 0)) > 0 and int(tm["total_chol_gemm_launches"]) == 0:
+        # N <= ~20k: the factorisation is ONE launch of the persistent tile kernel (csrc/chol_tiles.hpp) -- there are no
+        # separate trailing-update launches to quote; the roofline is the whole launch: contraction, leaves and strip
+        # solves, latency chain included (flops = the tiles' contractions)
+        n_t = int(tm["total_chol_tile_launches"])
+        tf = tm["total_chol_tile_flops"] / max(tm["total_chol_tile_ms"], 1e-9) / 1e9
+        out.update({
+            "kernel": "chol_tiles_kernel<8>, the persistent tile Cholesky: the WHOLE factorisation in one launch (left-looking "
+                      "128 x 128 tile tasks on v_mfma_f64_16x16x4_f64, leaves and strip solves inside, flags between workgroups)",
+            "subset_note": "achieved / frac cover the whole factorisation launch, latency chain included -- this size has no separate "
+                           "trailing-update launches; all_gemm_launches beside it adds the gradient's and the prediction's GEMM launches",
+            "achieved": round(tf, 3), "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "launches": n_t,
+            "avg_launch_ms": round(tm["total_chol_tile_ms"] / n_t, 5), "flops_per_launch": round(tm["total_chol_tile_flops"] / n_t, 1),
+            "achieved_over_wall_time": round(tf, 3),
+        })
+        out.pop("in_panel_products", None)
+        return out
     pt = pmc_traffic(config, "gemm_f64_kernel<2, 2, 4, 4")  # the 128 x 128 instantiation the bulk updates run
     if pt is not None and pt["flops_per_launch"] > 0:
         # the PMC passes count every launch of the 128x128 instantiation (bulk updates, solves, inverse, Sigma^-1,

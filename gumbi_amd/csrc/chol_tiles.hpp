@@ -40,8 +40,13 @@
 
 namespace gmb {
 
-constexpr int CT_STAGE_DOUBLES = 2 * KT * (2 * PITCH);  // the GEMM's two LDS stages (73,728 B)
-constexpr int CT_LDS_DOUBLES = LEAF_LDS_DOUBLES > CT_STAGE_DOUBLES ? LEAF_LDS_DOUBLES : CT_STAGE_DOUBLES;
+// k-tile depth of the contraction: 16 with two workgroups per compute unit (2 x 73,728 B of staging fit beside each other),
+// 32 with ONE eight-wave workgroup per compute unit (147,456 B) -- half the barriers per flop, and nobody else's MFMAs to
+// fill the barrier bubbles with
+__host__ __device__ constexpr int ct_kt(int nw) { return nw == 8 ? 32 : 16; }
+__host__ __device__ constexpr int ct_lds_doubles(int nw) {
+  return LEAF_LDS_DOUBLES > 2 * ct_kt(nw) * (2 * PITCH) ? LEAF_LDS_DOUBLES : 2 * ct_kt(nw) * (2 * PITCH);
+}
 
 struct CholTilesArgs {
   double* A;        // factor buffer: lower triangle of Sigma in, L out (column-major, leading dimension ld)
@@ -146,6 +151,7 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
                                         int* s_i) {
   constexpr int WGN = 2, WGM = NW / WGN;           // waves along n (rows) and m (columns)
   constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);  // MFMA tiles per wave
+  constexpr int KT = ct_kt(NW);            // (shadows gmb::KT of the launch-based GEMM)
   constexpr int PA = PITCH;                // LDS row pitch (doubles)
   constexpr int LA = TILE / 2, RA = 64 * NW / LA, NA = KT / RA;  // 64 lanes per k-row, RA k-rows per pass, NA passes
   const int tid = threadIdx.x;
@@ -315,7 +321,7 @@ __device__ __noinline__ bool ct_strip_call(const CholTilesArgs g_in, ct_g_u32* f
 
 template <int NW>
 __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
-  __shared__ __attribute__((aligned(16))) double lds[CT_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double lds[ct_lds_doubles(NW)];
   __shared__ int s_i[4];
   const int tid = threadIdx.x;
   const int lane = tid & 63;

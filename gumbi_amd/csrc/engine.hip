@@ -180,7 +180,7 @@ struct gmb_engine {
   bool ct_trace = false;
   bool ct_used = false;      // the last factorisation ran on the tile kernel (its abort word has to be read back)
   int ct_ntasks = 0;
-  int tiles_min_blocks = 1 << 30, tiles_max_blocks = 160;  // matrices (in 128-blocks) the tile kernel factors by default
+  int tiles_min_blocks = 40, tiles_max_blocks = 160;  // matrices (in 128-blocks) the tile kernel factors by default
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
   std::vector<hipEvent_t> sync_pool;
   size_t sync_next = 0;
@@ -336,9 +336,16 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
       }
     }
     switch (p.kind) {
+      case 8:  // the persistent tile kernel: contraction, leaves and strip solves of the whole factorisation in one launch
+        e->tm.total_chol_tile_ms += t;
+        e->tm.total_chol_tile_flops += p.flops;
+        e->tm.total_chol_tile_launches += 1;
+        e->tm.chol_gemm_ms += t;
+        e->tm.chol_gemm_flops += p.flops;
+        e->tm.chol_gemm_launches += 1;
+        break;
       case 0:
       case 7:
-      case 8:  // the persistent tile kernel: contraction, leaves and strip solves of the whole factorisation in one launch
         e->tm.chol_gemm_ms += t;
         e->tm.chol_gemm_flops += p.flops;
         e->tm.chol_gemm_launches += 1;
@@ -1820,6 +1827,8 @@ int gmb_set_profiling(gmb_engine* e, int32_t on) {
     e->tm.total_chol_gemm_ms = e->tm.total_chol_gemm_flops = e->tm.total_chol_gemm_wall_ms = 0.0;
     e->tm.total_chol_gemm_launches = 0;
     e->tm.total_chol_panel_gemm_ms = e->tm.total_chol_panel_gemm_flops = 0.0;
+    e->tm.total_chol_tile_ms = e->tm.total_chol_tile_flops = 0.0;
+    e->tm.total_chol_tile_launches = 0;
     e->tm.masked_cus = e->aux_shared ? e->wg_slots / 2 - e->part_cus : 0;
     e->tm.total_gemm_launches = 0;
     e->tm.total_kbuild_ms = e->tm.total_kbuild_bytes = 0.0;

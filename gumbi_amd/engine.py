@@ -95,6 +95,9 @@ class Timings(C.Structure):
         ("dist_grad_comm_ms", C.c_double),
         ("dist_grad_comm_exposed_ms", C.c_double),
         ("dist_lockstep_repairs", C.c_int64),
+        ("total_chol_tile_ms", C.c_double),
+        ("total_chol_tile_flops", C.c_double),
+        ("total_chol_tile_launches", C.c_int64),
     ]
 
     def as_dict(self):

@@ -152,6 +152,12 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
      construction); all ranks nevertheless LEAVE gmb_dist_factorize with rank 0's copy, so that optimisers running in
      lock step on every rank can never part company.  Cumulative count of ranks whose own copy differed (expected 0). */
   int64_t dist_lockstep_repairs;
+  /* The persistent tile Cholesky (csrc/chol_tiles.hpp: the WHOLE factorisation of a small matrix -- contraction, leaves and
+     strip solves -- in one launch), cumulative like total_gemm_*: launch durations (HIP events), the flops of the tiles'
+     contractions, launches.  Such a factorisation has no separate trailing-update launches: total_chol_gemm_* stay 0. */
+  double total_chol_tile_ms;
+  double total_chol_tile_flops;
+  int64_t total_chol_tile_launches;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"\b(?:double|int64_t)\s+([a-z_0-9]+)\s*;", body)
     assert fields == [n for n, _ in engine.Timings._fields_]
-    assert engine.C.sizeof(engine.Timings) == 8 * len(fields) == 43 * 8
+    assert engine.C.sizeof(engine.Timings) == 8 * len(fields) == 46 * 8
     # gmb_comm {int32 rank, world; void* ctx; fn* all_gather} and gmb_dist_step {9 x int32, pad, int64}
     assert engine.C.sizeof(engine.GmbComm) == 24 and engine.C.sizeof(engine.DistStep) == 48
     spec = engine.KernelSpec(D=6, idx_cont=[0, 1, 2], idx_lin=[1], coreg=[(3, 4)], out_col=5, n_out=2)
@@ -164,3 +164,25 @@ def test_covariance_grid_covers_every_tile_exactly_once(ti, tj, strip):
         grid, t = cov_grid(ti, tj, strip, tri_grid=0, keep_order=keep)
         tiles = list(map(tuple, t[:, 1:]))
         assert len(tiles) == len(set(tiles)) == ti * tj and grid == ti * -(-tj // strip)
+
+
+def test_tile_cholesky_tickets_enumerate_every_tile_once_in_a_topological_order():
+    from gumbi_amd import engine
+
+    """The ticket -> tile map the persistent tile Cholesky and the host share (gmb_debug_chol_task): every tile of the lower
+    block triangle exactly once, and every tile after the tiles it waits for -- (I, k), (J, k) for k < J and (J, J) --
+    which is what makes the launch deadlock-free whatever the residency of its workgroups."""
+    for nct, nrt in [(1, 1), (1, 2), (2, 2), (3, 4), (16, 16), (40, 41), (79, 79), (80, 81), (160, 161)]:
+        n = engine.chol_task_count(nct, nrt)
+        assert n == nct * nrt - nct * (nct - 1) // 2
+        tiles = [engine.chol_task(t, nct, nrt) for t in range(n)]
+        pos = {tile: t for t, tile in enumerate(tiles)}
+        assert len(pos) == n and all(j <= i < nrt and 0 <= j < nct for i, j in tiles)
+        step = max(1, n // 400)
+        for t in range(0, n, step):
+            i, j = tiles[t]
+            deps = [(j, j)] if i != j else []
+            deps += [(i, k) for k in range(j)] + [(j, k) for k in range(j)]
+            assert all(pos[dep] < t for dep in deps)
+    assert engine.chol_task(10 ** 6, 3, 4) == (-1, -1)
+

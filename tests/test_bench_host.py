@@ -141,3 +141,15 @@ def test_pmc_traffic_is_marked_stale_when_the_kernels_changed(tmp_path, monkeypa
     assert pt["launches"] == 10 and abs(pt["bytes_per_launch"] - 6.0e9) < 1 and pt["stale"] is False
     (tmp_path / "gumbi_amd" / "csrc" / "k.hpp").write_text("kernel v2")
     assert bench.pmc_traffic("cx", "gemm_f64_kernel<2, 2, 4, 4")["stale"] is True
+
+
+def test_roofline_block_quotes_the_tile_kernel_when_the_factorisation_is_one_launch():
+    """C2-class sizes: no trailing-update launches exist, the persistent tile kernel is the roofline's kernel."""
+    bench = load_bench()
+    tm = {"total_chol_gemm_flops": 0.0, "total_chol_gemm_ms": 0.0, "total_chol_gemm_launches": 0, "total_chol_gemm_wall_ms": 0.0,
+          "total_gemm_flops": 6.0e12, "total_gemm_ms": 100.0, "total_gemm_launches": 300, "total_gemm_wall_ms": 90.0,
+          "total_chol_panel_gemm_flops": 0.0, "total_chol_panel_gemm_ms": 0.0, "masked_gemm_flops": 0.0,
+          "total_chol_tile_ms": 20.0, "total_chol_tile_flops": 1.0e12, "total_chol_tile_launches": 3}
+    r = bench.roofline_block(tm, "c2")
+    assert "chol_tiles_kernel" in r["kernel"] and r["launches"] == 3 and abs(r["achieved"] - 50.0) < 1e-9
+    assert abs(r["frac"] - 50.0 / bench.FP64_MFMA_PEAK_TFLOPS) < 1e-4 and r["traffic"] is None and "in_panel_products" not in r

@@ -543,7 +543,7 @@ def test_cholesky_schedules_agree(gpu, N):
     theta = O.pack_theta(spec, ls, 0.9, 0.2)
     got = {}
     try:
-        for scheme in ("0", "2"):
+        for scheme in ("0", "2", "3"):
             os.environ["GMB_CHOL_SCHEME"] = scheme
             eng = make_engine(spec, theta, X, y)
             eng.factorize()
@@ -555,3 +555,82 @@ def test_cholesky_schedules_agree(gpu, N):
     for scheme in got:
         assert rel(got[scheme][0], L_ref) < 1e-10 and rel(got[scheme][1], v_ref) < 1e-10
     assert rel(got["0"][0], got["2"][0]) < 1e-12 and abs(got["0"][2] - got["2"][2]) < 1e-9 * abs(got["2"][2])
+    assert rel(got["0"][0], got["3"][0]) < 1e-12 and abs(got["0"][2] - got["3"][2]) < 1e-9 * abs(got["3"][2])
+
+
+# ----------------------------------------------------------------------------------------------
+# persistent tile Cholesky (csrc/chol_tiles.hpp): the whole factorisation in ONE launch
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [2, 5, 127, 128, 129, 640, 1000, 2560, 5200, 6016])
+def test_tile_cholesky_matches_oracle(gpu, N):
+    """Factor, v, log-det (NLML), gradient and predictions of the tile schedule against the oracle: ragged sizes, sizes with
+    and without a separate y block row (N % 128 == 0), one to 47 block columns (5200 and 6016 are inside the range the
+    engine picks the schedule for by itself; the others are forced)."""
+    d = 3
+    X, y, ls = O.synthetic_table(N, d, seed=21)
+    spec = O.make_spec(d, range(d), kind="Matern52")
+    theta = O.pack_theta(spec, ls, 1.1, 0.25)
+    eng = make_engine(spec, theta, X, y)
+    if N < 5000:
+        eng.set_chol_scheme(eng.CHOL_TILES)
+    eng.chol_task_trace(1)
+    eng.factorize()
+    tr = eng.chol_task_trace(0)
+    assert tr is not None, "the factorisation did not run on the tile kernel"
+    tiles, stamps = tr
+    nct, nrt = (N + 127) // 128, (N + 1 + 127) // 128
+    assert len(tiles) == nct * nrt - nct * (nct - 1) // 2 and (np.diff(stamps, axis=1) >= 0).all()
+    L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
+    nr = min(N, 1500)
+    L = eng.copy_factor(r0=N - nr, nr=nr)
+    assert rel(np.tril(L, N - nr), np.tril(L_ref[N - nr:], N - nr)) < 1e-10 and rel(eng.copy_v(), v_ref) < 1e-10
+    val_r, grad_r = O.nlml_and_grad(spec, theta, X, y)
+    val, grad = eng.nlml(grad=True)
+    assert abs(val - val_r) < 1e-10 * max(1.0, abs(val_r)) and rel(grad, grad_r) < 1e-8
+    Xs = np.random.default_rng(3).standard_normal((200, d))
+    mu, var = eng.predict(Xs)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+    assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-9
+    eng.close()
+
+
+def test_tile_cholesky_is_bit_reproducible(gpu):
+    """Every tile is written once by its owner and every contraction runs in k order in one accumulator: whatever order
+    the workgroups draw their tickets in, the factor comes out with the same bits -- across repeats and fresh engines."""
+    N, d = 5400, 4
+    X, y, ls = O.synthetic_table(N, d, seed=8)
+    spec = O.make_spec(d, range(d), kind="ExpQuad")
+    theta = O.pack_theta(spec, ls, 1.0, 0.2)
+    runs = []
+    for _ in range(2):
+        eng = make_engine(spec, theta, X, y)
+        eng.set_chol_scheme(eng.CHOL_TILES)
+        for _ in range(3):
+            eng.factorize()
+            runs.append((np.tril(eng.copy_factor(r0=N - 700, nr=700), N - 700).tobytes(), eng.copy_v().tobytes(), np.float64(eng.nlml()).tobytes()))
+        eng.close()
+    assert all(r == runs[0] for r in runs[1:])
+
+
+def test_tile_cholesky_reports_the_first_bad_pivot_like_the_recursion(gpu):
+    """A NaN point and an indefinite matrix: LinAlgError with the same global row as the stream schedules report, and the
+    engine factorises a well-posed problem afterwards (no flag or ticket state survives a failed launch)."""
+    N = 1500
+    X, y, ls = O.synthetic_table(N, 2, seed=9)
+    spec = O.make_spec(2, range(2))
+    theta = O.pack_theta(spec, ls, 1.0, 0.2)
+    Xbad = X.copy()
+    Xbad[777, 0] = np.nan
+    rows = {}
+    for scheme in (0, 3):
+        eng = make_engine(spec, theta, Xbad, y)
+        eng.set_chol_scheme(scheme)
+        with pytest.raises(np.linalg.LinAlgError):
+            eng.factorize()
+        rows[scheme] = eng.notpd_index()
+        eng.set_data(X, y)
+        eng.set_theta(theta)
+        eng.factorize()
+        assert np.isfinite(eng.nlml())
+        eng.close()
+    assert rows[0] == rows[3] >= 0

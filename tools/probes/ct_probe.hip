@@ -14,11 +14,11 @@
 using namespace gmb;
 
 __global__ __launch_bounds__(256, 2) void k_leaf_inline(LeafArgs a) {
-  __shared__ __attribute__((aligned(16))) double lds[CT_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double lds[ct_lds_doubles(4)];
   potrf_leaf_core<4>(a, lds);
 }
 __global__ __launch_bounds__(256, 2) void k_leaf_call(LeafArgs a) {
-  __shared__ __attribute__((aligned(16))) double lds[CT_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double lds[ct_lds_doubles(4)];
   ct_leaf_call<4>(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
 }
 #define CK(x) do { hipError_t s_ = (x); if (s_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(s_)); return 2; } } while (0)
