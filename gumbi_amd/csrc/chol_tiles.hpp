@@ -255,67 +255,118 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
   return true;
 }
 
-// The three phases of a task are compiled as separate functions: inlined into one persistent loop the register
-// allocator kept the loop-invariant state of all three live everywhere (474 SGPR + 418 VGPR spills); apart they
-// need 227 / 256 / 256 VGPRs and spill next to nothing.  The LDS pointer travels as an address_space(3) pointer so
-// that the bodies keep their ds_* instructions.
+// A task is compiled as ONE non-inlined function per kind (diagonal / off-diagonal tile).  Inlined into the persistent
+// loop, the register allocator kept the loop-invariant state of every phase live everywhere (474 SGPR + 418 VGPR
+// spills); one function per PHASE (contraction / leaf / strip) put the callee's register save -- ~110 scratch stores,
+// 3 - 5 us -- in front of the leaf and of the strip solve, i.e. twice per column on the latency chain.  With one call
+// per task the save runs when the task starts (long before its last dependency arrives) and the restore after its
+// tile is published.  Pointers travel as address_space(1) / (3) parameters and are put back into the structs inside:
+// through a struct they would arrive GENERIC and the bodies would fall back to flat_* accesses (which count against
+// lgkmcnt and stall the LDS pipeline of the contraction).
 typedef __attribute__((address_space(3))) double ct_lds_double;
 typedef __attribute__((address_space(3))) int ct_lds_int;
-
-// (pointers inside an argument struct reach a non-inlined function as GENERIC pointers and the bodies would fall back
-// to flat_* loads, which count against lgkmcnt and stall the LDS pipeline of the contraction: the pointers travel as
-// address_space(1) parameters instead and are put back into the structs inside)
 typedef __attribute__((address_space(1))) double ct_g_double;
 typedef __attribute__((address_space(1))) uint32_t ct_g_u32;
 typedef __attribute__((address_space(1))) int32_t ct_g_i32;
+typedef __attribute__((address_space(1))) unsigned long long ct_g_u64;
 
-template <int NW>
-__device__ __noinline__ bool ct_ksum_call(const CholTilesArgs g_in, ct_g_double* A, ct_g_u32* flags, ct_g_u32* ctl, const int I,
-                                          const int J, ct_lds_double* l3, ct_lds_int* s3) {
+struct CtPtrs {  // the global pointers of CholTilesArgs, typed
+  ct_g_double* A;
+  ct_g_double* dinv16;
+  ct_g_double* logdet;
+  ct_g_i32* info;
+  ct_g_u32* flags;
+  ct_g_u32* ctl;
+  ct_g_u64* dbg;
+};
+
+__device__ __forceinline__ CholTilesArgs ct_rebuild(const CholTilesArgs& g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
+                                                    ct_g_i32* info, ct_g_u32* flags, ct_g_u32* ctl, ct_g_u64* dbg) {
   CholTilesArgs g = g_in;
   g.A = (double*)A;
+  g.dinv16 = (double*)dinv16;
+  g.logdet = (double*)logdet;
+  g.info = (int32_t*)info;
   g.flags = (uint32_t*)flags;
   g.ctl = (uint32_t*)ctl;
-  return ct_ksum<NW>(g, I, J, (double*)l3, (int*)s3);
+  g.dbg = (unsigned long long*)dbg;
+  return g;
 }
+
+// publish tile (I, J): its final values were stored write-through (sc1), so there is no release fence -- every wave
+// drains its stores, barrier, then the flag (stored by all lanes of wave 0: same word, same value)
+__device__ __forceinline__ void ct_publish(const CholTilesArgs& g, const int I, const int J, const int t, const int wave) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave == 0) {
+    __hip_atomic_store(g.flags + (int64_t)I * g.nct + J, 1u, CT_RLX_AGENT);
+    if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
+  }
+}
+
+// Diagonal tile (J, J): contraction, leaf factorisation, publication.  false = the launch is being abandoned.
 template <int NW>
-__device__ __noinline__ void ct_leaf_call(const LeafArgs a_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
-                                          ct_g_i32* info, ct_lds_double* l3) {
-  LeafArgs a = a_in;
-  a.A = (double*)A;
-  a.dinv16 = (double*)dinv16;
-  a.logdet = (double*)logdet;
-  a.info = (int32_t*)info;
-  potrf_leaf_core<NW, true>(a, (double*)l3);
+__device__ __noinline__ bool ct_diag_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet, ct_g_i32* info,
+                                          ct_g_u32* flags, ct_g_u32* ctl, ct_g_u64* dbg, const int J, const int t, ct_lds_double* l3,
+                                          ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, ctl, dbg);
+  double* lds = (double*)l3;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (J > 0 && !ct_ksum<NW>(g, J, J, lds, (int*)s3)) return false;
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
+  // this workgroup's own epilogue stores are read back by other lanes: drain, then barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+  LeafArgs a;
+  a.A = g.A + (int64_t)J * TILE * (g.ld + 1);
+  a.lda = g.ld;
+  a.nvalid = (int)(g.N - (int64_t)J * TILE < TILE ? g.N - (int64_t)J * TILE : TILE);
+  a.dinv16 = g.dinv16 + (int64_t)J * 8 * 256;
+  a.logdet = g.logdet;
+  a.info = g.info;
+  a.row0 = (int64_t)J * TILE;
+  a.dbg = nullptr;
+  potrf_leaf_core<NW, true>(a, lds);
   __builtin_amdgcn_s_setprio(0);
+  ct_publish(g, J, J, t, wave);
+  return true;
 }
-// Strip solve of an off-diagonal tile: the slab's own data is requested BEFORE the wait for the diagonal block (it does not
-// depend on it), the solved slab is stored write-through.  Returns false when the launch is being abandoned.
+
+// Off-diagonal tile (I, J): contraction, strip solve against L(J, J), publication.  The slab's own data is requested
+// BEFORE the wait for the diagonal block (it does not depend on it); the solved slab is stored write-through.
 template <int NW>
-__device__ __noinline__ bool ct_strip_call(const CholTilesArgs g_in, ct_g_u32* flags, ct_g_u32* ctl, const TrsmArgs t_in, ct_g_double* B,
-                                           const ct_g_double* L, const ct_g_double* dinv16, const int J, const bool urgent,
-                                           ct_lds_int* s3) {
-  CholTilesArgs g = g_in;
-  g.flags = (uint32_t*)flags;
-  g.ctl = (uint32_t*)ctl;
-  TrsmArgs ta = t_in;
-  ta.B = (double*)B;
-  ta.L = (const double*)L;
-  ta.dinv16 = (const double*)dinv16;
+__device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
+                                             ct_g_i32* info, ct_g_u32* flags, ct_g_u32* ctl, ct_g_u64* dbg, const int I, const int J,
+                                             const int t, ct_lds_double* l3, ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, ctl, dbg);
   int* s_i = (int*)s3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (J > 0 && !ct_ksum<NW>(g, I, J, (double*)l3, s_i)) return false;
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
+  TrsmArgs ta;
+  ta.B = g.A + (int64_t)I * TILE + (int64_t)J * TILE * g.ld;
+  ta.ldb = g.ld;
+  ta.nrows = TILE;
+  ta.L = g.A + (int64_t)J * TILE * (g.ld + 1);
+  ta.ldl = g.ld;
+  ta.dinv16 = g.dinv16 + (int64_t)J * 8 * 256;
+  ta.nvalid = (int)(g.N - (int64_t)J * TILE < TILE ? g.N - (int64_t)J * TILE : TILE);
   // own epilogue stores of this tile are read back by other lanes: drain, barrier, then load
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   strip_d4 X0[8], X1[8];
   trsm_strip_load(ta, 16 * wave, X0);
   if constexpr (NW == 4) trsm_strip_load(ta, 16 * (wave + 4), X1);
-  if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J, urgent);
+  if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J, I == J + 1);
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
-  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)s_i[0] + 2] = wall_clock64();
-  trsm_strip_solve_store<true>(ta, 16 * wave, X0);
-  if constexpr (NW == 4) trsm_strip_solve_store<true>(ta, 16 * (wave + 4), X1);
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+  if (I == J + 1) __builtin_amdgcn_s_setprio(3);
+  trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+  if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  __builtin_amdgcn_s_setprio(0);
+  ct_publish(g, I, J, t, wave);
   return true;
 }
 
@@ -326,12 +377,12 @@ __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Everything one thread would do for the workgroup -- draw a ticket, release and publish a tile -- is done by ALL
-  // 64 lanes of wave 0 with identical operands, under a wave-uniform (scalar) branch: no lane-divergent control flow
-  // anywhere near a barrier.  Written as `if (tid == 0)` at the top and bottom of the loop, the compiler fused the two
-  // regions across the back edge and let the other 63 lanes of wave 0 run ahead to the next barrier while lane 0 was
-  // parked: the barrier completed without the new ticket and the workgroup span on the old one for ever (first
-  // hardware contact, r03).
+  // Everything one thread would do for the workgroup -- draw a ticket, publish a tile -- is done by ALL 64 lanes of
+  // wave 0 with identical operands, under a wave-uniform (scalar) branch: no lane-divergent control flow anywhere near
+  // a barrier.  Written as `if (tid == 0)` at the top and bottom of the loop, the compiler fused the two regions across
+  // the back edge and let the other 63 lanes of wave 0 run ahead to the next barrier while lane 0 was parked: the
+  // barrier completed without the new ticket and the workgroup span on the old one for ever (first hardware contact,
+  // r03).
   auto draw_ticket = [&]() {  // wave 0, all lanes: ONE add of 1 (the compiler folds the lanes' adds into one), lane 0's view
     const unsigned old = atomicAdd(g.ctl, lane == 0 ? 1u : 0u);
     s_i[0] = __builtin_amdgcn_readfirstlane((int)old);
@@ -344,51 +395,15 @@ __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
     int I, J;
     ct_decode(t, g.nct, g.nrt, I, J);
     if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 0] = wall_clock64();
-    if (J > 0) {
-      const bool ok = ct_ksum_call<NW>(g, (ct_g_double*)g.A, (ct_g_u32*)g.flags, (ct_g_u32*)g.ctl, I, J, (ct_lds_double*)lds, (ct_lds_int*)s_i);
-      if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
-    }
-    if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
-    const int nvalid = (int)(g.N - (int64_t)J * TILE < TILE ? g.N - (int64_t)J * TILE : TILE);
-    double* const Ljj = g.A + (int64_t)J * TILE * (g.ld + 1);
-    double* const dinv = g.dinv16 + (int64_t)J * 8 * 256;
-    if (I == J) {
-      // this workgroup's own epilogue stores are read back by other lanes: drain, then barrier
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
-      LeafArgs a;
-      a.A = Ljj;
-      a.lda = g.ld;
-      a.nvalid = nvalid;
-      a.dinv16 = dinv;
-      a.logdet = g.logdet;
-      a.info = g.info;
-      a.row0 = (int64_t)J * TILE;
-      a.dbg = nullptr;
-      ct_leaf_call<NW>(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
-    } else {
-      TrsmArgs ta;
-      ta.B = g.A + (int64_t)I * TILE + (int64_t)J * TILE * g.ld;
-      ta.ldb = g.ld;
-      ta.nrows = TILE;
-      ta.L = Ljj;
-      ta.ldl = g.ld;
-      ta.dinv16 = dinv;
-      ta.nvalid = nvalid;
-      const bool ok = ct_strip_call<NW>(g, (ct_g_u32*)g.flags, (ct_g_u32*)g.ctl, ta, (ct_g_double*)ta.B, (const ct_g_double*)ta.L,
-                                        (const ct_g_double*)ta.dinv16, J, I == J + 1, (ct_lds_int*)s_i);
-      if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
-    }
-    // publish the tile: its final values were stored write-through (sc1), so there is no release fence -- every wave
-    // drains its stores, barrier, then the flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (wave == 0) {
-      __hip_atomic_store(g.flags + (int64_t)I * g.nct + J, 1u, CT_RLX_AGENT);
-      if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
-      draw_ticket();  // the next one
-    }
+    bool ok;
+    if (I == J)
+      ok = ct_diag_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.logdet, (ct_g_i32*)g.info, (ct_g_u32*)g.flags,
+                            (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+    else
+      ok = ct_offdiag_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.logdet, (ct_g_i32*)g.info, (ct_g_u32*)g.flags,
+                               (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
+    if (wave == 0) draw_ticket();  // the next one (every thread passed the barrier of the publication: s_i[0] is free)
     __syncthreads();
   }
 }

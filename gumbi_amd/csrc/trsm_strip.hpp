@@ -86,6 +86,53 @@ __device__ __forceinline__ void trsm_strip_solve_store(const TrsmArgs& g, const 
     }
 }
 
+// The same solve with the operand loads written out ahead of their use: step s + 1's L_st / inv(L_ss) values are
+// requested before step s's MFMAs (two register sets, <= 32 values each).  Inside the persistent tile Cholesky's task
+// functions (chol_tiles.hpp) the compiler kept the source order of trsm_strip_solve_store -- load, wait, MFMA, load,
+// wait, ... 144 exposed L2 latencies, 40 us per slab instead of 9 -- although it batches the loads of the stand-alone
+// kernel by itself.
+template <bool WT = false>
+__device__ __forceinline__ void trsm_strip_solve_store_pf(const TrsmArgs& g, const int64_t r0, strip_d4 (&X)[8]) {
+  typedef strip_d4 d4;
+  const int lane = threadIdx.x & 63;
+  const int r16 = lane & 15, kq = lane >> 4;
+  double* Bp = g.B + r0 + r16;
+  double ops[2][32];
+  auto load_step = [&](const int s, double (&o)[32]) {
+    const double* Lrow = g.L + 16 * s + r16;
+#pragma unroll
+    for (int t = 0; t < s; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) o[4 * t + kk] = Lrow[(int64_t)(16 * t + 4 * kk + kq) * g.ldl];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) o[28 + kk] = g.dinv16[s * 256 + (4 * kk + kq) * 16 + r16];
+  };
+  load_step(0, ops[0]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s < 7) load_step(s + 1, ops[(s + 1) & 1]);
+    asm volatile("" ::: "memory");  // keep the requests above the MFMAs below
+    const double(&o)[32] = ops[s & 1];
+    const bool live = 16 * s + r16 < g.nvalid;
+    d4 y = X[s];
+#pragma unroll
+    for (int t = 0; t < s; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) y = __builtin_amdgcn_mfma_f64_16x16x4f64(live ? -o[4 * t + kk] : 0.0, X[t][kk], y, 0, 0, 0);
+    d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(o[28 + kk], y[kk], x, 0, 0, 0);
+    X[s] = x;
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (WT) __hip_atomic_store(&Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb], X[s][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb] = X[s][q];
+    }
+}
+
 // one 16-row slab (rows r0 .. r0+15) by the calling wavefront
 __device__ __forceinline__ void trsm_strip_slab(const TrsmArgs& g, const int64_t r0) {
   strip_d4 X[8];

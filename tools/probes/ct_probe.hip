@@ -17,9 +17,15 @@ __global__ __launch_bounds__(256, 2) void k_leaf_inline(LeafArgs a) {
   __shared__ __attribute__((aligned(16))) double lds[ct_lds_doubles(4)];
   potrf_leaf_core<4>(a, lds);
 }
+__device__ __noinline__ void leaf_call4(const LeafArgs a_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet, ct_g_i32* info,
+                                       ct_lds_double* l3) {
+  LeafArgs a = a_in;
+  a.A = (double*)A; a.dinv16 = (double*)dinv16; a.logdet = (double*)logdet; a.info = (int32_t*)info;
+  potrf_leaf_core<4>(a, (double*)l3);
+}
 __global__ __launch_bounds__(256, 2) void k_leaf_call(LeafArgs a) {
   __shared__ __attribute__((aligned(16))) double lds[ct_lds_doubles(4)];
-  ct_leaf_call<4>(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
+  leaf_call4(a, (ct_g_double*)a.A, (ct_g_double*)a.dinv16, (ct_g_double*)a.logdet, (ct_g_i32*)a.info, (ct_lds_double*)lds);
 }
 #define CK(x) do { hipError_t s_ = (x); if (s_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(s_)); return 2; } } while (0)
 
