@@ -841,10 +841,16 @@ int chol_tiles(gmb_engine* e) {
   }
   double flops = 0.0;
   for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (double)(nrt - j);
+  // eight-wave workgroups, one per compute unit: every phase of the latency chain has the whole compute unit (N = 10k:
+  // 6.8 ms against 8.7 ms with four-wave workgroups, two per compute unit -- which stay available to the tuning build)
   int nw = 8;
-  if (const char* cw = getenv("GMB_CT_WAVES")) nw = atoi(cw) == 4 ? 4 : 8;  // TEMP probe
+#ifdef GMB_TUNING
+  if (const char* cw = getenv("GMB_CT_WAVES")) nw = atoi(cw) == 4 ? 4 : 8;
+#endif
   int grid = (int)std::min<long long>(ntasks, nw == 8 ? e->wg_slots / 2 : e->wg_slots);
-  if (const char* cg = getenv("GMB_CT_GRID")) grid = std::max(1, std::min(grid, atoi(cg)));  // TEMP probe
+#ifdef GMB_TUNING
+  if (const char* cg = getenv("GMB_CT_GRID")) grid = std::max(1, std::min(grid, atoi(cg)));
+#endif
   ev_begin(e, 8, flops, nct, nrt, (int)e->Np, 0);
   if (nw == 8) hipLaunchKernelGGL(chol_tiles_kernel<8>, dim3(grid), dim3(512), 0, e->cur, a);
   else hipLaunchKernelGGL(chol_tiles_kernel<4>, dim3(grid), dim3(256), 0, e->cur, a);

@@ -44,3 +44,17 @@ def gpu():
     if n < 1:
         pytest.fail("this test needs an MI355X and libgumbi_hip.so; none is visible (no CPU fallback exists)")
     return n
+
+
+def pytest_runtest_teardown(item, nextitem):
+    """GUMBI_TEST_CEILING=1 (diagnostic): the register-only MFMA rate a FRESH process sees after every test -- a test that
+    leaves work running on the GPU (a worker that never drained a stream) shows up as a halved rate."""
+    import os
+
+    if os.environ.get("GUMBI_TEST_CEILING") != "1":
+        return
+    import subprocess
+
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "gpu_ceiling_now.py")], capture_output=True, text=True)
+    last = (out.stdout.strip().splitlines() or ["?"])[-1]
+    print(f"\n[ceiling after {item.name}] {last[:60]}", flush=True)

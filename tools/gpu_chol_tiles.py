@@ -60,6 +60,13 @@ for N, d in sizes:
             if j < 12 or j % 8 == 0 or j >= nct - 6:
                 print(f"  {j:3d}: diag {dj[0]:8.1f} {dj[1]:8.1f} {dj[2]:8.1f} {dj[3]:8.1f}  sub " +
                       (f"{sj[0]:8.1f} {sj[1]:8.1f} {sj[2]:8.1f} {sj[3]:8.1f}" if sj is not None else "-") + f"  step {step:6.1f}")
+        # contraction time per k-block of the bulk tiles (I >= J + 2), by column: minimum / median / maximum (waits included)
+        per = {}
+        for i, (ii, j) in enumerate(tiles):
+            if j > 0 and ii >= j + 2:
+                per.setdefault(int(j), []).append((st[i, 1] - st[i, 0]) / j)
+        print("  us per k-block of bulk tiles (min / median / max), by column:")
+        print("   " + "  ".join(f"{j}: {min(v):.1f}/{np.median(v):.1f}/{max(v):.1f}" for j, v in sorted(per.items()) if j % 6 == 0 or j < 4))
         busy = (st[:, 3] - st[:, 0]).sum()
         ks = (st[:, 1] - st[:, 0]).sum()
         print(f"  sum of task spans {busy/1e3:.2f} ms, of contraction spans {ks/1e3:.2f} ms over {min(len(tiles), 512)} workgroups")
