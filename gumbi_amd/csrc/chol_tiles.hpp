@@ -57,6 +57,7 @@ struct CholTilesArgs {
   double* logdet;   // += sum log L_cc
   int32_t* info;    // first non-positive pivot (global row + 1), 0 = ok
   uint32_t* flags;  // nrt * nct words, zeroed by the host before the launch; tile (I, J) is final when [I * nct + J] != 0
+  uint32_t* half;   // nct words (zeroed with the flags): the first 64 columns of the sub-diagonal tile (J + 1, J) are final
   uint32_t* ctl;    // [0] ticket counter, [1] abort word (zeroed with the flags)
   int32_t ntasks;
   uint32_t timeout_us;
@@ -201,13 +202,32 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
     }
   };
 
-  int kb = 0;
-  while (kb < J) {
-    if (wave == 0) s_i[1] = ct_wait_rows(g, I, J, kb, J);  // (every lane of wave 0 stores the same value)
+  // The contraction runs in SEGMENTS of k-tiles whose operands are final.  Off-diagonal tiles: runs of k-blocks by
+  // the tile flags of block rows I and J.  Diagonal tiles: the same up to the last k-block, which comes from the
+  // sub-diagonal tile (J, J-1) of the column before -- the end of the latency chain; that tile publishes its first 64
+  // columns half way through its solve (half[J-1]), so the last block is taken in two halves.
+  constexpr int KPB = TILE / KT;  // k-tiles per k-block
+  const int kt_end = J * KPB;
+  const bool diag = I == J;
+  int ktc = 0;
+  while (ktc < kt_end) {
+    const int kb = ktc / KPB;
+    if (wave == 0) {
+      int r;
+      if (diag && kb == J - 1) {
+        const bool first = ktc == kb * KPB;
+        r = ct_wait_one(g, first ? g.half + kb : g.flags + (int64_t)J * g.nct + kb, true);
+        if (r >= 0) r = first ? ktc + KPB / 2 : kt_end;
+      } else {
+        r = ct_wait_rows(g, I, J, kb, diag ? J - 1 : J);
+        if (r >= 0) r *= KPB;
+      }
+      s_i[1] = r;  // (every lane of wave 0 stores the same value)
+    }
     __syncthreads();
-    const int kb1 = __builtin_amdgcn_readfirstlane(s_i[1]);  // workgroup-uniform: keep the control flow scalar
-    if (kb1 < 0) return false;
-    const int kt0 = kb * (TILE / KT), kt1 = kb1 * (TILE / KT);
+    const int kt1 = __builtin_amdgcn_readfirstlane(s_i[1]);  // workgroup-uniform: keep the control flow scalar
+    if (kt1 < 0) return false;
+    const int kt0 = ktc;
     gload(kt0);
     lstore(0);
     __syncthreads();
@@ -235,7 +255,7 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
     }
     compute(st);
     __syncthreads();  // the next segment's first stage store (and the next wait's s_i) must not overtake slow waves
-    kb = kb1;
+    ktc = kt1;
   }
 
   // epilogue: T = A(I,J) - acc.  D layout of v_mfma_f64_16x16x4_f64: n = lane & 15, m = (lane >> 4) + 4 reg.
@@ -276,13 +296,15 @@ struct CtPtrs {  // the global pointers of CholTilesArgs, typed
   ct_g_double* logdet;
   ct_g_i32* info;
   ct_g_u32* flags;
+  ct_g_u32* half;
   ct_g_u32* ctl;
   ct_g_u64* dbg;
 };
 
 __device__ __forceinline__ CholTilesArgs ct_rebuild(const CholTilesArgs& g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
-                                                    ct_g_i32* info, ct_g_u32* flags, ct_g_u32* ctl, ct_g_u64* dbg) {
+                                                    ct_g_i32* info, ct_g_u32* flags, ct_g_u32* half, ct_g_u32* ctl, ct_g_u64* dbg) {
   CholTilesArgs g = g_in;
+  g.half = (uint32_t*)half;
   g.A = (double*)A;
   g.dinv16 = (double*)dinv16;
   g.logdet = (double*)logdet;
@@ -299,6 +321,7 @@ __device__ __forceinline__ void ct_publish(const CholTilesArgs& g, const int I, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave == 0) {
+    if (I == J + 1) __hip_atomic_store(g.half + J, 1u, CT_RLX_AGENT);  // (already up when the solve published its first half itself)
     __hip_atomic_store(g.flags + (int64_t)I * g.nct + J, 1u, CT_RLX_AGENT);
     if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
   }
@@ -307,9 +330,9 @@ __device__ __forceinline__ void ct_publish(const CholTilesArgs& g, const int I, 
 // Diagonal tile (J, J): contraction, leaf factorisation, publication.  false = the launch is being abandoned.
 template <int NW>
 __device__ __noinline__ bool ct_diag_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet, ct_g_i32* info,
-                                          ct_g_u32* flags, ct_g_u32* ctl, ct_g_u64* dbg, const int J, const int t, ct_lds_double* l3,
-                                          ct_lds_int* s3) {
-  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, ctl, dbg);
+                                          ct_g_u32* flags, ct_g_u32* half, ct_g_u32* ctl, ct_g_u64* dbg, const int J, const int t,
+                                          ct_lds_double* l3, ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg);
   double* lds = (double*)l3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (J > 0 && !ct_ksum<NW>(g, J, J, lds, (int*)s3)) return false;
@@ -337,9 +360,9 @@ __device__ __noinline__ bool ct_diag_task(const CholTilesArgs g_in, ct_g_double*
 // BEFORE the wait for the diagonal block (it does not depend on it); the solved slab is stored write-through.
 template <int NW>
 __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
-                                             ct_g_i32* info, ct_g_u32* flags, ct_g_u32* ctl, ct_g_u64* dbg, const int I, const int J,
-                                             const int t, ct_lds_double* l3, ct_lds_int* s3) {
-  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, ctl, dbg);
+                                             ct_g_i32* info, ct_g_u32* flags, ct_g_u32* half, ct_g_u32* ctl, ct_g_u64* dbg, const int I,
+                                             const int J, const int t, ct_lds_double* l3, ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg);
   int* s_i = (int*)s3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (J > 0 && !ct_ksum<NW>(g, I, J, (double*)l3, s_i)) return false;
@@ -363,8 +386,12 @@ __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_doub
   if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
   if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
   if (I == J + 1) __builtin_amdgcn_s_setprio(3);
-  trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
-  if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  if (NW == 8 && I == J + 1) {
+    trsm_strip_solve_store_pf<true, true>(ta, 16 * wave, X0, g.half + J);  // the chain's tile: first half published early
+  } else {
+    trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+    if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  }
   __builtin_amdgcn_s_setprio(0);
   ct_publish(g, I, J, t, wave);
   return true;
@@ -398,10 +425,10 @@ __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
     bool ok;
     if (I == J)
       ok = ct_diag_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.logdet, (ct_g_i32*)g.info, (ct_g_u32*)g.flags,
-                            (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+                            (ct_g_u32*)g.half, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
     else
       ok = ct_offdiag_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.logdet, (ct_g_i32*)g.info, (ct_g_u32*)g.flags,
-                               (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+                               (ct_g_u32*)g.half, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
     if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
     if (wave == 0) draw_ticket();  // the next one (every thread passed the barrier of the publication: s_i[0] is free)
     __syncthreads();

@@ -816,7 +816,7 @@ int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
 int chol_tiles(gmb_engine* e) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
   const int ntasks = ct_task_count(nct, nrt);
-  const int64_t words = 4 + (int64_t)nrt * nct;
+  const int64_t words = 4 + (int64_t)nrt * nct + nct;
   int rc;
   if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
   HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
@@ -831,6 +831,7 @@ int chol_tiles(gmb_engine* e) {
   a.info = e->dinfo;
   a.ctl = e->dct;
   a.flags = e->dct + 4;
+  a.half = e->dct + 4 + (int64_t)nrt * nct;
   a.ntasks = ntasks;
   a.timeout_us = 4000000u;  // a wait of 4 s means a lost flag: give the factorisation up, never the GPU
   a.dbg = nullptr;
