@@ -147,9 +147,12 @@ __device__ __forceinline__ int ct_wait_one(const CholTilesArgs& g, const uint32_
 // yet.  NW = 4: 2 x 2 waves of 4 x 4 MFMA tiles (two workgroups per compute unit); NW = 8: 4 x 2 waves of 2 x 4 MFMA
 // tiles (one workgroup per compute unit).  Every thread of the workgroup calls it; false = the launch is being
 // abandoned (uniform).
+// The accumulators start at -A(I,J) (requested first: the latency hides behind the first wait), so the epilogue is a
+// store of -acc with no read.  to_lds (diagonal tiles with a full block): the result goes straight into the leaf's
+// packed LDS layout (potrf_leaf_core<.., PRE = true>) instead of global memory.
 template <int NW>
 __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, const int J, double* __restrict__ lds,
-                                        int* s_i) {
+                                        int* s_i, const bool to_lds) {
   constexpr int WGN = 2, WGM = NW / WGN;           // waves along n (rows) and m (columns)
   constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);  // MFMA tiles per wave
   constexpr int KT = ct_kt(NW);            // (shadows gmb::KT of the launch-based GEMM)
@@ -164,11 +167,16 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
   const double* __restrict__ Ag = g.A + (int64_t)J * TILE + s_col;  // "m" operand: rows of block row J = columns of the tile
   const double* __restrict__ Bg = g.A + (int64_t)I * TILE + s_col;  // "n" operand: rows of block row I = rows of the tile
 
+  // D layout of v_mfma_f64_16x16x4_f64: n = lane & 15, m = (lane >> 4) + 4 reg
+  double* __restrict__ Cg = g.A + (int64_t)I * TILE + wn * (16 * WTN) + r16;
+  const int64_t m0 = (int64_t)J * TILE + wm * (16 * WTM) + kq;
   d4 acc[WTM][WTN];
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < WTN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j][r] = -Cg[(m0 + i * 16 + 4 * r) * g.ld + j * 16];
   d2 ra[NA], rb[NA];
 
   auto gload = [&](int kt) {
@@ -258,20 +266,30 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
     ktc = kt1;
   }
 
-  // epilogue: T = A(I,J) - acc.  D layout of v_mfma_f64_16x16x4_f64: n = lane & 15, m = (lane >> 4) + 4 reg.
-  double* __restrict__ Cg = g.A + (int64_t)I * TILE + wn * (16 * WTN) + r16;
-  const int64_t m0 = (int64_t)J * TILE + wm * (16 * WTM) + kq;
+  // epilogue: T = -acc
+  if (to_lds) {
+    // (the last barrier of the loop above has retired every read of the staging buffers the packed block overlays)
 #pragma unroll
-  for (int i = 0; i < WTM; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double* row = Cg + (m0 + i * 16 + 4 * r) * g.ld;
-      double c[WTN];
+      for (int r = 0; r < 4; ++r) {
+        const int c = wm * (16 * WTM) + i * 16 + kq + 4 * r;
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) c[j] = row[j * 16];
+        for (int j = 0; j < WTN; ++j) {
+          const int rr = wn * (16 * WTN) + j * 16 + r16;
+          if (rr >= (c & ~15)) lds[pk(rr, c)] = rr >= c ? -acc[i][j][r] : 0.0;
+        }
+      }
+  } else {
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) row[j * 16] = c[j] - acc[i][j][r];
-    }
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* row = Cg + (m0 + i * 16 + 4 * r) * g.ld;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) row[j * 16] = -acc[i][j][r];
+      }
+  }
   return true;
 }
 
@@ -335,22 +353,25 @@ __device__ __noinline__ bool ct_diag_task(const CholTilesArgs g_in, ct_g_double*
   const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg);
   double* lds = (double*)l3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (J > 0 && !ct_ksum<NW>(g, J, J, lds, (int*)s3)) return false;
+  const int nvalid = (int)(g.N - (int64_t)J * TILE < TILE ? g.N - (int64_t)J * TILE : TILE);
+  const bool pre = J > 0 && nvalid == TILE;  // the contraction leaves the block in the leaf's LDS layout
+  if (J > 0 && !ct_ksum<NW>(g, J, J, lds, (int*)s3, pre)) return false;
   if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
-  // this workgroup's own epilogue stores are read back by other lanes: drain, then barrier
+  // (not pre: this workgroup's own epilogue stores are read back by other lanes) drain, then barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
   LeafArgs a;
   a.A = g.A + (int64_t)J * TILE * (g.ld + 1);
   a.lda = g.ld;
-  a.nvalid = (int)(g.N - (int64_t)J * TILE < TILE ? g.N - (int64_t)J * TILE : TILE);
+  a.nvalid = nvalid;
   a.dinv16 = g.dinv16 + (int64_t)J * 8 * 256;
   a.logdet = g.logdet;
   a.info = g.info;
   a.row0 = (int64_t)J * TILE;
   a.dbg = nullptr;
-  potrf_leaf_core<NW, true>(a, lds);
+  if (pre) potrf_leaf_core<NW, true, true>(a, lds);
+  else potrf_leaf_core<NW, true, false>(a, lds);
   __builtin_amdgcn_s_setprio(0);
   ct_publish(g, J, J, t, wave);
   return true;
@@ -365,7 +386,7 @@ __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_doub
   const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg);
   int* s_i = (int*)s3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (J > 0 && !ct_ksum<NW>(g, I, J, (double*)l3, s_i)) return false;
+  if (J > 0 && !ct_ksum<NW>(g, I, J, (double*)l3, s_i, false)) return false;
   if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
   TrsmArgs ta;
   ta.B = g.A + (int64_t)I * TILE + (int64_t)J * TILE * g.ld;

@@ -302,7 +302,10 @@ constexpr int LEAF_LDS_DOUBLES = PK_SIZE + SB * SB + (LB + 1) + 8;  // 9873 doub
 
 // The leaf on LDS the caller provides (`lds`: LEAF_LDS_DOUBLES doubles, 16-byte aligned): the stand-alone kernel
 // below declares its own; the persistent tile Cholesky (chol_tiles.hpp) hands in the region its GEMM staging uses.
-template <int NW, bool WT = false>
+// PRE: the caller has already put the block into S (packed layout: (r, c) at pk(r, c) for r >= (c & ~15), zeros above
+// the diagonal inside the diagonal sub-blocks; full blocks only, nvalid == 128) -- the persistent tile Cholesky writes the
+// epilogue of the diagonal tile's contraction straight into LDS instead of sending it through global memory.
+template <int NW, bool WT = false, bool PRE = false>
 __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __restrict__ lds) {
   constexpr int NTH = 64 * NW;
   double* const S = lds;
@@ -336,7 +339,9 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
     S[a] = v[0];
     S[a + 1] = v[1];
   };
-  if (wave == 0) {
+  if constexpr (PRE) {
+    if (wave == 0) factor_diag16_mfma<WT>(&S[0], pk_pitch(0), dinv, gd, rdiag, 0, nv, g.info, g.row0, nullptr);
+  } else if (wave == 0) {
     d2 buf[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
