@@ -180,7 +180,7 @@ struct gmb_engine {
   bool ct_trace = false;
   bool ct_used = false;      // the last factorisation ran on the tile kernel (its abort word has to be read back)
   int ct_ntasks = 0;
-  int tiles_min_blocks = 40, tiles_max_blocks = 160;  // matrices (in 128-blocks) the tile kernel factors by default
+  int tiles_min_blocks = 16, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
   std::vector<hipEvent_t> sync_pool;
   size_t sync_next = 0;
