@@ -280,6 +280,41 @@ def cpu_baseline(cfg, target_seconds=20.0):
     }
 
 
+def tile_chain_summary(eng):
+    """One traced factorisation on the persistent tile kernel (csrc/chol_tiles.hpp; matrices of 16 .. 224 block columns): the
+    latency chain diagonal tile -> sub-diagonal tile -> next diagonal tile, per block column, and the contraction time per
+    k-block of the bulk tiles, from the per-task wall-clock stamps of gmb_chol_task_trace."""
+    eng.chol_task_trace(1)
+    try:
+        eng.factorize()
+        tr = eng.chol_task_trace(0)
+    finally:
+        eng.chol_task_trace(0)
+    if tr is None:
+        return None
+    return summarize_tile_trace(*tr)
+
+
+def summarize_tile_trace(tiles, stamps):
+    """(tiles, stamps) of Engine.chol_task_trace -> chain step / k-block statistics (pure numpy: tests/test_bench_host.py)."""
+    st = np.asarray(stamps, dtype=float) * 1e6  # us: taken / contraction done / solve input ready / published
+    tiles = np.asarray(tiles)
+    diag = {int(j): st[i] for i, (ii, j) in enumerate(tiles) if ii == j}
+    pub = np.array([diag[j][3] for j in sorted(diag)])
+    steps = np.diff(pub)
+    per_kb = [(st[i, 1] - st[i, 0]) / j for i, (ii, j) in enumerate(tiles) if j >= 8 and ii >= j + 2]
+    return {
+        "kernel": "chol_tiles_kernel<8> (one launch per factorisation)",
+        "block_columns": int(len(diag)), "tasks": int(len(tiles)),
+        "launch_us_traced": round(float(st[:, 3].max() - st[:, 0].min()), 1),
+        "chain_step_us": {"median": round(float(np.median(steps)), 1), "min": round(float(steps.min()), 1),
+                          "p90": round(float(np.percentile(steps, 90)), 1)} if len(steps) else None,
+        "leaf_us_median": round(float(np.median([d[3] - d[2] for d in diag.values()])), 1),
+        "contraction_us_per_k_block": {"median": round(float(np.median(per_kb)), 2), "max": round(float(np.max(per_kb)), 2)} if per_kb else None,
+        "note": "stamps cost a few per cent: the untraced launch is phases.profiled_last_evaluation_ms.chol_ms",
+    }
+
+
 def roofline_block(tm, config):
     """``roofline`` from the engine's per-launch HIP events (gmb_timings, cumulative since profiling was
     switched on): the trailing-update launches of the Cholesky alone, and every GEMM launch beside it."""
@@ -481,6 +516,7 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
     phases["profiled_last_evaluation_ms"] = {k: round(tm[k], 3) for k in
                                              ("kbuild_ms", "chol_ms", "chol_leaf_ms", "chol_trsm_ms", "chol_gemm_ms",
                                               "grad_ms", "grad_gemm_ms", "predict_ms", "predict_gemm_ms")}
+    phases["tile_cholesky"] = tile_chain_summary(eng)  # None when this size is factored by the stream schedules
     # the engine's streams go away before any other section creates its own: more than four live HIP
     # streams per process slow every kernel down on this stack
     eng.close()

@@ -153,3 +153,21 @@ def test_roofline_block_quotes_the_tile_kernel_when_the_factorisation_is_one_lau
     r = bench.roofline_block(tm, "c2")
     assert "chol_tiles_kernel" in r["kernel"] and r["launches"] == 3 and abs(r["achieved"] - 50.0) < 1e-9
     assert abs(r["frac"] - 50.0 / bench.FP64_MFMA_PEAK_TFLOPS) < 1e-4 and r["traffic"] is None and "in_panel_products" not in r
+
+
+def test_tile_trace_summary_reads_the_chain_off_the_stamps():
+    """summarize_tile_trace: chain step = distance between the publications of consecutive diagonal tiles; k-block time from
+    the bulk tiles (I >= J + 2) of the columns with at least 8 k-blocks."""
+    bench = load_bench()
+    nct = 12
+    tiles, stamps = [], []
+    for j in range(nct):
+        for i in range(j, nct):
+            tiles.append((i, j))
+            t0 = 50e-6 * j
+            ksum = 16e-6 * j
+            stamps.append((t0, t0 + ksum, t0 + ksum + 1e-6, 50e-6 * (j + 1) + (0 if i == j else 20e-6)))
+    out = bench.summarize_tile_trace(np.array(tiles), np.array(stamps))
+    assert out["block_columns"] == nct and out["tasks"] == len(tiles)
+    assert abs(out["chain_step_us"]["median"] - 50.0) < 1e-6 and abs(out["contraction_us_per_k_block"]["median"] - 16.0) < 1e-6
+
