@@ -62,6 +62,12 @@ struct CholTilesArgs {
   int32_t ntasks;
   uint32_t timeout_us;
   unsigned long long* dbg;  // optional, 4 x ntasks: wall-clock stamps (100 MHz) taken / contraction done / solve input ready / published
+  // Triangular solve V <- V L^-T with the factor in A (trsm_tiles_kernel; the predict path): V is ntm x nct tiles of 128 x 128,
+  // column-major with leading dimension ldv (rows = test points); task (r, c) owns tile (r, c) of V and waits for the tiles
+  // (r, k < c) of its own row only -- flags is ntm x nct then, and there are no diagonal tasks.
+  double* V;
+  int64_t ldv;
+  int32_t ntm;
 };
 
 __host__ __device__ inline int64_t ct_col_start(int J, int nrt) { return (int64_t)J * nrt - (int64_t)J * (J - 1) / 2; }
@@ -150,7 +156,9 @@ __device__ __forceinline__ int ct_wait_one(const CholTilesArgs& g, const uint32_
 // The accumulators start at -A(I,J) (requested first: the latency hides behind the first wait), so the epilogue is a
 // store of -acc with no read.  to_lds (diagonal tiles with a full block): the result goes straight into the leaf's
 // packed LDS layout (potrf_leaf_core<.., PRE = true>) instead of global memory.
-template <int NW>
+// TRSM: the "n" operand and the tile itself live in V (row tile I of the right-hand sides) instead of the factor buffer, and
+// only the flags of row I matter (the factor is final).
+template <int NW, bool TRSM = false>
 __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, const int J, double* __restrict__ lds,
                                         int* s_i, const bool to_lds) {
   constexpr int WGN = 2, WGM = NW / WGN;           // waves along n (rows) and m (columns)
@@ -165,10 +173,11 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
   const int r16 = lane & 15, kq = lane >> 4;
   const int s_row = tid / LA, s_col = 2 * (tid % LA);
   const double* __restrict__ Ag = g.A + (int64_t)J * TILE + s_col;  // "m" operand: rows of block row J = columns of the tile
-  const double* __restrict__ Bg = g.A + (int64_t)I * TILE + s_col;  // "n" operand: rows of block row I = rows of the tile
+  const int64_t ldb = TRSM ? g.ldv : g.ld;
+  const double* __restrict__ Bg = (TRSM ? g.V : g.A) + (int64_t)I * TILE + s_col;  // "n" operand: rows of block row I = rows of the tile
 
   // D layout of v_mfma_f64_16x16x4_f64: n = lane & 15, m = (lane >> 4) + 4 reg
-  double* __restrict__ Cg = g.A + (int64_t)I * TILE + wn * (16 * WTN) + r16;
+  double* __restrict__ Cg = (TRSM ? g.V : g.A) + (int64_t)I * TILE + wn * (16 * WTN) + r16;
   const int64_t m0 = (int64_t)J * TILE + wm * (16 * WTM) + kq;
   d4 acc[WTM][WTN];
 #pragma unroll
@@ -176,14 +185,14 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) acc[i][j][r] = -Cg[(m0 + i * 16 + 4 * r) * g.ld + j * 16];
+      for (int j = 0; j < WTN; ++j) acc[i][j][r] = -Cg[(m0 + i * 16 + 4 * r) * ldb + j * 16];
   d2 ra[NA], rb[NA];
 
   auto gload = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const d2*>(Ag + ((int64_t)kt * KT + s_row + RA * p) * g.ld);
 #pragma unroll
-    for (int p = 0; p < NA; ++p) rb[p] = *reinterpret_cast<const d2*>(Bg + ((int64_t)kt * KT + s_row + RA * p) * g.ld);
+    for (int p = 0; p < NA; ++p) rb[p] = *reinterpret_cast<const d2*>(Bg + ((int64_t)kt * KT + s_row + RA * p) * ldb);
   };
   auto lstore = [&](int st) {
     double* As = lds + st * (KT * 2 * PA);
@@ -216,7 +225,7 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
   // columns half way through its solve (half[J-1]), so the last block is taken in two halves.
   constexpr int KPB = TILE / KT;  // k-tiles per k-block
   const int kt_end = J * KPB;
-  const bool diag = I == J;
+  const bool diag = !TRSM && I == J;
   int ktc = 0;
   while (ktc < kt_end) {
     const int kb = ktc / KPB;
@@ -227,7 +236,7 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
         r = ct_wait_one(g, first ? g.half + kb : g.flags + (int64_t)J * g.nct + kb, true);
         if (r >= 0) r = first ? ktc + KPB / 2 : kt_end;
       } else {
-        r = ct_wait_rows(g, I, J, kb, diag ? J - 1 : J);
+        r = ct_wait_rows(g, I, TRSM ? I : J, kb, diag ? J - 1 : J);
         if (r >= 0) r *= KPB;
       }
       s_i[1] = r;  // (every lane of wave 0 stores the same value)
@@ -285,7 +294,7 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        double* row = Cg + (m0 + i * 16 + 4 * r) * g.ld;
+        double* row = Cg + (m0 + i * 16 + 4 * r) * ldb;
 #pragma unroll
         for (int j = 0; j < WTN; ++j) row[j * 16] = -acc[i][j][r];
       }
@@ -320,8 +329,10 @@ struct CtPtrs {  // the global pointers of CholTilesArgs, typed
 };
 
 __device__ __forceinline__ CholTilesArgs ct_rebuild(const CholTilesArgs& g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
-                                                    ct_g_i32* info, ct_g_u32* flags, ct_g_u32* half, ct_g_u32* ctl, ct_g_u64* dbg) {
+                                                    ct_g_i32* info, ct_g_u32* flags, ct_g_u32* half, ct_g_u32* ctl, ct_g_u64* dbg,
+                                                    ct_g_double* V = nullptr) {
   CholTilesArgs g = g_in;
+  g.V = (double*)V;
   g.half = (uint32_t*)half;
   g.A = (double*)A;
   g.dinv16 = (double*)dinv16;
@@ -416,6 +427,70 @@ __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_doub
   __builtin_amdgcn_s_setprio(0);
   ct_publish(g, I, J, t, wave);
   return true;
+}
+
+// Tile (r, c) of V <- V L^-T: contraction over the tiles (r, k < c) of its own row, strip solve against L(c, c) (final:
+// no wait), publication for the later tiles of the row.
+template <int NW>
+__device__ __noinline__ bool ct_trsm_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* V, ct_g_u32* flags,
+                                          ct_g_u32* ctl, ct_g_u64* dbg, const int r, const int c, const int t, ct_lds_double* l3,
+                                          ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, nullptr, nullptr, flags, nullptr, ctl, dbg, V);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (c > 0 && !ct_ksum<NW, true>(g, r, c, (double*)l3, (int*)s3, false)) return false;
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
+  TrsmArgs ta;
+  ta.B = g.V + (int64_t)r * TILE + (int64_t)c * TILE * g.ldv;
+  ta.ldb = g.ldv;
+  ta.nrows = TILE;
+  ta.L = g.A + (int64_t)c * TILE * (g.ld + 1);
+  ta.ldl = g.ld;
+  ta.dinv16 = g.dinv16 + (int64_t)c * 8 * 256;
+  ta.nvalid = (int)(g.N - (int64_t)c * TILE < TILE ? g.N - (int64_t)c * TILE : TILE);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own epilogue stores are read back by other lanes
+  __syncthreads();
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+  strip_d4 X0[8], X1[8];
+  trsm_strip_load(ta, 16 * wave, X0);
+  if constexpr (NW == 4) trsm_strip_load(ta, 16 * (wave + 4), X1);
+  trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+  if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave == 0) {
+    __hip_atomic_store(g.flags + (int64_t)r * g.nct + c, 1u, CT_RLX_AGENT);
+    if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
+  }
+  return true;
+}
+
+// V <- V L^-T as ONE persistent launch (the predict path for matrices the tile Cholesky factors): tickets in column-major
+// order (c outer, r inner) -- a task waits only for earlier tiles of its own row, so the order is topological and the
+// launch cannot deadlock.  Unlike the stream form (79 strip launches at N = 10k, each a kernel boundary on every row) the
+// rows advance independently and the contraction runs at the tile Cholesky's rate.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void trsm_tiles_kernel(CholTilesArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[ct_lds_doubles(NW)];
+  __shared__ int s_i[4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto draw_ticket = [&]() {  // (see chol_tiles_body: wave-uniform, every lane the same operands)
+    const unsigned old = atomicAdd(g.ctl, lane == 0 ? 1u : 0u);
+    s_i[0] = __builtin_amdgcn_readfirstlane((int)old);
+  };
+  if (wave == 0) draw_ticket();
+  __syncthreads();
+  for (;;) {
+    const int t = __builtin_amdgcn_readfirstlane(s_i[0]);
+    if (t >= g.ntasks) return;
+    const int c = t / g.ntm, r = t - c * g.ntm;
+    if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 0] = wall_clock64();
+    const bool ok = ct_trsm_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.V, (ct_g_u32*)g.flags, (ct_g_u32*)g.ctl,
+                                     (ct_g_u64*)g.dbg, r, c, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
+    if (wave == 0) draw_ticket();
+    __syncthreads();
+  }
 }
 
 template <int NW>

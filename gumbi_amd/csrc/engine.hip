@@ -179,6 +179,7 @@ struct gmb_engine {
   int64_t cap_ct_trace = 0;
   bool ct_trace = false;
   bool ct_used = false;      // the last factorisation ran on the tile kernel (its abort word has to be read back)
+  bool tt_used = false;      // the current prediction ran its triangular solve on the tile kernel (same abort word)
   int ct_ntasks = 0;
   int tiles_min_blocks = 16, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
@@ -859,6 +860,40 @@ int chol_tiles(gmb_engine* e) {
   HIP_TRY(e, hipGetLastError());
   e->ct_used = true;
   e->ct_ntasks = ntasks;
+  return GMB_OK;
+}
+
+// V <- V L^-T (V: ntm x Np/128 tiles, leading dimension ldv) as one persistent launch (chol_tiles.hpp: trsm_tiles_kernel)
+int trsm_tiles(gmb_engine* e, double* V, int64_t ldv, int ntm, int ev_kind) {
+  const int nct = (int)(e->Np / TILE);
+  const long long ntasks = (long long)ntm * nct;
+  if (ntasks <= 0) return GMB_OK;
+  const int64_t words = 4 + (int64_t)ntm * nct;
+  int rc;
+  if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
+  CholTilesArgs a{};
+  a.A = e->dA;
+  a.ld = e->ld;
+  a.nct = nct;
+  a.nrt = nct;
+  a.N = e->N;
+  a.dinv16 = e->dDinv16;
+  a.ctl = e->dct;
+  a.flags = e->dct + 4;
+  a.ntasks = (int)ntasks;
+  a.timeout_us = 4000000u;
+  a.V = V;
+  a.ldv = ldv;
+  a.ntm = ntm;
+  double flops = 0.0;
+  for (int c = 0; c < nct; ++c) flops += (double)ntm * (2.0 * TILE * TILE * TILE * c + (double)TILE * TILE * TILE);
+  const int grid = (int)std::min<long long>(ntasks, e->wg_slots / 2);
+  ev_begin(e, ev_kind, flops, nct, ntm, (int)e->Np, 0);
+  hipLaunchKernelGGL(trsm_tiles_kernel<8>, dim3(grid), dim3(512), 0, e->cur, a);
+  ev_end(e);
+  HIP_TRY(e, hipGetLastError());
+  e->tt_used = true;
   return GMB_OK;
 }
 
@@ -2028,7 +2063,23 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
     if (e->terms.size() > 1 &&
         (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
       return rc;
-    if ((rc = trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, (int)(e->Np / TILE), 3, 6))) return rc;
+    {
+      // the triangular solve V <- V L^-T: one persistent launch for the matrices the tile Cholesky factors, else the recursion
+      const int nblocks = (int)(e->Np / TILE);
+      const bool tiles = !e->naive_leaf && (e->chol_scheme == 3 || (e->chol_scheme < 0 && nblocks >= e->tiles_min_blocks &&
+                                                                     nblocks <= e->tiles_max_blocks));
+      e->cur = e->stream;
+      e->tt_used = false;
+      if ((rc = tiles ? trsm_tiles(e, e->dV, mpad, (int)(mpad / TILE), 3)
+                      : trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, nblocks, 3, 6)))
+        return rc;
+      if (e->tt_used) {  // a launch that gave up waiting must not be mistaken for a prediction
+        uint32_t ab = 0;
+        HIP_TRY(e, hipMemcpyAsync(&ab, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (ab != 0) return fail(e, GMB_EHIP, "tile triangular solve: a workgroup waited longer than its time-out for a tile (launch abandoned)");
+      }
+    }
     {
       double* pmu = e->dpart;
       double* ps = e->dpart + (int64_t)nchunk * mpad;

@@ -32,13 +32,25 @@ for N, d in sizes:
         for _ in range(reps):
             e.factorize()
             best = min(best, e.timings()['chol_ms'])
+        if os.environ.get('CT_PREDICT') == '1':  # the triangular solve of the predict path follows the same switch
+            Xs = np.random.default_rng(5).standard_normal((int(os.environ.get('CT_M', '10000')), d))
+            mu, var = e.predict(Xs)
+            tp = 1e9
+            for _ in range(reps):
+                e.predict(Xs)
+                tp = min(tp, e.timings()['predict_ms'])
+            if scheme == schemes[0]:
+                pref = (mu, var)
+            pd = f" predict {tp:.2f} ms ({N * N * len(Xs) / tp / 1e9:.1f} TF/s) dmu {np.max(np.abs(mu - pref[0])) / np.max(np.abs(pref[0])):.1e} dvar {np.max(np.abs(var - pref[1])):.1e}"
+        else:
+            pd = ""
         if ref is None:
             ref = (rows, v, nl)
-            line.append(f"scheme {scheme}: {best:.3f} ms ({N**3/3/best/1e9:.1f} TF/s) nlml {nl:.12g}")
+            line.append(f"scheme {scheme}: {best:.3f} ms ({N**3/3/best/1e9:.1f} TF/s) nlml {nl:.12g}" + pd)
         else:
             dl = np.max(np.abs(np.tril(rows, N - nr) - np.tril(ref[0], N - nr))) / np.max(np.abs(ref[0]))
             dv = np.max(np.abs(v - ref[1])) / np.max(np.abs(ref[1]))
-            line.append(f"scheme {scheme}: {best:.3f} ms ({N**3/3/best/1e9:.1f} TF/s) dL {dl:.1e} dv {dv:.1e} dnlml {abs(nl-ref[2])/abs(ref[2]):.1e}")
+            line.append(f"scheme {scheme}: {best:.3f} ms ({N**3/3/best/1e9:.1f} TF/s) dL {dl:.1e} dv {dv:.1e} dnlml {abs(nl-ref[2])/abs(ref[2]):.1e}" + pd)
     print(f"N={N} d={d}: " + " | ".join(line), flush=True)
     if os.environ.get('CT_TRACE') == '1' and 3 in schemes:
         e.set_chol_scheme(3)
