@@ -587,10 +587,14 @@ def test_tile_cholesky_matches_oracle(gpu, N):
     val_r, grad_r = O.nlml_and_grad(spec, theta, X, y)
     val, grad = eng.nlml(grad=True)
     assert abs(val - val_r) < 1e-10 * max(1.0, abs(val_r)) and rel(grad, grad_r) < 1e-8
-    Xs = np.random.default_rng(3).standard_normal((200, d))
-    mu, var = eng.predict(Xs)
-    mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
-    assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-9
+    # 200 test points: the recursion's triangular solve; 1500: the persistent tile solve (trsm_tiles_kernel, 8 .. 96 row tiles)
+    for M in (200, 1500):
+        Xs = np.random.default_rng(3).standard_normal((M, d))
+        mu, var = eng.predict(Xs)
+        mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+        assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-9
+        mu2, var2 = eng.predict(Xs)
+        assert mu2.tobytes() == mu.tobytes() and var2.tobytes() == var.tobytes()  # bit-reproducible
     eng.close()
 
 
