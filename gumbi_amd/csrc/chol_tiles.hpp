@@ -98,7 +98,9 @@ __device__ __forceinline__ bool ct_give_up(const CholTilesArgs& g, unsigned& spi
     t0 = now;
     return false;
   }
-  if (now - t0 > (unsigned long long)g.timeout_us * 100ull) {
+  // both the wall clock AND a million polls actually executed: a process that was swapped off the GPU for seconds (several
+  // ranks sharing one device) comes back with the clock advanced but nothing wrong
+  if (now - t0 > (unsigned long long)g.timeout_us * 100ull && spins > (1u << 20)) {
     __hip_atomic_store(g.ctl + 1, 1u, CT_RLX_AGENT);
     return true;
   }

@@ -1,6 +1,7 @@
 // Stand-alone probe of the persistent tile Cholesky's pieces (first hardware contact / debugging):
 //   ct_probe <test> [N]   test 0: leaf core<4> inlined in a 256-thread kernel; 1: the same through the non-inlined call;
-//                         2: chol_tiles_kernel on an N x N matrix (default 128); 6: the same with 8 waves; prints max |L - L_ref|.
+//                         2: chol_tiles_kernel on an N x N matrix (default 128); 6: the same with 8 waves; 7: the same with a lost tile (expects `abort 1` after the
+//                         time-out, not a hang); prints max |L - L_ref|.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/ct_probe.hip -o tools/probes/bin/ct_probe
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -101,6 +102,11 @@ int main(int argc, char** argv) {
     const int grid = ntasks < 512 ? ntasks : 512;
     if (test == 2) hipLaunchKernelGGL(chol_tiles_kernel<4>, dim3(grid), dim3(256), 0, st, g);
     if (test == 6) hipLaunchKernelGGL(chol_tiles_kernel<8>, dim3(grid < 256 ? grid : 256), dim3(512), 0, st, g);
+    if (test == 7) {  // a lost tile: ticket 0 is never handed out, every other task waits for tile (0, 0) -- the watchdog must end the launch
+      const uint32_t one = 1;
+      CK(hipMemcpy(dct, &one, 4, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(chol_tiles_kernel<8>, dim3(grid < 256 ? grid : 256), dim3(512), 0, st, g);
+    }
   }
   CK(hipGetLastError());
   auto t0 = std::chrono::steady_clock::now();
