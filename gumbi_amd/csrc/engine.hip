@@ -181,6 +181,7 @@ struct gmb_engine {
   bool ct_used = false;      // the last factorisation ran on the tile kernel (its abort word has to be read back)
   bool tt_used = false;      // the current prediction ran its triangular solve on the tile kernel (same abort word)
   int ct_ntasks = 0;
+  int ct_lose = 0;           // fault injection (gmb_debug_chol_lose_tickets): one shot
   int tiles_min_blocks = 16, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
   std::vector<hipEvent_t> sync_pool;
@@ -821,6 +822,12 @@ int chol_tiles(gmb_engine* e) {
   int rc;
   if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
   HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
+  if (e->ct_lose > 0) {  // fault injection: tickets 0 .. ct_lose-1 are never handed out
+    const uint32_t first = (uint32_t)e->ct_lose;
+    e->ct_lose = 0;
+    HIP_TRY(e, hipMemcpyAsync(e->dct, &first, sizeof first, hipMemcpyHostToDevice, e->cur));
+    HIP_TRY(e, hipStreamSynchronize(e->cur));  // (`first` lives on this stack frame)
+  }
   CholTilesArgs a{};
   a.A = e->dA;
   a.ld = e->ld;
@@ -2334,6 +2341,12 @@ int64_t gmb_chol_task_trace(gmb_engine* e, int32_t enable, uint64_t* out, int64_
     HIP_TRY(e, hipMemcpy(out, e->dct_trace, (size_t)std::min<int64_t>(n, cap_tasks) * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   }
   return n;
+}
+
+int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n) {
+  if (!e || n < 0) return GMB_EINVAL;
+  e->ct_lose = n;
+  return GMB_OK;
 }
 
 int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme) {

@@ -248,6 +248,7 @@ _SIGNATURES = {
     "gmb_debug_chol_task": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gmb_chol_task_trace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "gmb_set_chol_scheme": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gmb_debug_chol_lose_tickets": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gmb_blk_covariance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "gmb_blk_trsm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
@@ -474,6 +475,10 @@ class Engine:
     def set_chol_scheme(self, scheme: int) -> int:
         """Schedule of the following factorisations; returns the previous setting."""
         return int(self._lib.gmb_set_chol_scheme(self._h, int(scheme)))
+
+    def debug_lose_tickets(self, n: int):
+        """Fault injection (tests): the next tile factorisation never computes the tiles of tickets 0 .. n-1."""
+        self._check(self._lib.gmb_debug_chol_lose_tickets(self._h, int(n)), "gmb_debug_chol_lose_tickets")
 
     def chol_task_trace(self, enable: int = -1):
         """Per-task stamps of the last persistent tile factorisation: ``(tiles, stamps)`` with ``tiles`` the (I, J) of every

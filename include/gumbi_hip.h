@@ -282,6 +282,10 @@ int64_t gmb_debug_chol_task(int32_t t, int32_t nct, int32_t nrt, int32_t* I, int
  * cap_tasks of them.  Returns the number of tasks of the last tile factorisation (0: the last factorisation used another
  * schedule or recorded nothing), or a negative gmb_status. */
 int64_t gmb_chol_task_trace(gmb_engine* e, int32_t enable, uint64_t* out, int64_t cap_tasks);
+/* Fault injection for the tests: the NEXT persistent tile factorisation starts its ticket counter at `n`, i.e. the tiles of
+ * tickets 0 .. n-1 are never computed and every other task ends up waiting for one of them.  The launch must notice (bounded
+ * waits: a few seconds), drain, and gmb_factorize must return GMB_EHIP -- never hang the GPU.  One shot. */
+int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n);
 /* Schedule of the Cholesky for the following factorisations: -1 = by size (default), 0 = plain recursion, 2 = masked
  * look-ahead, 3 = persistent tile kernel.  Returns the previous setting. */
 int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme);

@@ -638,3 +638,30 @@ def test_tile_cholesky_reports_the_first_bad_pivot_like_the_recursion(gpu):
         assert np.isfinite(eng.nlml())
         eng.close()
     assert rows[0] == rows[3] >= 0
+
+
+def test_tile_cholesky_gives_up_on_a_lost_tile_instead_of_hanging(gpu):
+    """Fault injection: the first diagonal tile is never computed, so every other task of the launch ends up waiting for it.
+    The waits are bounded -- the launch drains after its time-out and gmb_factorize fails loudly (GumbiHipError, status
+    GMB_EHIP) within seconds; the engine then factorises the same problem correctly (fresh flags and tickets every launch)."""
+    import time
+
+    from gumbi_amd.engine import GumbiHipError
+
+    N, d = 3000, 3
+    X, y, ls = O.synthetic_table(N, d, seed=4)
+    spec = O.make_spec(d, range(d))
+    theta = O.pack_theta(spec, ls, 1.0, 0.2)
+    eng = make_engine(spec, theta, X, y)
+    eng.set_chol_scheme(eng.CHOL_TILES)
+    eng.factorize()
+    ref = eng.nlml()
+    eng.debug_lose_tickets(1)
+    t0 = time.time()
+    with pytest.raises(GumbiHipError, match="time-out"):
+        eng.factorize()
+    assert 1.0 < time.time() - t0 < 30.0
+    eng.factorize()
+    assert eng.nlml() == ref
+    eng.close()
+
