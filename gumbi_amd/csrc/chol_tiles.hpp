@@ -58,6 +58,7 @@ struct CholTilesArgs {
   int32_t* info;    // first non-positive pivot (global row + 1), 0 = ok
   uint32_t* flags;  // nrt * nct words, zeroed by the host before the launch; tile (I, J) is final when [I * nct + J] != 0
   uint32_t* half;   // nct words (zeroed with the flags): the first 64 columns of the sub-diagonal tile (J + 1, J) are final
+  uint32_t* prog;   // nct words (zeroed with the flags): progress of the leaf of column J (LeafArgs::prog)
   uint32_t* ctl;    // [0] ticket counter, [1] abort word (zeroed with the flags)
   int32_t ntasks;
   uint32_t timeout_us;
@@ -326,15 +327,17 @@ struct CtPtrs {  // the global pointers of CholTilesArgs, typed
   ct_g_i32* info;
   ct_g_u32* flags;
   ct_g_u32* half;
+  ct_g_u32* prog;
   ct_g_u32* ctl;
   ct_g_u64* dbg;
 };
 
 __device__ __forceinline__ CholTilesArgs ct_rebuild(const CholTilesArgs& g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
                                                     ct_g_i32* info, ct_g_u32* flags, ct_g_u32* half, ct_g_u32* ctl, ct_g_u64* dbg,
-                                                    ct_g_double* V = nullptr) {
+                                                    ct_g_double* V = nullptr, ct_g_u32* prog = nullptr) {
   CholTilesArgs g = g_in;
   g.V = (double*)V;
+  g.prog = (uint32_t*)prog;
   g.half = (uint32_t*)half;
   g.A = (double*)A;
   g.dinv16 = (double*)dinv16;
@@ -361,9 +364,9 @@ __device__ __forceinline__ void ct_publish(const CholTilesArgs& g, const int I, 
 // Diagonal tile (J, J): contraction, leaf factorisation, publication.  false = the launch is being abandoned.
 template <int NW>
 __device__ __noinline__ bool ct_diag_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet, ct_g_i32* info,
-                                          ct_g_u32* flags, ct_g_u32* half, ct_g_u32* ctl, ct_g_u64* dbg, const int J, const int t,
-                                          ct_lds_double* l3, ct_lds_int* s3) {
-  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg);
+                                          ct_g_u32* flags, ct_g_u32* half, ct_g_u32* prog, ct_g_u32* ctl, ct_g_u64* dbg, const int J,
+                                          const int t, ct_lds_double* l3, ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg, nullptr, prog);
   double* lds = (double*)l3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nvalid = (int)(g.N - (int64_t)J * TILE < TILE ? g.N - (int64_t)J * TILE : TILE);
@@ -383,6 +386,7 @@ __device__ __noinline__ bool ct_diag_task(const CholTilesArgs g_in, ct_g_double*
   a.info = g.info;
   a.row0 = (int64_t)J * TILE;
   a.dbg = nullptr;
+  a.prog = NW == 8 ? g.prog + J : nullptr;  // (the strip solve below it follows the leaf column by column)
   if (pre) potrf_leaf_core<NW, true, true>(a, lds);
   else potrf_leaf_core<NW, true, false>(a, lds);
   __builtin_amdgcn_s_setprio(0);
@@ -390,13 +394,81 @@ __device__ __noinline__ bool ct_diag_task(const CholTilesArgs g_in, ct_g_double*
   return true;
 }
 
+// The strip solve of the CHAIN's tile (J + 1, J), following the leaf of (J, J) column by column: step s needs row block s
+// of L(J, J) -- block columns < s -- and the sub-block inverse s, which the leaf publishes as `prog` = s + 1
+// (LeafArgs::prog) while it is still factoring the rest.  Every wave polls for itself (relaxed, agent scope) and reads its
+// operands with write-through-coherent loads (sc1: they were stored sc1 and must not come from this compute unit's L1),
+// so there is no fence and no workgroup barrier per step.  The operands of step s + 1 are requested before step s is
+// computed, as in trsm_strip_solve_store_pf; the first 64 columns are published half way (`half_flag`), the caller
+// publishes the tile.  A poll that gives up (abort word / time-out) simply stops waiting: the result is garbage, the
+// caller sees the abort word.
+__device__ __forceinline__ void ct_strip_solve_pipelined(const CholTilesArgs& g, const TrsmArgs& ta, const int64_t r0, strip_d4 (&X)[8],
+                                                        const uint32_t* prog, uint32_t* half_flag) {
+  typedef strip_d4 d4;
+  const int lane = threadIdx.x & 63;
+  const int r16 = lane & 15, kq = lane >> 4;
+  double* Bp = ta.B + r0 + r16;
+  unsigned spins = 0;
+  unsigned long long t0 = 0ull;
+  bool gave_up = false;
+  auto wait_prog = [&](const uint32_t need) {
+    while (!gave_up && __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog, CT_RLX_AGENT)) < need) {
+      if (ct_give_up(g, spins, t0)) gave_up = true;
+      else __builtin_amdgcn_s_sleep(1);
+    }
+  };
+  double ops[2][32];
+  auto load_step = [&](const int s, double (&o)[32]) {
+    const double* Lrow = ta.L + 16 * s + r16;
+#pragma unroll
+    for (int t = 0; t < s; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) o[4 * t + kk] = __hip_atomic_load(&Lrow[(int64_t)(16 * t + 4 * kk + kq) * ta.ldl], CT_RLX_AGENT);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) o[28 + kk] = __hip_atomic_load(&ta.dinv16[s * 256 + (4 * kk + kq) * 16 + r16], CT_RLX_AGENT);
+  };
+  wait_prog(1u);
+  load_step(0, ops[0]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s < 7) {
+      wait_prog((uint32_t)(s + 2));
+      load_step(s + 1, ops[(s + 1) & 1]);
+    }
+    asm volatile("" ::: "memory");  // keep the requests above the MFMAs below
+    const double(&o)[32] = ops[s & 1];
+    d4 y = X[s];
+#pragma unroll
+    for (int t = 0; t < s; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) y = __builtin_amdgcn_mfma_f64_16x16x4f64(-o[4 * t + kk], X[t][kk], y, 0, 0, 0);
+    d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(o[28 + kk], y[kk], x, 0, 0, 0);
+    X[s] = x;
+    if (s == 3) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __hip_atomic_store(&Bp[(int64_t)(16 * s2 + kq + 4 * q) * ta.ldb], X[s2][q], CT_RLX_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) __hip_atomic_store(half_flag, 1u, CT_RLX_AGENT);
+    }
+  }
+#pragma unroll
+  for (int s = 4; s < 8; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) __hip_atomic_store(&Bp[(int64_t)(16 * s + kq + 4 * q) * ta.ldb], X[s][q], CT_RLX_AGENT);
+}
+
 // Off-diagonal tile (I, J): contraction, strip solve against L(J, J), publication.  The slab's own data is requested
 // BEFORE the wait for the diagonal block (it does not depend on it); the solved slab is stored write-through.
 template <int NW>
 __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* logdet,
-                                             ct_g_i32* info, ct_g_u32* flags, ct_g_u32* half, ct_g_u32* ctl, ct_g_u64* dbg, const int I,
-                                             const int J, const int t, ct_lds_double* l3, ct_lds_int* s3) {
-  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg);
+                                             ct_g_i32* info, ct_g_u32* flags, ct_g_u32* half, ct_g_u32* prog, ct_g_u32* ctl, ct_g_u64* dbg,
+                                             const int I, const int J, const int t, ct_lds_double* l3, ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg, nullptr, prog);
   int* s_i = (int*)s3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (J > 0 && !ct_ksum<NW>(g, I, J, (double*)l3, s_i, false)) return false;
@@ -415,16 +487,28 @@ __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_doub
   strip_d4 X0[8], X1[8];
   trsm_strip_load(ta, 16 * wave, X0);
   if constexpr (NW == 4) trsm_strip_load(ta, 16 * (wave + 4), X1);
-  if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J, I == J + 1);
-  __syncthreads();
-  if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
-  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
-  if (I == J + 1) __builtin_amdgcn_s_setprio(3);
-  if (NW == 8 && I == J + 1) {
-    trsm_strip_solve_store_pf<true, true>(ta, 16 * wave, X0, g.half + J);  // the chain's tile: first half published early
+  if (NW == 8 && I == J + 1 && ta.nvalid == TILE) {
+    // the chain's tile: follow the leaf of (J, J) column by column instead of waiting for its flag
+    if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+    __builtin_amdgcn_s_setprio(3);
+    ct_strip_solve_pipelined(g, ta, 16 * wave, X0, g.prog + J, g.half + J);
+    __builtin_amdgcn_s_setprio(0);
+    if (wave == 0) s_i[1] = __builtin_amdgcn_readfirstlane(__hip_atomic_load(g.ctl + 1, CT_RLX_AGENT)) != 0u ? -1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
   } else {
-    trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
-    if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+    if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J, I == J + 1);
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
+    if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+    if (I == J + 1) __builtin_amdgcn_s_setprio(3);
+    if (NW == 8 && I == J + 1) {
+      trsm_strip_solve_store_pf<true, true>(ta, 16 * wave, X0, g.half + J);  // the chain's tile: first half published early
+    } else {
+      trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+      if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+    }
   }
   __builtin_amdgcn_s_setprio(0);
   ct_publish(g, I, J, t, wave);
@@ -523,10 +607,10 @@ __device__ __forceinline__ void chol_tiles_body(const CholTilesArgs& g) {
     bool ok;
     if (I == J)
       ok = ct_diag_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.logdet, (ct_g_i32*)g.info, (ct_g_u32*)g.flags,
-                            (ct_g_u32*)g.half, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+                            (ct_g_u32*)g.half, (ct_g_u32*)g.prog, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
     else
       ok = ct_offdiag_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.logdet, (ct_g_i32*)g.info, (ct_g_u32*)g.flags,
-                               (ct_g_u32*)g.half, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+                               (ct_g_u32*)g.half, (ct_g_u32*)g.prog, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
     if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
     if (wave == 0) draw_ticket();  // the next one (every thread passed the barrier of the publication: s_i[0] is free)
     __syncthreads();

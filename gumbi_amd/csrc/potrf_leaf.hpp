@@ -80,6 +80,10 @@ struct LeafArgs {
   int64_t row0;     // global index of the block's first row (for info)
   double* dbg;      // optional: 8 wall-clock stamps (100 MHz) at the phase boundaries
                     // (software XCD partition probe, GMB_PROBE_XCD)
+  uint32_t* prog;   // optional (persistent tile Cholesky, full blocks only): progress word another workgroup polls --
+                    // value k + 1 = block columns 0 .. k-1 of the factored block and the sub-block inverses 0 .. k
+                    // are in memory (stored write-through).  The strip solve of the tile below starts its step k then
+                    // instead of waiting for the whole block.
 };
 
 #define LEAF_STAMP(i) do { if (g.dbg && threadIdx.x == 0) g.dbg[i] = (double)wall_clock64(); } while (0)
@@ -307,6 +311,7 @@ constexpr int LEAF_LDS_DOUBLES = PK_SIZE + SB * SB + (LB + 1) + 8;  // 9873 doub
 // epilogue of the diagonal tile's contraction straight into LDS instead of sending it through global memory.
 template <int NW, bool WT = false, bool PRE = false>
 __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __restrict__ lds) {
+  const bool pipe = WT && g.prog != nullptr && g.nvalid == LB;  // publish block column by block column
   constexpr int NTH = 64 * NW;
   double* const S = lds;
   double* const dinv = lds + PK_SIZE;
@@ -378,6 +383,10 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
   }
   __syncthreads();
   LEAF_STAMP(1);
+  if (pipe && wave == 0) {  // the first sub-block inverse is out (wave 0 stored it above)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(g.prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // finished block column s goes back to global memory while the factorisation continues
   auto write_back = [&](int s, int first, int nthreads) {
@@ -452,17 +461,24 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
 #pragma unroll
           for (int r = 0; r < 4; ++r) dst[(kq + 4 * r) * pd] -= acc[r];
         }
-        // write-back is deferred to the steps where these waves run out of update tiles
-        if (s >= 3) write_back(s - 3, tid - 64, NTH - 64);
+        // write-back is deferred to the steps where these waves run out of update tiles -- unless the block is
+        // published column by column: then block column s goes out now and must have landed before the barrier
+        if (pipe) {
+          write_back(s, tid - 64, NTH - 64);
+        } else if (s >= 3) {
+          write_back(s - 3, tid - 64, NTH - 64);
+        }
       }
+      if (pipe) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (wave 0: the next sub-block inverse)
     }
     LEAF_STAMP(10 + 3 * s);
     __syncthreads();
+    if (pipe && wave == 0) __hip_atomic_store(g.prog, (uint32_t)(s + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
   LEAF_STAMP(2);
   // ---- remaining block columns back, accumulate log-det --------------------------------------
-  for (int s = LB / SB - 4; s < LB / SB; ++s) write_back(s, tid, NTH);
+  for (int s = pipe ? LB / SB - 1 : LB / SB - 4; s < LB / SB; ++s) write_back(s, tid, NTH);
   {
     double lg = 0.0;
     if (tid < nv) lg = -log(rdiag[tid]);
