@@ -57,7 +57,7 @@ struct CholTilesArgs {
   double* logdet;   // += sum log L_cc
   int32_t* info;    // first non-positive pivot (global row + 1), 0 = ok
   uint32_t* flags;  // nrt * nct words, zeroed by the host before the launch; tile (I, J) is final when [I * nct + J] != 0
-  uint32_t* half;   // nct words (zeroed with the flags): the first 64 columns of the sub-diagonal tile (J + 1, J) are final
+  uint32_t* half;   // 2 x nct words (zeroed with the flags): the first 64 columns of the tiles (J + 1, J) [word J] and (J + 2, J) [word nct + J] are final
   uint32_t* prog;   // nct words (zeroed with the flags): progress of the leaf of column J (LeafArgs::prog)
   uint32_t* ctl;    // [0] ticket counter, [1] abort word (zeroed with the flags)
   int32_t ntasks;
@@ -151,6 +151,22 @@ __device__ __forceinline__ int ct_wait_one(const CholTilesArgs& g, const uint32_
   }
 }
 
+// ONE wave: wait until both words are set (the same word twice = one word); 0 = acquired, -1 = abandoned
+__device__ __forceinline__ int ct_wait_two(const CholTilesArgs& g, const uint32_t* p, const uint32_t* q) {
+  unsigned spins = 0;
+  unsigned long long t0 = 0ull;
+  for (;;) {
+    const uint32_t a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, CT_RLX_AGENT));
+    const uint32_t b = __builtin_amdgcn_readfirstlane(__hip_atomic_load(q, CT_RLX_AGENT));
+    if (a != 0u && b != 0u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return 0;
+    }
+    if (ct_give_up(g, spins, t0)) return -1;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 // T = A(I,J) - sum_{k < 128 J} L(I,k) L(J,k)^T, written over A(I,J).  The k loop of gemm_f64_body (same staging,
 // same pinned instruction order) on a 128 x 128 tile, cut into segments at the k-blocks whose tiles were not final
 // yet.  NW = 4: 2 x 2 waves of 4 x 4 MFMA tiles (two workgroups per compute unit); NW = 8: 4 x 2 waves of 2 x 4 MFMA
@@ -222,24 +238,30 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
     }
   };
 
-  // The contraction runs in SEGMENTS of k-tiles whose operands are final.  Off-diagonal tiles: runs of k-blocks by
-  // the tile flags of block rows I and J.  Diagonal tiles: the same up to the last k-block, which comes from the
-  // sub-diagonal tile (J, J-1) of the column before -- the end of the latency chain; that tile publishes its first 64
-  // columns half way through its solve (half[J-1]), so the last block is taken in two halves.
+  // The contraction runs in SEGMENTS of k-tiles whose operands are final.  Ordinary tiles: runs of k-blocks by the
+  // tile flags of block rows I and J.  The tiles of the latency chain -- the diagonal tile and the one below it -- take
+  // their LAST k-block, which comes from the tiles (I, J-1) and (J, J-1) of the column before (the chain's own output), in
+  // two halves: those tiles publish their first 64 columns half way through their solve (half[]).
   constexpr int KPB = TILE / KT;  // k-tiles per k-block
   const int kt_end = J * KPB;
   const bool diag = !TRSM && I == J;
+  const bool chain = !TRSM && I <= J + 1;
   int ktc = 0;
   while (ktc < kt_end) {
     const int kb = ktc / KPB;
     if (wave == 0) {
       int r;
-      if (diag && kb == J - 1) {
+      if (chain && kb == J - 1) {
         const bool first = ktc == kb * KPB;
-        r = ct_wait_one(g, first ? g.half + kb : g.flags + (int64_t)J * g.nct + kb, true);
+        // tile (J, J-1) is the first sub-diagonal tile of column J-1, tile (J+1, J-1) the second
+        const uint32_t* hp = g.half + kb;
+        const uint32_t* hq = diag ? hp : g.half + g.nct + kb;
+        const uint32_t* fp = g.flags + (int64_t)J * g.nct + kb;
+        const uint32_t* fq = g.flags + (int64_t)I * g.nct + kb;
+        r = first ? ct_wait_two(g, hp, hq) : ct_wait_two(g, fp, fq);
         if (r >= 0) r = first ? ktc + KPB / 2 : kt_end;
       } else {
-        r = ct_wait_rows(g, I, TRSM ? I : J, kb, diag ? J - 1 : J);
+        r = ct_wait_rows(g, I, TRSM ? I : J, kb, chain ? J - 1 : J);
         if (r >= 0) r *= KPB;
       }
       s_i[1] = r;  // (every lane of wave 0 stores the same value)
@@ -355,7 +377,7 @@ __device__ __forceinline__ void ct_publish(const CholTilesArgs& g, const int I, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave == 0) {
-    if (I == J + 1) __hip_atomic_store(g.half + J, 1u, CT_RLX_AGENT);  // (already up when the solve published its first half itself)
+    if (I == J + 1 || I == J + 2) __hip_atomic_store(g.half + (int64_t)(I - J - 1) * g.nct + J, 1u, CT_RLX_AGENT);  // (already up when the solve published its first half itself)
     __hip_atomic_store(g.flags + (int64_t)I * g.nct + J, 1u, CT_RLX_AGENT);
     if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
   }
@@ -487,24 +509,25 @@ __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_doub
   strip_d4 X0[8], X1[8];
   trsm_strip_load(ta, 16 * wave, X0);
   if constexpr (NW == 4) trsm_strip_load(ta, 16 * (wave + 4), X1);
-  if (NW == 8 && I == J + 1 && ta.nvalid == TILE) {
-    // the chain's tile: follow the leaf of (J, J) column by column instead of waiting for its flag
+  const bool near_chain = I <= J + 2;  // the two tiles below the diagonal feed the next column's chain tiles
+  if (NW == 8 && near_chain && ta.nvalid == TILE) {
+    // follow the leaf of (J, J) column by column instead of waiting for its flag
     if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
     __builtin_amdgcn_s_setprio(3);
-    ct_strip_solve_pipelined(g, ta, 16 * wave, X0, g.prog + J, g.half + J);
+    ct_strip_solve_pipelined(g, ta, 16 * wave, X0, g.prog + J, g.half + (int64_t)(I - J - 1) * g.nct + J);
     __builtin_amdgcn_s_setprio(0);
     if (wave == 0) s_i[1] = __builtin_amdgcn_readfirstlane(__hip_atomic_load(g.ctl + 1, CT_RLX_AGENT)) != 0u ? -1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
   } else {
-    if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J, I == J + 1);
+    if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)J * g.nct + J, near_chain);
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
     if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
-    if (I == J + 1) __builtin_amdgcn_s_setprio(3);
-    if (NW == 8 && I == J + 1) {
-      trsm_strip_solve_store_pf<true, true>(ta, 16 * wave, X0, g.half + J);  // the chain's tile: first half published early
+    if (near_chain) __builtin_amdgcn_s_setprio(3);
+    if (NW == 8 && near_chain) {
+      trsm_strip_solve_store_pf<true, true>(ta, 16 * wave, X0, g.half + (int64_t)(I - J - 1) * g.nct + J);  // first half published early
     } else {
       trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
       if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);

@@ -818,7 +818,7 @@ int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
 int chol_tiles(gmb_engine* e) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
   const int ntasks = ct_task_count(nct, nrt);
-  const int64_t words = 4 + (int64_t)nrt * nct + 2 * (int64_t)nct;
+  const int64_t words = 4 + (int64_t)nrt * nct + 3 * (int64_t)nct;
   int rc;
   if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
   HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
@@ -840,7 +840,7 @@ int chol_tiles(gmb_engine* e) {
   a.ctl = e->dct;
   a.flags = e->dct + 4;
   a.half = e->dct + 4 + (int64_t)nrt * nct;
-  a.prog = a.half + nct;
+  a.prog = a.half + 2 * (int64_t)nct;
   a.ntasks = ntasks;
   a.timeout_us = 4000000u;  // a wait of 4 s means a lost flag: give the factorisation up, never the GPU
   a.dbg = nullptr;

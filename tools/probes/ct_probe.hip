@@ -60,11 +60,11 @@ int main(int argc, char** argv) {
   }
   double *dA, *dinv, *dscal; int32_t* dinfo; uint32_t* dct; unsigned long long* dtr;
   CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dinv, (size_t)nct * 2048 * 8)); CK(hipMalloc(&dscal, 64 * 8));
-  CK(hipMalloc(&dinfo, 4)); CK(hipMalloc(&dct, (4 + (size_t)nrt * nct + 2 * nct) * 4));
+  CK(hipMalloc(&dinfo, 4)); CK(hipMalloc(&dct, (4 + (size_t)nrt * nct + 3 * nct) * 4));
   const int ntasks = ct_task_count(nct, nrt);
   CK(hipMalloc(&dtr, (size_t)ntasks * 32));
   CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-  CK(hipMemset(dscal, 0, 64 * 8)); CK(hipMemset(dinfo, 0, 4)); CK(hipMemset(dct, 0, (4 + (size_t)nrt * nct + 2 * nct) * 4)); CK(hipMemset(dtr, 0, (size_t)ntasks * 32));
+  CK(hipMemset(dscal, 0, 64 * 8)); CK(hipMemset(dinfo, 0, 4)); CK(hipMemset(dct, 0, (4 + (size_t)nrt * nct + 3 * nct) * 4)); CK(hipMemset(dtr, 0, (size_t)ntasks * 32));
   hipStream_t st; CK(hipStreamCreate(&st));
   if (test < 2 || test == 5) {
     LeafArgs a{}; a.A = dA; a.lda = ld; a.nvalid = N < 128 ? N : 128; a.dinv16 = dinv; a.logdet = dscal; a.info = dinfo; a.row0 = 0; a.dbg = nullptr;
@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
     else hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(512), 0, st, a);
   } else {
     CholTilesArgs g{}; g.A = dA; g.ld = ld; g.nct = nct; g.nrt = nrt; g.N = N; g.dinv16 = dinv; g.logdet = dscal; g.info = dinfo;
-    g.ctl = dct; g.flags = dct + 4; g.half = dct + 4 + (size_t)nrt * nct; g.prog = g.half + nct; g.ntasks = ntasks; g.timeout_us = 2000000u; g.dbg = dtr;
+    g.ctl = dct; g.flags = dct + 4; g.half = dct + 4 + (size_t)nrt * nct; g.prog = g.half + 2 * nct; g.ntasks = ntasks; g.timeout_us = 2000000u; g.dbg = dtr;
     const int grid = ntasks < 512 ? ntasks : 512;
     if (test == 2) hipLaunchKernelGGL(chol_tiles_kernel<4>, dim3(grid), dim3(256), 0, st, g);
     if (test == 6) hipLaunchKernelGGL(chol_tiles_kernel<8>, dim3(grid < 256 ? grid : 256), dim3(512), 0, st, g);
