@@ -57,7 +57,8 @@ struct CholTilesArgs {
   double* logdet;   // += sum log L_cc
   int32_t* info;    // first non-positive pivot (global row + 1), 0 = ok
   uint32_t* flags;  // nrt * nct words, zeroed by the host before the launch; tile (I, J) is final when [I * nct + J] != 0
-  uint32_t* half;   // 2 x nct words (zeroed with the flags): the first 64 columns of the tiles (J + 1, J) [word J] and (J + 2, J) [word nct + J] are final
+  uint32_t* half;   // 2 x nct words (zeroed with the flags): how many 32-column quarters (0 .. 4) of the tiles (J + 1, J) [word J] and
+                    // (J + 2, J) [word nct + J] are final -- the two tiles below the diagonal publish themselves quarter by quarter
   uint32_t* prog;   // nct words (zeroed with the flags): progress of the leaf of column J (LeafArgs::prog)
   uint32_t* ctl;    // [0] ticket counter, [1] abort word (zeroed with the flags)
   int32_t ntasks;
@@ -151,15 +152,17 @@ __device__ __forceinline__ int ct_wait_one(const CholTilesArgs& g, const uint32_
   }
 }
 
-// ONE wave: wait until both words are set (the same word twice = one word); 0 = acquired, -1 = abandoned
-__device__ __forceinline__ int ct_wait_two(const CholTilesArgs& g, const uint32_t* p, const uint32_t* q) {
+// ONE wave: wait until both words are >= need (the same word twice = one word); 0 = there (acquired unless the caller reads
+// with write-through-coherent loads and asks for no fence), -1 = abandoned
+__device__ __forceinline__ int ct_wait_two(const CholTilesArgs& g, const uint32_t* p, const uint32_t* q, const uint32_t need,
+                                           const bool acquire) {
   unsigned spins = 0;
   unsigned long long t0 = 0ull;
   for (;;) {
     const uint32_t a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, CT_RLX_AGENT));
     const uint32_t b = __builtin_amdgcn_readfirstlane(__hip_atomic_load(q, CT_RLX_AGENT));
-    if (a != 0u && b != 0u) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (a >= need && b >= need) {
+      if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       return 0;
     }
     if (ct_give_up(g, spins, t0)) return -1;
@@ -213,6 +216,22 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
 #pragma unroll
     for (int p = 0; p < NA; ++p) rb[p] = *reinterpret_cast<const d2*>(Bg + ((int64_t)kt * KT + s_row + RA * p) * ldb);
   };
+  // the same through write-through-coherent (sc1) loads: data another workgroup stored sc1 moments ago, read without an
+  // acquire fence (8-byte pieces: the widest agent-scope atomic load)
+  auto gload_sc1 = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const double* pa = Ag + ((int64_t)kt * KT + s_row + RA * p) * g.ld;
+      ra[p][0] = __hip_atomic_load(pa, CT_RLX_AGENT);
+      ra[p][1] = __hip_atomic_load(pa + 1, CT_RLX_AGENT);
+    }
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const double* pb = Bg + ((int64_t)kt * KT + s_row + RA * p) * ldb;
+      rb[p][0] = __hip_atomic_load(pb, CT_RLX_AGENT);
+      rb[p][1] = __hip_atomic_load(pb + 1, CT_RLX_AGENT);
+    }
+  };
   auto lstore = [&](int st) {
     double* As = lds + st * (KT * 2 * PA);
     double* Bs = As + KT * PA;
@@ -241,25 +260,26 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
   // The contraction runs in SEGMENTS of k-tiles whose operands are final.  Ordinary tiles: runs of k-blocks by the
   // tile flags of block rows I and J.  The tiles of the latency chain -- the diagonal tile and the one below it -- take
   // their LAST k-block, which comes from the tiles (I, J-1) and (J, J-1) of the column before (the chain's own output), in
-  // two halves: those tiles publish their first 64 columns half way through their solve (half[]).
+  // four quarters: those tiles publish themselves 32 columns at a time while they are being solved (half[]); the
+  // quarters are read with write-through-coherent loads, so their waits need no fence.
   constexpr int KPB = TILE / KT;  // k-tiles per k-block
+  constexpr int KPQ = KPB / 4;    // k-tiles per quarter
   const int kt_end = J * KPB;
   const bool diag = !TRSM && I == J;
   const bool chain = !TRSM && I <= J + 1;
   int ktc = 0;
   while (ktc < kt_end) {
     const int kb = ktc / KPB;
+    const bool quarter = chain && kb == J - 1;
     if (wave == 0) {
       int r;
-      if (chain && kb == J - 1) {
-        const bool first = ktc == kb * KPB;
+      if (quarter) {
         // tile (J, J-1) is the first sub-diagonal tile of column J-1, tile (J+1, J-1) the second
         const uint32_t* hp = g.half + kb;
         const uint32_t* hq = diag ? hp : g.half + g.nct + kb;
-        const uint32_t* fp = g.flags + (int64_t)J * g.nct + kb;
-        const uint32_t* fq = g.flags + (int64_t)I * g.nct + kb;
-        r = first ? ct_wait_two(g, hp, hq) : ct_wait_two(g, fp, fq);
-        if (r >= 0) r = first ? ktc + KPB / 2 : kt_end;
+        const int q = (ktc - kb * KPB) / KPQ;
+        r = ct_wait_two(g, hp, hq, (uint32_t)(q + 1), false);
+        if (r >= 0) r = ktc + KPQ;
       } else {
         r = ct_wait_rows(g, I, TRSM ? I : J, kb, chain ? J - 1 : J);
         if (r >= 0) r *= KPB;
@@ -270,6 +290,17 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
     const int kt1 = __builtin_amdgcn_readfirstlane(s_i[1]);  // workgroup-uniform: keep the control flow scalar
     if (kt1 < 0) return false;
     const int kt0 = ktc;
+    if (quarter) {  // KPQ k-tiles, not pipelined among themselves (one per quarter with k-tiles of 32)
+      for (int kt = kt0; kt < kt1; ++kt) {
+        gload_sc1(kt);
+        lstore(0);
+        __syncthreads();
+        compute(0);
+        __syncthreads();
+      }
+      ktc = kt1;
+      continue;
+    }
     gload(kt0);
     lstore(0);
     __syncthreads();
@@ -377,7 +408,7 @@ __device__ __forceinline__ void ct_publish(const CholTilesArgs& g, const int I, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave == 0) {
-    if (I == J + 1 || I == J + 2) __hip_atomic_store(g.half + (int64_t)(I - J - 1) * g.nct + J, 1u, CT_RLX_AGENT);  // (already up when the solve published its first half itself)
+    if (I == J + 1 || I == J + 2) __hip_atomic_store(g.half + (int64_t)(I - J - 1) * g.nct + J, 4u, CT_RLX_AGENT);  // all four quarters
     __hip_atomic_store(g.flags + (int64_t)I * g.nct + J, 1u, CT_RLX_AGENT);
     if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
   }
@@ -468,18 +499,18 @@ __device__ __forceinline__ void ct_strip_solve_pipelined(const CholTilesArgs& g,
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(o[28 + kk], y[kk], x, 0, 0, 0);
     X[s] = x;
-    if (s == 3) {
+    if (s == 1 || s == 3 || s == 5) {  // a quarter (32 columns) is final: out it goes, and the count with it
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2)
+      for (int s2 = s - 1; s2 <= s; ++s2)
 #pragma unroll
         for (int q = 0; q < 4; ++q) __hip_atomic_store(&Bp[(int64_t)(16 * s2 + kq + 4 * q) * ta.ldb], X[s2][q], CT_RLX_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) __hip_atomic_store(half_flag, 1u, CT_RLX_AGENT);
+      if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) __hip_atomic_store(half_flag, (uint32_t)((s + 1) / 2), CT_RLX_AGENT);
     }
   }
 #pragma unroll
-  for (int s = 4; s < 8; ++s)
+  for (int s = 6; s < 8; ++s)
 #pragma unroll
     for (int q = 0; q < 4; ++q) __hip_atomic_store(&Bp[(int64_t)(16 * s + kq + 4 * q) * ta.ldb], X[s][q], CT_RLX_AGENT);
 }
@@ -526,12 +557,8 @@ __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_doub
     if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
     if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
     if (near_chain) __builtin_amdgcn_s_setprio(3);
-    if (NW == 8 && near_chain) {
-      trsm_strip_solve_store_pf<true, true>(ta, 16 * wave, X0, g.half + (int64_t)(I - J - 1) * g.nct + J);  // first half published early
-    } else {
-      trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
-      if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
-    }
+    trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+    if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
   }
   __builtin_amdgcn_s_setprio(0);
   ct_publish(g, I, J, t, wave);

@@ -182,7 +182,8 @@ struct gmb_engine {
   bool tt_used = false;      // the current prediction ran its triangular solve on the tile kernel (same abort word)
   int ct_ntasks = 0;
   int ct_lose = 0;           // fault injection (gmb_debug_chol_lose_tickets): one shot
-  int tiles_min_blocks = 16, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default
+  int tiles_min_blocks = 6, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default (measured faster from N = 768 on)
+  int tiles_trsm_min_blocks = 16;                    // ... and the tile triangular solve of the predict path (measured from N = 2560 on)
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
   std::vector<hipEvent_t> sync_pool;
   size_t sync_next = 0;
@@ -2079,7 +2080,7 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
       // large GEMMs run at 73 TF/s against the persistent loop's 69)
       const int ntm = (int)(mpad / TILE);
       const bool tiles = !e->naive_leaf && ntm >= 8 && ntm <= 96 &&
-                         (e->chol_scheme == 3 || (e->chol_scheme < 0 && nblocks >= e->tiles_min_blocks && nblocks <= e->tiles_max_blocks));
+                         (e->chol_scheme == 3 || (e->chol_scheme < 0 && nblocks >= e->tiles_trsm_min_blocks && nblocks <= e->tiles_max_blocks));
       e->cur = e->stream;
       e->tt_used = false;
       if ((rc = tiles ? trsm_tiles(e, e->dV, mpad, (int)(mpad / TILE), 3)

@@ -435,6 +435,9 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
         __builtin_amdgcn_wave_barrier();
         factor_diag16_mfma<WT>(Sn, pn, dinv, gd ? gd + (s + 1) * SB * SB : nullptr, rdiag, c0 + SB, nv, g.info, g.row0);
       } else {
+        // published column by column: block column s (final since the barrier above) goes out FIRST, so that its
+        // write-through stores land under the update tiles below and the drain before the next barrier is free
+        if (pipe) write_back(s, tid - 64, NTH - 64);
         const int ntile = n * (n + 1) / 2;
         // Tiles 1 .. ntile-1 (t = 0 is the diagonal tile wave 0 owns) are dealt in rounds of 2 (NW - 2) + 1
         // slots: two per wave, but only ONE for wave NW / 2 -- it shares its SIMD with wave 0, whose
@@ -463,11 +466,7 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
         }
         // write-back is deferred to the steps where these waves run out of update tiles -- unless the block is
         // published column by column: then block column s goes out now and must have landed before the barrier
-        if (pipe) {
-          write_back(s, tid - 64, NTH - 64);
-        } else if (s >= 3) {
-          write_back(s - 3, tid - 64, NTH - 64);
-        }
+        if (!pipe && s >= 3) write_back(s - 3, tid - 64, NTH - 64);
       }
       if (pipe) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (wave 0: the next sub-block inverse)
     }

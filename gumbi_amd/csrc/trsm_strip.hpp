@@ -91,13 +91,8 @@ __device__ __forceinline__ void trsm_strip_solve_store(const TrsmArgs& g, const 
 // functions (chol_tiles.hpp) the compiler kept the source order of trsm_strip_solve_store -- load, wait, MFMA, load,
 // wait, ... 144 exposed L2 latencies, 40 us per slab instead of 9 -- although it batches the loads of the stand-alone
 // kernel by itself.
-// MID (every wave of the workgroup solves one slab of the SAME 128-row tile): the first 64 columns are stored
-// (write-through) as soon as they are final -- after step 3 of 8 -- and `*mid_flag` is raised once every wave's stores
-// have landed: the consumer of this tile (the diagonal tile below it) starts its last contraction block half a solve
-// earlier.
-template <bool WT = false, bool MID = false>
-__device__ __forceinline__ void trsm_strip_solve_store_pf(const TrsmArgs& g, const int64_t r0, strip_d4 (&X)[8],
-                                                          uint32_t* mid_flag = nullptr) {
+template <bool WT = false>
+__device__ __forceinline__ void trsm_strip_solve_store_pf(const TrsmArgs& g, const int64_t r0, strip_d4 (&X)[8]) {
   typedef strip_d4 d4;
   const int lane = threadIdx.x & 63;
   const int r16 = lane & 15, kq = lane >> 4;
@@ -128,21 +123,9 @@ __device__ __forceinline__ void trsm_strip_solve_store_pf(const TrsmArgs& g, con
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(o[28 + kk], y[kk], x, 0, 0, 0);
     X[s] = x;
-    if constexpr (MID) {
-      if (s == 3) {
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            __hip_atomic_store(&Bp[(int64_t)(16 * s2 + kq + 4 * q) * g.ldb], X[s2][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) __hip_atomic_store(mid_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
   }
 #pragma unroll
-  for (int s = MID ? 4 : 0; s < 8; ++s)
+  for (int s = 0; s < 8; ++s)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if constexpr (WT) __hip_atomic_store(&Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb], X[s][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
