@@ -221,13 +221,16 @@ def pmc_traffic(config, kernel_filter):
 
 
 def kernel_sources_sha16():
-    """sha256 over gumbi_amd/csrc/* (sorted): ties a committed counter summary to the kernels it was taken on."""
+    """sha256 over the CODE of gumbi_amd/csrc/* (sorted; `//` comments and white space stripped, so that rewording a
+    comment does not disown a counter summary): ties a committed PMC summary to the kernels it was taken on."""
     import hashlib
+    import re
 
     h = hashlib.sha256()
     for path in sorted((ROOT / "gumbi_amd" / "csrc").glob("*.h*")):
         h.update(path.name.encode())
-        h.update(path.read_bytes())
+        code = re.sub(r"//[^\n]*", "", path.read_text())
+        h.update("".join(code.split()).encode())
     return h.hexdigest()[:16]
 
 

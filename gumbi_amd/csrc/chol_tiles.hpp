@@ -1,20 +1,22 @@
-// chol_tiles.hpp -- the whole Cholesky factorisation of a SMALL matrix (N <= ~20k) as ONE persistent launch.
+// chol_tiles.hpp -- the whole Cholesky factorisation of a matrix of 0.8k .. 28k rows as ONE persistent launch (and the
+// triangular solve of the predict path in the same form).
 //
 // Why: at C2's size (N = 10k, 79 block columns) the multi-kernel schedules of engine.hip are bound by their
 // latency chain (leaf -> strip solve -> rank-128 update, 79 times) and by what the stream model can overlap with it:
 // 8.8 ms where the flops alone need 4.7 ms.  Here the factorisation is a list of TILE TASKS served
-// by resident workgroups from one ticket counter; dependencies are per-tile flags in global memory, so bulk work
-// and the chain interleave at tile granularity without any kernel boundary.
+// by resident workgroups (512 threads, one per compute unit) from one ticket counter; dependencies are per-tile flags
+// in global memory, so bulk work and the chain interleave at tile granularity without any kernel boundary.
 //
 // Task (I, J), I >= J, owns the 128 x 128 tile (block row I, block column J) and is LEFT-LOOKING:
 //   1. T = A(I,J) - sum_{k < J} L(I,k) L(J,k)^T   -- one long-k MFMA contraction (the k loop of gemm_f64.hpp),
 //      which walks the k-blocks in order and waits for the flags of L(I,k), L(J,k) only when it reaches a block
 //      that is not final yet: everything that CAN be accumulated early is;
-//   2. I == J:  L(J,J) = chol(T) with the leaf of potrf_leaf.hpp (in this workgroup's LDS), sub-block inverses
-//      and log-det as in the stand-alone leaf kernel;
-//      I >  J:  wait for L(J,J), then L(I,J) = T L(J,J)^-T with the strip solve of trsm_strip.hpp (two 16-row
-//      slabs per wavefront);
-//   3. publish the tile (agent-scope release, then its flag).
+//   2. I == J:  L(J,J) = chol(T) with the leaf of potrf_leaf.hpp (T goes straight into the leaf's LDS layout),
+//      sub-block inverses and log-det as in the stand-alone leaf kernel;
+//      I >  J:  L(I,J) = T L(J,J)^-T with the strip solve of trsm_strip.hpp, one 16-row slab per wavefront --
+//      after the flag of L(J,J), or, for the two tiles right below the diagonal, FOLLOWING the leaf column by
+//      column (LeafArgs::prog);
+//   3. publish the tile: its values were stored write-through (sc1), every wave drains, barrier, the flag.
 // Tickets are handed out in column-major order (J outer, I = J first), which is a topological order of the
 // dependency graph: a task only ever waits for tasks with smaller tickets, which are finished or held by a running
 // workgroup -- the launch cannot deadlock whatever the residency or placement of its workgroups.  Every tile is
@@ -22,11 +24,16 @@
 // accumulator, so the factor is bit-reproducible from run to run (it does differ in the last bits from the
 // recursive schedule, which groups the same sums differently).
 //
+// The latency chain -- (J,J) -> (J+1,J) -> (J+1,J+1) -- is what bounds small matrices; its tiles hand their results on
+// in pieces: the leaf publishes finished 16-column blocks (prog), the two tiles below the diagonal publish finished
+// 32-column quarters (half[]), and the next column's chain tiles take their last k-block quarter by quarter.
+//
 // Inter-workgroup visibility follows the gfx950 recipe (per-XCD L2s are not coherent, L1 is per CU): producer =
-// every wave drains its stores, barrier, ONE lane agent-scope release + drain, relaxed agent-scope flag store;
-// consumer = ONE wave polls relaxed, ONE agent-scope acquire, barrier, plain loads.  Every wait is bounded: a wave
-// that waits longer than `timeout_us` raises the abort word, every waiter sees it and the launch drains
-// (the host reports GMB_EHIP) -- a lost flag can cost a factorisation, never the GPU.
+// write-through (sc1) stores, every wave drains, barrier, relaxed agent-scope flag store; consumer = ONE wave polls
+// relaxed, ONE agent-scope acquire, barrier, plain loads -- or, for the pieces above, write-through-coherent (sc1)
+// loads and no fence.  Every wait is bounded: a wave that waits longer than `timeout_us` (and a million polls) raises
+// the abort word, every waiter sees it and the launch drains (the host reports GMB_EHIP) -- a lost flag can cost a
+// factorisation, never the GPU.
 //
 // Replaces the per-evaluation dpotrf of pm.gp.Marginal (gumbi/regression/pymc/GP.py:811, 845-847) for the sizes
 // Gumbi users actually fit.
