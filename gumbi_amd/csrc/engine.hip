@@ -2075,12 +2075,13 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
     {
       // the triangular solve V <- V L^-T: one persistent launch for the matrices the tile Cholesky factors, else the recursion
       const int nblocks = (int)(e->Np / TILE);
-      // (measured window, r03: 5 - 10 % faster than the recursion for 1k .. 12k test points -- the standard 10^4-point grid --,
-      // slower for a few hundred points, where the launch cannot fill the chip, and for 4 x 10^4, where the recursion's
-      // large GEMMs run at 73 TF/s against the persistent loop's 69)
+      // (measured window, r03: 5 - 10 % faster than the recursion for 4k .. 12k test points -- the standard 10^4-point grid -- at
+      // N >= 2560; slower for 2000 points and fewer, where the launch cannot fill the chip, and for 4 x 10^4, where the
+      // recursion's large GEMMs run at 73 TF/s against the persistent loop's 69; scheme 3 forces it for any size)
       const int ntm = (int)(mpad / TILE);
-      const bool tiles = !e->naive_leaf && ntm >= 8 && ntm <= 96 &&
-                         (e->chol_scheme == 3 || (e->chol_scheme < 0 && nblocks >= e->tiles_trsm_min_blocks && nblocks <= e->tiles_max_blocks));
+      const bool tiles = !e->naive_leaf && ntm <= 96 &&
+                         (e->chol_scheme == 3 || (e->chol_scheme < 0 && ntm >= 32 && nblocks >= e->tiles_trsm_min_blocks &&
+                                                  nblocks <= e->tiles_max_blocks));
       e->cur = e->stream;
       e->tt_used = false;
       if ((rc = tiles ? trsm_tiles(e, e->dV, mpad, (int)(mpad / TILE), 3)
