@@ -1064,6 +1064,11 @@ int winv_levels(gmb_engine* e, int nt) {
   std::vector<std::vector<InvNode>> levels;
   collect_inv_nodes(0, nt, 0, levels);
   hipStream_t streams[4] = {e->stream, e->aux[0], e->aux[1], e->aux_shared ? e->aux[0] : e->aux[2]};
+  // Small matrices (<= 64 block columns): only the two top levels are not batched, i.e. at most two nodes could run
+  // side by side -- less than the event records / stream waits of the fork and the joins cost on the host, which is
+  // what such a gradient is bound by (timeline at N = 2048: 70 us of idle GPU before the first batched level).  One
+  // stream, no events.
+  if (nt <= 64) streams[1] = streams[2] = streams[3] = e->stream;
   int rc;
   for (int a = 1; a < 4; ++a)
     if ((rc = order_after(e, streams[0], streams[a]))) return rc;
