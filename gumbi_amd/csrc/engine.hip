@@ -182,6 +182,12 @@ struct gmb_engine {
   bool tt_used = false;      // the current prediction ran its triangular solve on the tile kernel (same abort word)
   int ct_ntasks = 0;
   int ct_lose = 0;           // fault injection (gmb_debug_chol_lose_tickets): one shot
+  // a factorisation that has been enqueued but not checked yet (factorize_enqueue / factorize_finish): where its scalars
+  // land on the host, and the events around its two phases
+  double h_scal[2] = {0.0, 0.0};
+  int32_t h_info = 0;
+  uint32_t h_abort = 0;
+  hipEvent_t fe[4] = {nullptr, nullptr, nullptr, nullptr};  // K-build begin / end, Cholesky begin / end
   int tiles_min_blocks = 6, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default (measured faster from N = 768 on)
   int tiles_trsm_min_blocks = 16;                    // ... and the tile triangular solve of the predict path (measured from N = 2560 on)
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
@@ -1761,6 +1767,8 @@ void gmb_destroy(gmb_engine* e) {
     if (p) (void)hipFree(p);
   for (int a = 0; a < 3; ++a)
     if (e->aux[a] && !e->aux_borrowed && !(a == 2 && e->aux_shared)) (void)hipStreamDestroy(e->aux[a]);
+  for (auto ev : e->fe)
+    if (ev) (void)hipEventDestroy(ev);
   for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
   for (auto ev : e->time_pool) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1903,7 +1911,11 @@ int64_t gmb_notpd_index(const gmb_engine* e) { return e ? e->notpd : -1; }
 
 int gmb_factor_valid(const gmb_engine* e) { return (e && e->N > 0 && e->have_theta && e->factored && !e->factor_consumed) ? 1 : 0; }
 
-int gmb_factorize(gmb_engine* e) {
+namespace {
+
+// Everything of gmb_factorize up to (not including) the host's look at the results: K-build, Cholesky, v = L^-1 y, and the
+// asynchronous copies of log-det / |v|^2 / failure index / abort word into the engine.  Nothing is synchronised.
+int factorize_enqueue(gmb_engine* e) {
   int rc = require_ready(e, false);
   if (rc) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -1915,15 +1927,17 @@ int gmb_factorize(gmb_engine* e) {
   tm.kbuild_ms = tm.chol_ms = tm.chol_gemm_ms = tm.chol_gemm_flops = 0.0;
   tm.chol_leaf_ms = tm.chol_trsm_ms = 0.0;
   tm.chol_gemm_launches = 0;
+  for (auto& ev : e->fe)
+    if (!ev) HIP_TRY(e, hipEventCreate(&ev));
   HIP_TRY(e, hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream));
   HIP_TRY(e, hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream));
 
   // 1. covariance build: lower-triangular tiles of Sigma, y row, identity padding
-  PhaseTimer tk(e);
+  HIP_TRY(e, hipEventRecord(e->fe[0], e->stream));
   if ((rc = build_sigma(e, e->dA, e->ld))) return rc;
-  tk.stop();
+  HIP_TRY(e, hipEventRecord(e->fe[1], e->stream));
   // 2. Cholesky
-  PhaseTimer tc(e);
+  HIP_TRY(e, hipEventRecord(e->fe[2], e->stream));
   e->chol_update_kind = 7;
   if (e->panel_auto) {
     // wider panels for larger matrices: a k = 1024 trailing update pays its C read-modify-write and
@@ -1943,21 +1957,28 @@ int gmb_factorize(gmb_engine* e) {
   // 3. v = L^-1 y is row N of the factor
   hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
                      e->dscal + 1);
-  tc.stop();
+  HIP_TRY(e, hipEventRecord(e->fe[3], e->stream));
   HIP_TRY(e, hipGetLastError());
-  double hs[2];
-  int32_t info = 0;
-  HIP_TRY(e, hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(&info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-  uint32_t ct_abort = 0;
-  if (e->ct_used) HIP_TRY(e, hipMemcpyAsync(&ct_abort, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  e->h_info = 0;
+  e->h_abort = 0;
+  HIP_TRY(e, hipMemcpyAsync(e->h_scal, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(&e->h_info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  if (e->ct_used) HIP_TRY(e, hipMemcpyAsync(&e->h_abort, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  return GMB_OK;
+}
+
+// The host's look at an enqueued factorisation: synchronise, timings, failure checks; sets e->factored.
+int factorize_finish(gmb_engine* e) {
+  gmb_timings& tm = e->tm;
+  e->factored = false;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  if (ct_abort != 0) {
+  if (e->h_abort != 0) {
     ev_collect(e);
     return fail(e, GMB_EHIP, "tile Cholesky: a workgroup waited longer than its time-out for a tile (launch abandoned)");
   }
-  tm.kbuild_ms = tk.ms();
-  tm.chol_ms = tc.ms();
+  float t = 0.f;
+  if (hipEventElapsedTime(&t, e->fe[0], e->fe[1]) == hipSuccess) tm.kbuild_ms = t;
+  if (hipEventElapsedTime(&t, e->fe[2], e->fe[3]) == hipSuccess) tm.chol_ms = t;
   tm.kbuild_bytes = 8.0 * (double)e->N * (double)(e->N + 1) / 2.0 +
                     8.0 * (double)e->N * (double)(e->spec.n_cont + 1);
   ev_collect(e);
@@ -1966,19 +1987,45 @@ int gmb_factorize(gmb_engine* e) {
     tm.total_kbuild_bytes += tm.kbuild_bytes;
     tm.total_kbuild_launches += 1;
   }
-  if (info != 0) {
-    e->notpd = (int64_t)info - 1;
+  if (e->h_info != 0) {
+    e->notpd = (int64_t)e->h_info - 1;
     return fail(e, GMB_ENOTPD, "covariance matrix is not positive definite at row %lld",
                 (long long)e->notpd);
   }
-  e->logdet = hs[0];
-  e->vnorm2 = hs[1];
+  e->logdet = e->h_scal[0];
+  e->vnorm2 = e->h_scal[1];
   if (!std::isfinite(e->logdet) || !std::isfinite(e->vnorm2)) {
     e->notpd = 0;
     return fail(e, GMB_ENOTPD, "factorisation produced non-finite values");
   }
   e->factored = true;
   return GMB_OK;
+}
+
+}  // namespace
+
+int gmb_factorize(gmb_engine* e) {
+  const int rc = factorize_enqueue(e);
+  return rc ? rc : factorize_finish(e);
+}
+
+int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, double* grad) {
+  if (!e || !nlml) return GMB_EINVAL;
+  int rc = gmb_set_theta(e, theta, n);
+  if (rc) return rc;
+  if ((rc = factorize_enqueue(e))) return rc;
+  int rc_grad = GMB_OK;
+  std::vector<double> h;
+  if (grad) {
+    // the gradient's launches follow the factorisation's on the same stream with no host round trip in between; if the
+    // factorisation turns out to have failed they ran on garbage and their result is dropped below
+    e->factored = true;
+    rc_grad = grad_accumulate(e, h);
+  }
+  if ((rc = factorize_finish(e))) return rc;
+  if (rc_grad) return rc_grad;
+  *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
+  return grad ? grad_chain_rule(e, h, grad) : GMB_OK;
 }
 
 int gmb_nlml(gmb_engine* e, double* nlml, double* grad) {

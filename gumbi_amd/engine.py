@@ -221,6 +221,7 @@ _SIGNATURES = {
     "gmb_notpd_index": (C.c_int64, [C.c_void_p]),
     "gmb_factor_valid": (C.c_int, [C.c_void_p]),
     "gmb_nlml": (C.c_int, [C.c_void_p, _DBL_P, _DBL_P]),
+    "gmb_evaluate": (C.c_int, [C.c_void_p, _DBL_P, C.c_int32, _DBL_P, _DBL_P]),
     "gmb_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                               C.c_void_p, C.c_int32]),
     "gmb_ls_limits": (C.c_int, [C.c_int32, _DBL_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _DBL_P, _DBL_P]),
@@ -438,6 +439,15 @@ class Engine:
         g = np.empty(self.spec.theta_size(), dtype=np.float64)
         self._check(self._lib.gmb_nlml(self._h, C.byref(val), _dptr(g)), "gmb_nlml")
         return val.value, g
+
+    def evaluate(self, theta, grad: bool = True):
+        """``set_theta`` + ``factorize`` + ``nlml`` in one call (no host round trip between the factorisation and the
+        gradient): ``(nlml, gradient)`` or ``nlml``."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        val = C.c_double()
+        g = np.empty(self.spec.theta_size(), dtype=np.float64) if grad else None
+        self._check(self._lib.gmb_evaluate(self._h, _dptr(theta), theta.size, C.byref(val), _dptr(g) if grad else None), "gmb_evaluate")
+        return (val.value, g) if grad else val.value
 
     def predict(self, Xs, with_noise=True):
         Xs = np.ascontiguousarray(Xs, dtype=np.float64)

@@ -320,9 +320,13 @@ class HipGP(Regressor):
         # down must not leave `_last_eval_theta` pointing at an earlier point whose factor is gone
         self._last_eval_theta = None
         try:
-            eng.set_theta(theta)
-            eng.factorize()
-            nlml, g_nlml = eng.nlml(grad=True)
+            fused = getattr(eng, "evaluate", None)  # the single-GPU engine: one C call, no host round trip in between
+            if fused is not None:
+                nlml, g_nlml = fused(theta)
+            else:
+                eng.set_theta(theta)
+                eng.factorize()
+                nlml, g_nlml = eng.nlml(grad=True)
         except np.linalg.LinAlgError:  # covariance not positive definite at this theta: reject the step
             self._rejected += 1
             return _REJECTED, np.zeros_like(u)

@@ -210,6 +210,12 @@ int64_t gmb_notpd_index(const gmb_engine* e); /* 0-based failing row after GMB_E
  * 0 after gmb_set_* or after gmb_dist_nlml with a gradient (which leaves U = L^-T in the factor buffer). */
 int gmb_factor_valid(const gmb_engine* e);
 
+/* One objective (+ gradient) evaluation at `theta` in ONE call: gmb_set_theta + gmb_factorize + gmb_nlml, with the gradient's
+ * launches enqueued right behind the factorisation's -- no host synchronisation or language round trip in between (at
+ * N = 2000 that is 0.1 of 1.5 ms per evaluation of pm.find_MAP's objective, gumbi/regression/pymc/GP.py:811).  Same status
+ * codes and side effects as the three calls (GMB_ENOTPD with gmb_notpd_index when the covariance is not positive definite;
+ * grad may be NULL). */
+int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, double* grad);
 /* Negative log marginal likelihood  N/2 log 2pi + sum log L_ii + |v|^2/2  of the last
  * factorisation, and (if grad != NULL, length gmb_theta_size) its gradient w.r.t. natural-scale
  * theta: 1/2 tr((Sigma^-1 - a a^T) dSigma/dtheta).  The factorisation stays valid (gmb_predict may follow

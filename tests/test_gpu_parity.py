@@ -665,3 +665,36 @@ def test_tile_cholesky_gives_up_on_a_lost_tile_instead_of_hanging(gpu):
     assert eng.nlml() == ref
     eng.close()
 
+
+@pytest.mark.parametrize("N", [300, 3000])
+def test_fused_evaluation_equals_the_three_calls(gpu, N):
+    """gmb_evaluate = gmb_set_theta + gmb_factorize + gmb_nlml with the gradient enqueued right behind the factorisation: the
+    same bits, the factor stays usable for a prediction, and a covariance that is not positive definite is reported as by
+    gmb_factorize (the gradient that ran on the failed factor is dropped)."""
+    d = 3
+    X, y, ls = O.synthetic_table(N, d, seed=17)
+    spec = O.make_spec(d, range(d), kind="Matern32")
+    theta = O.pack_theta(spec, ls, 1.2, 0.3)
+    Xs = np.random.default_rng(1).standard_normal((64, d))
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    val_a, g_a = eng.nlml(grad=True)
+    mu_a, var_a = eng.predict(Xs)
+    val_b, g_b = eng.evaluate(theta * 1.0)
+    assert np.float64(val_a).tobytes() == np.float64(val_b).tobytes() and g_a.tobytes() == g_b.tobytes()
+    assert eng.factor_is_current()
+    mu_b, var_b = eng.predict(Xs)
+    assert mu_a.tobytes() == mu_b.tobytes() and var_a.tobytes() == var_b.tobytes()
+    assert np.float64(eng.evaluate(theta, grad=False)).tobytes() == np.float64(val_a).tobytes()
+    val_r, grad_r = O.nlml_and_grad(spec, theta, X, y)
+    assert abs(val_b - val_r) < 1e-10 * max(1.0, abs(val_r)) and rel(g_b, grad_r) < 1e-8
+    Xbad = X.copy()
+    Xbad[N // 2, 1] = np.nan
+    eng.set_data(Xbad, y)
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.evaluate(theta)
+    assert eng.notpd_index() >= 0 and not eng.factor_is_current()
+    eng.set_data(X, y)
+    assert np.float64(eng.evaluate(theta)[0]).tobytes() == np.float64(val_a).tobytes()
+    eng.close()
+
