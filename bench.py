@@ -27,7 +27,8 @@ launches alone -- the kernel the north star's MFMA target is stated on -- from p
 profiled evaluations after the timed region, plus the same figure over every GEMM launch, plus the register-only
 MFMA ceiling sampled for >= 1 s BEFORE and AFTER the timed region), ``kbuild`` (HBM GB/s of the covariance build),
 ``phases``, ``cpu_baseline`` (the oracle on a bounded sample on the host cores) and, while the time budget
-(GUMBI_BENCH_BUDGET_S, default 1500 s of process time) allows, ``strong_scaling_base_gflops`` / ``c5_single_gpu``
+(GUMBI_BENCH_BUDGET_S, default 1500 s of process time) allows, ``c2_single_gpu`` (the N = 10k fit whose factorisation is ONE
+launch of the persistent tile kernel: step, phases, the launch's roofline), ``strong_scaling_base_gflops`` / ``c5_single_gpu``
 (the N = 100k problem of the multi-GPU runs on this one GPU), ``default_start`` and ``end_to_end`` (the user-level
 ``DataSet -> GP.fit() -> prepare_grid() -> predict_grid()`` wall time, host transfers included).
 
@@ -531,6 +532,24 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
                 ceiling={"before_timed_region": ceiling_before, "after_timed_region": ceiling_after})
 
 
+def c2_side_section(local_rank, clock):
+    """C2 (N = 10k, d = 4, RBF-ARD, M = 10^4) as a side figure of the default run: one timed MAP fit to convergence +
+    prediction (after one capped warm-up step), the phases of one evaluation at the MAP and the roofline of its
+    factorisation launch.  ``python bench.py --config c2`` is the full-length form."""
+    cfg = CONFIGS["c2"]
+    res = map_fit_workload(cfg, "c2", local_rank, 1, 1, 0, clock)
+    elapsed = res["elapsed"]
+    r = roofline_block(res["tm"], "c2")
+    ph = res["phases"]
+    return {
+        "workload": cfg["label"],
+        "ms_per_step": round(1e3 * elapsed, 3), "map_evals": res["n_evals"], "value": round(res["flops"] / elapsed / 1e9, 2),
+        "unit": "GFLOP/s", "fit_quality": {k: res["quality"][k] for k in ("corr", "sigma_rel_err", "converged") if k in res["quality"]},
+        "phases": {k: ph[k] for k in ("factorize_ms", "factorize_plus_gradient_ms", "predict_ms", "rates_tflops", "tile_cholesky") if k in ph},
+        "factorisation_roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "frac", "launches", "avg_launch_ms") if k in r},
+    }
+
+
 def default_start_fit(cfg, local_rank):
     """Side figure: the same table fitted with the reference's DEFAULTS -- no ls_bounds, lengthscale prior from the
     smallest pairwise gap (gp_utils.py:34-46), PyMC's initial point (the prior's mode, l = 0.023)."""
@@ -873,6 +892,17 @@ def main():
     if world == 1 and out is not None and "error" not in out and config_name != "c5":
         if not args.no_cpu_baseline and os.environ.get("GUMBI_BENCH_NO_CPU") != "1":
             out["cpu_baseline"] = cpu_baseline(cfg)
+        if config_name == "c3" and os.environ.get("GUMBI_BENCH_NO_C2") != "1":
+            # the size class Gumbi users live in (BASELINE.json configs[1], N = 10k): a converging fit + prediction, with the
+            # phases of one evaluation -- its factorisation is ONE launch of the persistent tile kernel (csrc/chol_tiles.hpp)
+            est = 40.0
+            if budget.allows(est):
+                try:
+                    out["c2_single_gpu"] = c2_side_section(local_rank, clock)
+                except Exception as err:
+                    out["c2_single_gpu"] = {"error": f"{type(err).__name__}: {err}"[:300]}
+            else:
+                out["c2_single_gpu"] = budget.skipped(est)
         if os.environ.get("GUMBI_BENCH_NO_DIST") != "1":
             est = 75.0
             if budget.allows(est):
