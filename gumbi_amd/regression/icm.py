@@ -142,11 +142,9 @@ class IcmEngine:
             tp[self.i_tau] *= lam_p
         return tp
 
-    def _load(self, p, st):
-        """The inner engine that holds system p, factorised at the current theta.  With one engine per system
-        (they fit: P x (factor + gradient workspace) <= RESIDENT_BYTES) nothing is recomputed while theta stands --
-        the gradient leaves the factor intact -- so ``predict`` after ``nlml`` and repeated ``predict`` calls reuse
-        the resident factors; otherwise engine 0 serves the systems in turn."""
+    def _prepare(self, p, st):
+        """The inner engine that holds system p with its inputs, kernel and rotated y in place; also its slot, the system's
+        theta and whether it still has to be factorised at it."""
         k = p if self._per_system else 0
         while len(self._engs) <= k:
             self._engs.append(Engine(sibling_of=self.eng))
@@ -160,11 +158,38 @@ class IcmEngine:
         elif slot["p"] != p or slot["y"] is not st["Yt"]:
             eng.set_y(st["Yt"][p])
             slot.update(p=p, y=st["Yt"], theta=None)
-        if slot["theta"] is None or not np.array_equal(slot["theta"], tp) or not eng.factor_is_current():
+        stale = slot["theta"] is None or not np.array_equal(slot["theta"], tp) or not eng.factor_is_current()
+        return eng, slot, tp, stale
+
+    def _load(self, p, st):
+        """The inner engine that holds system p, factorised at the current theta.  With one engine per system
+        (they fit: P x (factor + gradient workspace) <= RESIDENT_BYTES) nothing is recomputed while theta stands --
+        the gradient leaves the factor intact -- so ``predict`` after ``nlml`` and repeated ``predict`` calls reuse
+        the resident factors; otherwise engine 0 serves the systems in turn."""
+        eng, slot, tp, stale = self._prepare(p, st)
+        if stale:
             eng.set_theta(tp)
             eng.factorize()
             slot["theta"] = tp
         return eng
+
+    def _evaluate(self, p, st):
+        """System p's objective and gradient: ONE engine call (gmb_evaluate: factorisation and gradient enqueued back to
+        back) when it has to be factorised anyway -- every evaluation of a MAP fit --, else the gradient alone."""
+        eng, slot, tp, stale = self._prepare(p, st)
+        if stale:
+            slot["theta"] = None
+            fused = getattr(eng, "evaluate", None)
+            if fused is not None:
+                f, g = fused(tp)
+            else:  # (a stand-in engine of the CPU tests)
+                eng.set_theta(tp)
+                eng.factorize()
+                f, g = eng.nlml(grad=True)
+            slot["theta"] = tp
+        else:
+            f, g = eng.nlml(grad=True)
+        return eng, f, g
 
     # -- evaluation -------------------------------------------------------------------------------------------
     def factorize(self):
@@ -187,8 +212,7 @@ class IcmEngine:
         s = np.zeros(P)
         At = np.zeros((P, N))
         for p in range(P):
-            eng = self._load(p, st)
-            f, g = eng.nlml(grad=True)
+            eng, f, g = self._evaluate(p, st)
             a = eng.copy_alpha()
             val += f
             At[p] = a
