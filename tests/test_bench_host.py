@@ -171,3 +171,23 @@ def test_tile_trace_summary_reads_the_chain_off_the_stamps():
     assert out["block_columns"] == nct and out["tasks"] == len(tiles)
     assert abs(out["chain_step_us"]["median"] - 50.0) < 1e-6 and abs(out["contraction_us_per_k_block"]["median"] - 16.0) < 1e-6
 
+
+
+def test_schedule_model_orders_are_topological_and_column_major_is_not_beaten():
+    """tools/ct_schedule_sim.py: the model behind the decision to keep the column-major ticket order -- every
+    candidate order it compares is a topological order of the tile graph (simulate asserts it), chunked orders hold every
+    k-block of every tile exactly once, and none of them beats column-major by more than a few per cent at a C2-class size."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import ct_schedule_sim as S
+
+    nct = 30
+    base, occ = S.simulate(nct, S.column_major(nct))
+    assert nct * 40.0 < base < 2.0 * nct * 40.0 and 0.0 < occ <= 1.0  # chain-bound at this size: ~40 us per block column
+    for order in (S.slanted(nct, 0.2), S.slanted(nct, 100.0), S.chunked(nct, 8, True), S.chunked(nct, 8, False)):
+        seen = {}
+        for (i, j, k0, k1, final) in order:
+            assert seen.get((i, j), 0) == k0  # chunks of a tile come in k order and leave no gap
+            seen[(i, j)] = k1
+        assert all(seen[(i, j)] == j for j in range(nct) for i in range(j, nct)) and len(seen) == nct * (nct + 1) // 2
+        t, _ = S.simulate(nct, order)
+        assert t > 0.97 * base

@@ -58,6 +58,8 @@ for N, d in sizes:
         e.factorize()
         tiles, st = e.chol_task_trace(0)
         st = st * 1e6  # us
+        if os.environ.get('CT_TRACE_SAVE'):  # raw stamps for offline analysis (tools/ct_schedule_sim.py)
+            np.savez(os.environ['CT_TRACE_SAVE'] + f"_{N}.npz", tiles=np.asarray(tiles), stamps_us=st)
         nct = (N + 127) // 128
         diag = {int(j): st[i] for i, (ii, j) in enumerate(tiles) if ii == j}
         sub = {int(j): st[i] for i, (ii, j) in enumerate(tiles) if ii == j + 1}
