@@ -2135,13 +2135,16 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
     {
       // the triangular solve V <- V L^-T: one persistent launch for the matrices the tile Cholesky factors, else the recursion
       const int nblocks = (int)(e->Np / TILE);
-      // (measured window, r03: 5 - 10 % faster than the recursion for 4k .. 12k test points -- the standard 10^4-point grid -- at
-      // N >= 2560; slower for 2000 points and fewer, where the launch cannot fill the chip, and for 4 x 10^4, where the
-      // recursion's large GEMMs run at 73 TF/s against the persistent loop's 69; scheme 3 forces it for any size)
+      // (measured window, r03: faster than the recursion whenever the launch has enough tile tasks to fill the chip --
+      // row tiles x block columns >= 576: 1000 test points at N = 10k 4.05 -> 3.25 ms, 2500 at N = 5k 2.15 -> 1.86, 640 at
+      // N = 16k 6.55 -> 5.24, 384 at N = 28k 12.7 -> 8.9; 5 - 10 % for the standard 10^4-point grid -- and slower below
+      // that (a few row tiles walk the block columns as a chain either way, the recursion's launches are lighter), and for
+      // 4 x 10^4 points, where the recursion's large GEMMs run at 73 TF/s against the persistent loop's 69;
+      // scheme 3 forces it for any size; tools/gpu_chol_tiles.py CT_PREDICT=1)
       const int ntm = (int)(mpad / TILE);
-      const bool tiles = !e->naive_leaf && ntm <= 96 &&
-                         (e->chol_scheme == 3 || (e->chol_scheme < 0 && ntm >= 32 && nblocks >= e->tiles_trsm_min_blocks &&
-                                                  nblocks <= e->tiles_max_blocks));
+      const bool by_size = nblocks >= e->tiles_trsm_min_blocks && nblocks <= e->tiles_max_blocks &&
+                           (ntm >= 32 || (long long)ntm * nblocks >= 576);
+      const bool tiles = !e->naive_leaf && ntm <= 96 && (e->chol_scheme == 3 || (e->chol_scheme < 0 && by_size));
       e->cur = e->stream;
       e->tt_used = false;
       if ((rc = tiles ? trsm_tiles(e, e->dV, mpad, (int)(mpad / TILE), 3)
