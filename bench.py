@@ -385,6 +385,16 @@ def roofline_block(tm, config):
             "achieved_over_wall_time": round(tf, 3),
         })
         out.pop("in_panel_products", None)
+        pt = pmc_traffic(config, "chol_tiles_kernel<8>")  # every launch of this kernel is one factorisation: bytes per launch as counted
+        if pt is not None and pt["launches"] > 0:
+            out["traffic"] = round(pt["bytes_per_launch"], 1)
+            out["traffic_unit"] = ("HBM-side bytes per factorisation launch: (2*FETCH_SIZE + WRITE_SIZE) of chol_tiles_kernel<8> over one "
+                                   "bench step (rocprofv3 PMC passes) / its launches; the lower triangle itself is 8 N^2 / 2 bytes -- the "
+                                   "rest is operand tiles re-read from HBM because the reader sits on another XCD's L2")
+            out["traffic_flop_per_byte"] = round(tm["total_chol_tile_flops"] / n_t / max(pt["bytes_per_launch"], 1.0), 2)
+            out["traffic_source"] = pt["source"]
+            out["traffic_is_stale"] = pt["stale"]
+            out["traffic_kernel_sources_sha16"] = {"then": pt["kernel_sources_sha16_then"], "now": pt["kernel_sources_sha16_now"]}
         return out
     pt = pmc_traffic(config, "gemm_f64_kernel<2, 2, 4, 4")  # the 128 x 128 instantiation the bulk updates run
     if pt is not None and pt["flops_per_launch"] > 0:

@@ -150,9 +150,14 @@ def test_roofline_block_quotes_the_tile_kernel_when_the_factorisation_is_one_lau
           "total_gemm_flops": 6.0e12, "total_gemm_ms": 100.0, "total_gemm_launches": 300, "total_gemm_wall_ms": 90.0,
           "total_chol_panel_gemm_flops": 0.0, "total_chol_panel_gemm_ms": 0.0, "masked_gemm_flops": 0.0,
           "total_chol_tile_ms": 20.0, "total_chol_tile_flops": 1.0e12, "total_chol_tile_launches": 3}
-    r = bench.roofline_block(tm, "c2")
+    r = bench.roofline_block(tm, "no-such-config")
     assert "chol_tiles_kernel" in r["kernel"] and r["launches"] == 3 and abs(r["achieved"] - 50.0) < 1e-9
     assert abs(r["frac"] - 50.0 / bench.FP64_MFMA_PEAK_TFLOPS) < 1e-4 and r["traffic"] is None and "in_panel_products" not in r
+    # with the committed counter summary of the C2 bench: HBM-side bytes per factorisation launch of that kernel, as counted
+    r = bench.roofline_block(tm, "c2")
+    pt = bench.pmc_traffic("c2", "chol_tiles_kernel<8>")
+    assert pt is not None and r["traffic"] == round(pt["bytes_per_launch"], 1) and 4.0e8 < r["traffic"] < 1.0e11
+    assert r["traffic_source"].startswith("profiles/") and r["traffic_is_stale"] == pt["stale"]
 
 
 def test_tile_trace_summary_reads_the_chain_off_the_stamps():
