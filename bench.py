@@ -556,7 +556,7 @@ def c2_side_section(local_rank, clock):
         "ms_per_step": round(1e3 * elapsed, 3), "map_evals": res["n_evals"], "value": round(res["flops"] / elapsed / 1e9, 2),
         "unit": "GFLOP/s", "fit_quality": {k: res["quality"][k] for k in ("corr", "sigma_rel_err", "converged") if k in res["quality"]},
         "phases": {k: ph[k] for k in ("factorize_ms", "factorize_plus_gradient_ms", "predict_ms", "rates_tflops", "tile_cholesky") if k in ph},
-        "factorisation_roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "frac", "launches", "avg_launch_ms") if k in r},
+        "factorisation_roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "frac", "launches", "avg_launch_ms", "traffic", "traffic_source", "traffic_is_stale") if k in r},
     }
 
 
