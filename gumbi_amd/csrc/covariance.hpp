@@ -307,8 +307,8 @@ struct CovTileArgs {
 // slot-equivalents against 54 + LDS: C3 3.33 -> 4.1 TB/s, C5 (ExpQuad) 4.46 -> 5.55, d = 16 2.3 -> 3.3 (wall clock of
 // gmb_blk_covariance; a torch fill of the same buffer: 6.7 TB/s; stores alone in this pattern: 5.5 - 6.0).
 // A wave owns 32 rows (its row operand stays in registers) and walks the strip's `ncb` blocks of 16 columns;
-// the D layout (n = lane & 15 <-> row, m = (lane >> 4) + 4 reg <-> column) makes every store a set of 128 B
-// row segments.
+// the D layout (n = lane & 15 <-> row, m = (lane >> 4) + 4 reg <-> column) with the wave's two row blocks interleaved
+// makes every store instruction a set of four 256 B column segments (16-byte stores).
 template <int KIND, int NC, bool NT>
 __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const int64_t gi0, const int64_t gj0, const int ncb) {
   // Where the two norm slots would cost a further MFMA (d = 4, 8, 16: ceil((d + 2) / 4) > d / 4) the norms enter
@@ -325,7 +325,7 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
   double brow[2][NG], nrow[2];
 #pragma unroll
   for (int ib = 0; ib < 2; ++ib) {
-    const double* src = a.rows.xs + gi0 + 32 * wave + 16 * ib + r16;
+    const double* src = a.rows.xs + gi0 + 32 * wave + 2 * r16 + ib;  // slot r16 of block ib <-> row 2 r16 + ib: see the stores
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int k = 4 * g + kq;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
   const double eta2 = a.p.eta2;
   const uint64_t col_bytes = (uint64_t)a.ldo * 8u;
   char* tile = reinterpret_cast<char*>(a.out + (gi0 - a.i0) + (gj0 - a.j0) * a.ldo);  // uniform
-  const uint32_t lane_off = (uint32_t)((32 * wave + r16) * 8) + (uint32_t)kq * (uint32_t)col_bytes;
+  const uint32_t lane_off = (uint32_t)((32 * wave + 2 * r16) * 8) + (uint32_t)kq * (uint32_t)col_bytes;
 #if GMB_KB_PROBE >= 2
   double probe_sum = 0.0;
 #endif
@@ -380,26 +380,27 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
       for (int g = 0; g < NG; ++g)
         acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[g], brow[ib][g], acc[ib], 0, 0, 0);
     }
+    // The two row blocks of a wave interleave (block ib holds rows 2 r16 + ib), so a lane's two results for a column are
+    // NEIGHBOURS in memory: one 16-byte store per column instead of two 8-byte ones -- a store instruction writes 4 columns x
+    // 256 contiguous bytes (r03: half the store instructions and address arithmetic of the build).
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
+    for (int r = 0; r < 4; ++r) {
 #if GMB_KB_PROBE == 1 || GMB_KB_PROBE == 3  // probes: the store stream alone (no transcendental work); 3: neither
-        const double v = acc[ib][r];
+      const d2 v = d2{acc[0][r], acc[1][r]};
 #else
-        const double v = stationary_interior<KIND>(acc[ib][r], eta2);
+      const d2 v = d2{stationary_interior<KIND>(acc[0][r], eta2), stationary_interior<KIND>(acc[1][r], eta2)};
 #endif
-        double* dst = reinterpret_cast<double*>(tile + ((uint64_t)(4 * r) * col_bytes + 128u * ib) + lane_off);
+      d2* dst = reinterpret_cast<d2*>(tile + (uint64_t)(4 * r) * col_bytes + lane_off);
 #if GMB_KB_PROBE >= 2     // probe: the arithmetic alone (one store per lane and tile)
-        probe_sum += v;
-        if (jb == ncb - 1 && r == 3 && ib == 1) *dst = probe_sum;
+      probe_sum += v[0] + v[1];
+      if (jb == ncb - 1 && r == 3) *dst = d2{probe_sum, probe_sum};
 #else
-        // streaming stores for matrices far larger than the caches (the factorisation that follows starts at the
-        // other end of a 10 .. 80 GB buffer): +3 .. 7 % on the build at N = 50k / 100k
-        if constexpr (NT) __builtin_nontemporal_store(v, dst);
-        else *dst = v;
+      // streaming stores for matrices far larger than the caches (the factorisation that follows starts at the
+      // other end of a 10 .. 80 GB buffer): +3 .. 7 % on the build at N = 50k / 100k
+      if constexpr (NT) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
 #endif
-      }
+    }
     tile += 16 * col_bytes;
 #pragma unroll
     for (int g = 0; g < NG; ++g) acol[g] = anext[g];
