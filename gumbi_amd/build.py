@@ -15,8 +15,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libgumbi_hip.so"
 SOURCES = ["engine.hip"]
-HEADERS = ["gemm_f64.hpp", "potrf_leaf.hpp", "trsm_strip.hpp", "chol_tiles.hpp", "covariance.hpp", "gradient.hpp", "dist_driver.hpp",
-           "../../include/gumbi_hip.h"]
+HEADERS = sorted(p.name for p in CSRC.glob("*.hpp")) + ["../../include/gumbi_hip.h"]
 ARCH = "gfx950"
 
 

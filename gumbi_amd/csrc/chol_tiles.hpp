@@ -45,6 +45,10 @@
 #include "potrf_leaf.hpp"
 #include "trsm_strip.hpp"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "chol_tiles.hpp: the publication protocol (sc1 write-through stores + relaxed agent-scope flags, one acquire per consuming workgroup) is written for gfx950's cache hierarchy"
+#endif
+
 namespace gmb {
 
 // k-tile depth of the contraction: 16 with two workgroups per compute unit (2 x 73,728 B of staging fit beside each other),

@@ -179,9 +179,12 @@ struct gmb_engine {
   int64_t cap_ct_trace = 0;
   bool ct_trace = false;
   bool ct_used = false;      // the last factorisation ran on the tile kernel (its abort word has to be read back)
+  bool ct_traced = false;    // ... and left task stamps in dct_trace
   bool tt_used = false;      // the current prediction ran its triangular solve on the tile kernel (same abort word)
   int ct_ntasks = 0;
   int ct_lose = 0;           // fault injection (gmb_debug_chol_lose_tickets): one shot
+  bool fact_in_flight = false;  // factorize_enqueue has run, factorize_finish has not
+  bool ct_injected = false;  // the last tile launch ran with injected faults (its failure is reported, not retried)
   // a factorisation that has been enqueued but not checked yet (factorize_enqueue / factorize_finish): where its scalars
   // land on the host, and the events around its two phases
   // (PINNED host memory: an asynchronous copy into pageable memory makes the host wait for the stream, and the gradient of
@@ -834,6 +837,7 @@ int chol_tiles(gmb_engine* e) {
   int rc;
   if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
   HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
+  e->ct_injected = e->ct_lose > 0;
   if (e->ct_lose > 0) {  // fault injection: tickets 0 .. ct_lose-1 are never handed out
     const uint32_t first = (uint32_t)e->ct_lose;
     e->ct_lose = 0;
@@ -856,7 +860,9 @@ int chol_tiles(gmb_engine* e) {
   a.ntasks = ntasks;
   a.timeout_us = 4000000u;  // a wait of 4 s means a lost flag: give the factorisation up, never the GPU
   a.dbg = nullptr;
+  e->ct_traced = false;
   if (e->ct_trace) {
+    e->ct_traced = true;
     if ((rc = ensure(e, &e->dct_trace, &e->cap_ct_trace, 4 * (int64_t)ntasks))) return rc;
     HIP_TRY(e, hipMemsetAsync(e->dct_trace, 0, (size_t)ntasks * 4 * sizeof(unsigned long long), e->cur));
     a.dbg = e->dct_trace;
@@ -1478,7 +1484,7 @@ int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
   }
   // 1. W = L^-1 (dW, lower) and U = L^-T (factor buffer, upper); the factor is consumed from here on
   e->factor_consumed = true;
-  e->sync_next = 0;
+  if (!e->fact_in_flight) e->sync_next = 0;  // (gmb_evaluate: the factorisation's cross-stream waits may still be pending on pooled events)
   if (e->par_inverse) {
     if ((rc = winv_levels(e, nt))) return rc;
   } else if ((rc = winv_cols(e, 0, nt))) {
@@ -1958,6 +1964,7 @@ int factorize_enqueue(gmb_engine* e) {
   const bool masked = !tiles && e->lookahead && e->aux_shared && e->Np / TILE > e->panel_blocks &&
                       (e->chol_scheme == 2 || (e->chol_scheme < 0 && e->Np / TILE <= e->masked_max_blocks));
   e->ct_used = false;
+  e->ct_traced = false;
   e->cur = e->stream;
   if ((rc = tiles ? chol_tiles(e) : masked ? chol_lookahead_masked(e) : chol_cols(e, 0, nblocks, (int)(e->Nr / TILE)))) return rc;
   // 3. v = L^-1 y is row N of the factor
@@ -1971,6 +1978,7 @@ int factorize_enqueue(gmb_engine* e) {
   HIP_TRY(e, hipMemcpyAsync(e->hl->scal, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipMemcpyAsync(&e->hl->info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
   if (e->ct_used) HIP_TRY(e, hipMemcpyAsync(&e->hl->abort, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  e->fact_in_flight = true;
   return GMB_OK;
 }
 
@@ -1978,6 +1986,7 @@ int factorize_enqueue(gmb_engine* e) {
 int factorize_finish(gmb_engine* e) {
   gmb_timings& tm = e->tm;
   e->factored = false;
+  e->fact_in_flight = false;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   if (!e->hl) return fail(e, GMB_EINVAL, "internal: no factorisation enqueued");
   if (e->hl->abort != 0) {
@@ -2012,9 +2021,24 @@ int factorize_finish(gmb_engine* e) {
 
 }  // namespace
 
+// A tile-kernel launch that gave up waiting (abort word set: a lost flag, or a GPU shared with a process that starved it
+// for seconds) says nothing about the matrix: factor it once more with the plain recursion before reporting an error.
+// Injected faults (gmb_debug_chol_lose_tickets) are reported as they are -- the tests want to see the bounded wait.
+static int factorize_retry_after_abort(gmb_engine* e, int rc) {
+  if (rc != GMB_EHIP || !e->ct_used || !e->hl || e->hl->abort == 0 || e->ct_injected) return rc;
+  fprintf(stderr, "libgumbi_hip: tile Cholesky abandoned after a time-out; refactorising with the plain recursion\n");
+  const int scheme = e->chol_scheme;
+  e->chol_scheme = 0;
+  int rc2 = factorize_enqueue(e);
+  if (!rc2) rc2 = factorize_finish(e);
+  e->chol_scheme = scheme;
+  return rc2;
+}
+
 int gmb_factorize(gmb_engine* e) {
-  const int rc = factorize_enqueue(e);
-  return rc ? rc : factorize_finish(e);
+  int rc = factorize_enqueue(e);
+  if (!rc) rc = factorize_retry_after_abort(e, factorize_finish(e));
+  return rc;
 }
 
 int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, double* grad) {
@@ -2030,7 +2054,13 @@ int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, do
     e->factored = true;
     rc_grad = grad_accumulate(e, h);
   }
-  if ((rc = factorize_finish(e))) return rc;
+  if ((rc = factorize_finish(e))) {
+    // the gradient ran on garbage: nothing of it may outlive this call (gmb_copy_alpha checks have_alpha only)
+    e->have_alpha = false;
+    e->factor_consumed = false;
+    if (factorize_retry_after_abort(e, rc) != GMB_OK) return rc;
+    rc_grad = grad ? grad_accumulate(e, h) : GMB_OK;  // (an abandoned tile launch: the recursion's factor, the gradient again)
+  }
   if (rc_grad) return rc_grad;
   *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
   return grad ? grad_chain_rule(e, h, grad) : GMB_OK;
@@ -2400,7 +2430,8 @@ int64_t gmb_debug_chol_task(int32_t t, int32_t nct, int32_t nrt, int32_t* I, int
 int64_t gmb_chol_task_trace(gmb_engine* e, int32_t enable, uint64_t* out, int64_t cap_tasks) {
   if (!e) return GMB_EINVAL;
   if (enable >= 0) e->ct_trace = enable != 0;
-  const int64_t n = (e->ct_used && e->dct_trace && e->cap_ct_trace >= 4 * (int64_t)e->ct_ntasks) ? e->ct_ntasks : 0;
+  // only the stamps of the LAST factorisation count: 0 when it did not run on the tile kernel or ran untraced
+  const int64_t n = (e->ct_used && e->ct_traced && e->dct_trace && e->cap_ct_trace >= 4 * (int64_t)e->ct_ntasks) ? e->ct_ntasks : 0;
   if (out && n > 0) {
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -2419,13 +2450,16 @@ int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme) {
   if (!e) return GMB_EINVAL;
   const int old = e->chol_scheme;
   e->chol_scheme = scheme;
-  return old;
+  return old + 1;  // previous scheme + 1: "by size" (-1) comes back as 0, so no valid answer collides with a (negative) status
 }
 
 int gmb_blk_covariance(gmb_engine* e, double* out, int64_t ldo) {
   int rc = require_ready(e, false);
   if (rc) return rc;
   if (!out || ldo < e->Nr) return fail(e, GMB_EINVAL, "gmb_blk_covariance: out is null or ldo < %lld", (long long)e->Nr);
+  // the interior tiles go out as 16-byte stores (covariance.hpp: cov_interior_tile): two rows per lane
+  if ((((uintptr_t)out) | (uintptr_t)(ldo * (int64_t)sizeof(double))) & 15u)
+    return fail(e, GMB_EINVAL, "gmb_blk_covariance: out must be 16-byte aligned and ldo even (16-byte stores)");
   HIP_TRY(e, hipSetDevice(e->device));
   if ((rc = build_sigma(e, out, ldo))) return rc;
   HIP_TRY(e, hipStreamSynchronize(e->stream));

@@ -290,7 +290,8 @@ def _preload_hip_runtime():
 #: GMB_ABI_VERSION of include/gumbi_hip.h this binding was written against (the layout of
 #: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3; version 4 replaced the block-level
 #: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``, ``gmb_set_y`` and ``gmb_create_sibling``;
-#: version 6 the communication fields of ``gmb_timings`` and ``gmb_rccl_comm_ranks``)
+#: version 6 the communication fields of ``gmb_timings`` and ``gmb_rccl_comm_ranks``; version 7 ``gmb_evaluate``, the tile
+#: Cholesky's doors ``gmb_set_chol_scheme`` / ``gmb_chol_task_trace`` / ``gmb_debug_chol_*``)
 ABI_VERSION = 7
 
 
@@ -484,7 +485,10 @@ class Engine:
 
     def set_chol_scheme(self, scheme: int) -> int:
         """Schedule of the following factorisations; returns the previous setting."""
-        return int(self._lib.gmb_set_chol_scheme(self._h, int(scheme)))
+        prev = int(self._lib.gmb_set_chol_scheme(self._h, int(scheme)))  # previous + 1, or a negative status
+        if prev < 0:
+            self._check(prev, "gmb_set_chol_scheme")
+        return prev - 1
 
     def debug_lose_tickets(self, n: int):
         """Fault injection (tests): the next tile factorisation never computes the tiles of tickets 0 .. n-1."""

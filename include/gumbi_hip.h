@@ -293,7 +293,8 @@ int64_t gmb_chol_task_trace(gmb_engine* e, int32_t enable, uint64_t* out, int64_
  * waits: a few seconds), drain, and gmb_factorize must return GMB_EHIP -- never hang the GPU.  One shot. */
 int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n);
 /* Schedule of the Cholesky for the following factorisations: -1 = by size (default), 0 = plain recursion, 2 = masked
- * look-ahead, 3 = persistent tile kernel.  Returns the previous setting. */
+ * look-ahead, 3 = persistent tile kernel.  Returns the previous setting PLUS ONE (0 = by size, 1 = recursion, 3, 4), so
+ * that no valid answer collides with a negative gmb_status. */
 int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme);
 /* The covariance build alone: what gmb_factorize factors -- the lower-triangle 128 x 128 tiles of
  * Sigma = K + noise + jitter (pymc/GP.py:580), row N = y, identity padding -- written column-major into `out`
