@@ -369,6 +369,38 @@ def roofline_block(tm, config):
             "achieved": round(mtf, 3),
             "frac_of_their_share_of_peak": round(mtf / (FP64_MFMA_PEAK_TFLOPS * tm["masked_cus"] / ncu), 4),
         }
+    if int(tm.get("total_eval_tile_launches", 0)) > 0 and int(tm["total_chol_gemm_launches"]) == 0:
+        # N <= ~28k: the matrix work of a MAP evaluation is ONE launch of the persistent evaluation kernel (csrc/eval_tiles.hpp):
+        # the tile Cholesky, L^-T by rows and Sigma^-1 = U U^T as 128 x 128 tile tasks from one ticket counter -- the roofline is
+        # that whole launch, latency chain, leaves and strip solves included
+        n_t = int(tm["total_eval_tile_launches"])
+        tf = tm["total_eval_tile_flops"] / max(tm["total_eval_tile_ms"], 1e-9) / 1e9
+        n_alg = float(CONFIGS[config]["N"]) if config in CONFIGS else 0.0
+        alg_tf = n_alg**3 * n_t / max(tm["total_eval_tile_ms"], 1e-9) / 1e9  # N^3/3 each: Cholesky, inverse, Sigma^-1 (unpadded)
+        out.update({
+            "kernel": "eval_tiles_kernel<8>, the persistent evaluation launch: tile Cholesky + L^-T by rows + Sigma^-1 = U U^T as "
+                      "128 x 128 tile tasks on v_mfma_f64_16x16x4_f64 (LDS-DMA staged contraction, leaves and strip solves inside, "
+                      "flags between workgroups) -- ONE launch per MAP evaluation",
+            "subset_note": "achieved / frac cover the whole evaluation launch (factorisation + inverse + Sigma^-1), latency chain "
+                           "included; flops = the tiles' contractions on the 128-padded matrix, achieved_on_unpadded_N3 = N^3 per "
+                           "launch over the same time; all_gemm_launches beside it adds the prediction's launches",
+            "achieved": round(tf, 3), "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "launches": n_t,
+            "avg_launch_ms": round(tm["total_eval_tile_ms"] / n_t, 5), "flops_per_launch": round(tm["total_eval_tile_flops"] / n_t, 1),
+            "achieved_over_wall_time": round(tf, 3),
+            "achieved_on_unpadded_N3": round(alg_tf, 3), "frac_on_unpadded_N3": round(alg_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+        })
+        out.pop("in_panel_products", None)
+        pt = pmc_traffic(config, "eval_tiles_kernel<8>")
+        if pt is not None and pt["launches"] > 0:
+            out["traffic"] = round(pt["bytes_per_launch"], 1)
+            out["traffic_unit"] = ("HBM-side bytes per evaluation launch: (2*FETCH_SIZE + WRITE_SIZE) of eval_tiles_kernel<8> over one "
+                                   "bench step (rocprofv3 PMC passes) / its launches; L, U and Sigma^-1 themselves are 3 x 8 N^2 / 2 "
+                                   "bytes -- the rest is operand tiles re-read from HBM (the reader sits on another XCD's L2)")
+            out["traffic_flop_per_byte"] = round(tm["total_eval_tile_flops"] / n_t / max(pt["bytes_per_launch"], 1.0), 2)
+            out["traffic_source"] = pt["source"]
+            out["traffic_is_stale"] = pt["stale"]
+            out["traffic_kernel_sources_sha16"] = {"then": pt["kernel_sources_sha16_then"], "now": pt["kernel_sources_sha16_now"]}
+        return out
     if int(tm.get("total_chol_tile_launches", 0)) > 0 and int(tm["total_chol_gemm_launches"]) == 0:
         # N <= ~20k: the factorisation is ONE launch of the persistent tile kernel (csrc/chol_tiles.hpp) -- there are no
         # separate trailing-update launches to quote; the roofline is the whole launch: contraction, leaves and strip

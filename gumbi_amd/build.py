@@ -42,7 +42,8 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         return LIB
     LIB.parent.mkdir(parents=True, exist_ok=True)
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", *(["-DGMB_TUNING"] if tuning else []), *[str(CSRC / s) for s in SOURCES], "-o", str(target)]
+           "-Wno-unused-function", *(["-DGMB_TUNING"] if tuning else []), *(os.environ.get("GUMBI_BUILD_DEFINES", "").split() if tuning else []),
+           *[str(CSRC / s) for s in SOURCES], "-o", str(target)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

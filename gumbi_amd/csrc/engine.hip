@@ -34,6 +34,7 @@
 #include "potrf_leaf.hpp"
 #include "trsm_strip.hpp"
 #include "chol_tiles.hpp"
+#include "eval_tiles.hpp"
 
 using namespace gmb;
 
@@ -196,6 +197,19 @@ struct gmb_engine {
   };
   HostLanding* hl = nullptr;
   hipEvent_t fe[4] = {nullptr, nullptr, nullptr, nullptr};  // K-build begin / end, Cholesky begin / end
+  // persistent evaluation launch (eval_tiles.hpp): L^-T by rows and Sigma^-1 as tile tasks, fused with the tile Cholesky
+  // when the caller asks for the gradient together with the factorisation (gmb_evaluate)
+  int grad_scheme = -1;        // -1 = by size; 0 = launch tree (winv_levels); 1 = tile tasks behind the factorisation; 2 = fused
+  int et_lag = -1;             // the INV tasks of column c - lag follow the CHOL tasks of column c in the task list (-1: by size)
+  uint32_t* det_tasks = nullptr;  // task list on the device, and what it was built for
+  int64_t cap_et_tasks = 0;
+  int et_key[4] = {-1, -1, -1, -1};
+  int et_ntasks = 0;
+  double* dUdiag = nullptr;    // diagonal tiles of U = L^-T
+  int64_t cap_udiag = 0;
+  double* dApart = nullptr;    // partial products U(r,c) v_c
+  int64_t cap_apart = 0;
+  bool et_fused = false;       // the factorisation in flight carries INV / ZZ tasks: Sigma^-1 (dW) and the alpha parts come with it
   int tiles_min_blocks = 6, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default (measured faster from N = 768 on)
   int tiles_trsm_min_blocks = 16;                    // ... and the tile triangular solve of the predict path (measured from N = 2560 on)
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
@@ -343,7 +357,7 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
     float t = 0.f;
     (void)hipEventElapsedTime(&t, p.a, p.b);
     if (trace) fprintf(trace, "%d %d %d %d %d %.5f %.1f\n", p.kind, p.mt, p.nt, p.k, p.flags, t, p.flops / 1e9);
-    if (p.kind == 0 || p.kind == 7 || p.kind == 8 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
+    if (p.kind == 0 || p.kind == 7 || p.kind == 8 || p.kind == 9 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
       e->tm.total_gemm_ms += t;
       e->tm.total_gemm_flops += p.flops;
       e->tm.total_gemm_launches += 1;
@@ -360,6 +374,13 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
         e->tm.chol_gemm_ms += t;
         e->tm.chol_gemm_flops += p.flops;
         e->tm.chol_gemm_launches += 1;
+        break;
+      case 9:  // the persistent evaluation launch: (factorisation +) inverse + Sigma^-1 (flags & 1: with the factorisation)
+        e->tm.total_eval_tile_ms += t;
+        e->tm.total_eval_tile_flops += p.flops;
+        e->tm.total_eval_tile_launches += 1;
+        e->tm.grad_gemm_ms += t;
+        e->tm.grad_gemm_flops += p.flops;
         break;
       case 0:
       case 7:
@@ -923,6 +944,102 @@ int trsm_tiles(gmb_engine* e, double* V, int64_t ldv, int ntm, int ev_kind) {
   return GMB_OK;
 }
 
+// One persistent launch for L^-T (rows), Sigma^-1 = U U^T into dW and the alpha parts -- with the factorisation's own tile
+// tasks in the same launch (with_chol) or behind a factorisation that is already final (eval_tiles.hpp).
+int grad_workspace(gmb_engine* e);
+int eval_tiles(gmb_engine* e, bool with_chol) {
+  const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
+  int rc;
+  // The ticket counter runs ahead of the factorisation's latency chain by about as many tasks as there are workgroups: an
+  // inverse task drawn before its diagonal block L(c, c) exists would sit on a compute unit waiting for it (lag 1 at
+  // N = 10k: 75 us median per task, 18.3 ms per evaluation; a quarter of the block columns behind: none, 16.3 ms;
+  // tools/gpu_eval_lag.py)
+  const int lag = e->et_lag >= 0 ? e->et_lag : std::max(2, std::min(24, nct / 4));
+  if (e->et_key[0] != nct || e->et_key[1] != nrt || e->et_key[2] != (int)with_chol || e->et_key[3] != lag) {
+    std::vector<uint32_t> list;
+    et_build_tasks(nct, nrt, with_chol, lag, list);
+    if ((rc = ensure(e, &e->det_tasks, &e->cap_et_tasks, (int64_t)list.size()))) return rc;
+    HIP_TRY(e, hipMemcpy(e->det_tasks, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    e->et_key[0] = nct;
+    e->et_key[1] = nrt;
+    e->et_key[2] = (int)with_chol;
+    e->et_key[3] = lag;
+    e->et_ntasks = (int)list.size();
+  }
+  const int ntasks = e->et_ntasks;
+  const int64_t chol_words = (int64_t)nrt * nct + 3 * (int64_t)nct;
+  const int64_t words = 4 + chol_words + (int64_t)nct * nct;
+  if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
+  if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
+  if ((rc = ensure(e, &e->dUdiag, &e->cap_udiag, (int64_t)nct * TILE * TILE))) return rc;
+  if ((rc = ensure(e, &e->dApart, &e->cap_apart, (int64_t)nct * nct * TILE))) return rc;
+  if ((rc = grad_workspace(e))) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
+  // a factor that is final already: every tile flag reads "final" (any non-zero word)
+  if (!with_chol) HIP_TRY(e, hipMemsetAsync(e->dct + 4, 1, (size_t)nrt * nct * sizeof(uint32_t), e->cur));
+  e->ct_injected = with_chol && e->ct_lose > 0;
+  if (with_chol && e->ct_lose > 0) {  // fault injection: tickets 0 .. ct_lose-1 are never handed out
+    const uint32_t first = (uint32_t)e->ct_lose;
+    e->ct_lose = 0;
+    HIP_TRY(e, hipMemcpyAsync(e->dct, &first, sizeof first, hipMemcpyHostToDevice, e->cur));
+    HIP_TRY(e, hipStreamSynchronize(e->cur));
+  }
+  CholTilesArgs a{};
+  a.A = e->dA;
+  a.ld = e->ld;
+  a.nct = nct;
+  a.nrt = nrt;
+  a.N = e->N;
+  a.dinv16 = e->dDinv16;
+  a.logdet = e->dscal;
+  a.info = e->dinfo;
+  a.ctl = e->dct;
+  a.flags = e->dct + 4;
+  a.half = e->dct + 4 + (int64_t)nrt * nct;
+  a.prog = a.half + 2 * (int64_t)nct;
+  a.ntasks = ntasks;
+  a.timeout_us = 4000000u;
+  a.dbg = nullptr;
+  e->ct_traced = false;
+  if (e->ct_trace) {
+    e->ct_traced = true;
+    if ((rc = ensure(e, &e->dct_trace, &e->cap_ct_trace, 4 * (int64_t)ntasks))) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->dct_trace, 0, (size_t)ntasks * 4 * sizeof(unsigned long long), e->cur));
+    a.dbg = e->dct_trace;
+  }
+  EvalTilesArgs x{};
+  x.tasks = e->det_tasks;
+  x.ntasks = ntasks;
+  x.uflags = e->dct + 4 + chol_words;
+  x.udiag = e->dUdiag;
+  x.Z = e->dW;
+  x.ldz = e->Np;
+  x.apart = e->dApart;
+  x.yb = (int)(e->N / TILE);
+  double flops = 0.0;
+  if (with_chol)
+    for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (double)(nrt - j);
+  for (int c = 0; c < nct; ++c) flops += 2.0 * TILE * TILE * TILE * 0.5 * (double)c * (double)(c + 1);              // INV column c
+  for (int I = 0; I < nct; ++I) flops += 2.0 * TILE * TILE * TILE * (double)(nct - I) * (double)(I + 1);             // ZZ block row I
+  int nw = 8;
+#ifdef GMB_TUNING
+  if (const char* cw = getenv("GMB_ET_WAVES")) nw = atoi(cw) == 4 ? 4 : 8;
+#endif
+  const int grid = (int)std::min<long long>(ntasks, nw == 8 ? e->wg_slots / 2 : e->wg_slots);
+  ev_begin(e, 9, flops, nct, nrt, (int)e->Np, with_chol ? 1 : 0);
+  if (nw == 8) hipLaunchKernelGGL(eval_tiles_kernel<8>, dim3(grid), dim3(512), 0, e->cur, a, x);
+#ifdef GMB_TUNING
+  else hipLaunchKernelGGL(eval_tiles_kernel<4>, dim3(grid), dim3(256), 0, e->cur, a, x);
+#endif
+  ev_end(e);
+  HIP_TRY(e, hipGetLastError());
+  hipLaunchKernelGGL(alpha_from_parts_kernel, dim3(nct), dim3(TILE), 0, e->cur, e->dApart, nct, e->N, e->dalpha);
+  HIP_TRY(e, hipGetLastError());
+  e->ct_used = true;
+  e->ct_ntasks = ntasks;
+  return GMB_OK;
+}
+
 // ---- cross-stream ordering helpers -----------------------------------------------------------
 hipEvent_t next_sync_event(gmb_engine* e) {
   if (e->sync_next == e->sync_pool.size()) {
@@ -1450,6 +1567,14 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
   return GMB_OK;
 }
 
+// matrices whose inverse / Sigma^-1 run as tile tasks (eval_tiles.hpp): the sizes the tile Cholesky factors
+bool grad_by_tiles(const gmb_engine* e) {
+  const int nt = (int)(e->Np / TILE);
+  if (e->naive_leaf || e->grad_scheme == 0) return false;
+  if (e->grad_scheme > 0) return nt >= 1 && nt <= 0x7fff;
+  return nt >= e->tiles_min_blocks && nt <= e->tiles_max_blocks;
+}
+
 // Single-GPU gradient: W = L^-1 and U = L^-T by recursive block inversion, alpha = W^T v, Sigma^-1 = U U^T
 // into dW, reductions.  The factor is consumed.
 int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
@@ -1462,6 +1587,28 @@ int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
   if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
   if ((rc = grad_workspace(e))) return rc;
   const int nt = (int)(e->Np / TILE);
+  if (e->et_fused || grad_by_tiles(e)) {
+    // Sigma^-1 and the alpha parts come from the persistent evaluation launch: already enqueued with the factorisation
+    // (gmb_evaluate), or launched here behind a factor that is final.  L stays intact: nothing to save or restore.
+    PhaseTimer tgt(e);
+    bool own_launch = false;
+    if (!e->et_fused) {
+      e->cur = e->stream;
+      if ((rc = eval_tiles(e, false))) return rc;
+      own_launch = true;
+    }
+    e->et_fused = false;
+    if ((rc = grad_reduce(e, 0, 1, e->dW, e->Np, false, h))) return rc;
+    tgt.stop();
+    uint32_t ab = 0;
+    if (own_launch) HIP_TRY(e, hipMemcpyAsync(&ab, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    tm.grad_ms = tgt.ms();
+    ev_collect(e);
+    if (ab != 0) return fail(e, GMB_EHIP, "tile inverse: a workgroup waited longer than its time-out for a tile (launch abandoned)");
+    e->have_alpha = true;
+    return GMB_OK;
+  }
   if ((rc = ensure(e, &e->dDiagSave, &e->cap_diag, (int64_t)nt * TILE * TILE))) return rc;
   PhaseTimer tg(e);
   // the diagonal blocks of L are put back at the end: U takes their place in between
@@ -1927,7 +2074,7 @@ namespace {
 
 // Everything of gmb_factorize up to (not including) the host's look at the results: K-build, Cholesky, v = L^-1 y, and the
 // asynchronous copies of log-det / |v|^2 / failure index / abort word into the engine.  Nothing is synchronised.
-int factorize_enqueue(gmb_engine* e) {
+int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
   int rc = require_ready(e, false);
   if (rc) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -1966,7 +2113,12 @@ int factorize_enqueue(gmb_engine* e) {
   e->ct_used = false;
   e->ct_traced = false;
   e->cur = e->stream;
-  if ((rc = tiles ? chol_tiles(e) : masked ? chol_lookahead_masked(e) : chol_cols(e, 0, nblocks, (int)(e->Nr / TILE)))) return rc;
+  e->et_fused = false;
+  if (tiles && with_grad && grad_by_tiles(e) && e->grad_scheme != 1) {
+    // the gradient's inverse and Sigma^-1 ride in the factorisation's launch (eval_tiles.hpp)
+    if ((rc = eval_tiles(e, true))) return rc;
+    e->et_fused = true;
+  } else if ((rc = tiles ? chol_tiles(e) : masked ? chol_lookahead_masked(e) : chol_cols(e, 0, nblocks, (int)(e->Nr / TILE)))) return rc;
   // 3. v = L^-1 y is row N of the factor
   hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
                      e->dscal + 1);
@@ -2045,7 +2197,7 @@ int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, do
   if (!e || !nlml) return GMB_EINVAL;
   int rc = gmb_set_theta(e, theta, n);
   if (rc) return rc;
-  if ((rc = factorize_enqueue(e))) return rc;
+  if ((rc = factorize_enqueue(e, grad != nullptr))) return rc;
   int rc_grad = GMB_OK;
   std::vector<double> h;
   if (grad) {
@@ -2058,6 +2210,7 @@ int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, do
     // the gradient ran on garbage: nothing of it may outlive this call (gmb_copy_alpha checks have_alpha only)
     e->have_alpha = false;
     e->factor_consumed = false;
+    e->et_fused = false;
     if (factorize_retry_after_abort(e, rc) != GMB_OK) return rc;
     rc_grad = grad ? grad_accumulate(e, h) : GMB_OK;  // (an abandoned tile launch: the recursion's factor, the gradient again)
   }
@@ -2451,6 +2604,23 @@ int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme) {
   const int old = e->chol_scheme;
   e->chol_scheme = scheme;
   return old + 1;  // previous scheme + 1: "by size" (-1) comes back as 0, so no valid answer collides with a (negative) status
+}
+
+int gmb_set_grad_scheme(gmb_engine* e, int32_t scheme, int32_t lag) {
+  if (!e || scheme < -1 || scheme > 2) return GMB_EINVAL;
+  const int old = e->grad_scheme;
+  e->grad_scheme = scheme;
+  if (lag >= 0) e->et_lag = lag;
+  return old + 1;
+}
+
+int64_t gmb_debug_eval_tasks(int32_t nct, int32_t nrt, int32_t with_chol, int32_t lag, uint32_t* out, int64_t cap) {
+  if (nct < 1 || nrt < nct || nrt > 0x7fff || lag < 0) return GMB_EINVAL;
+  std::vector<uint32_t> list;
+  et_build_tasks(nct, nrt, with_chol != 0, lag, list);
+  if (out)
+    for (int64_t i = 0; i < (int64_t)list.size() && i < cap; ++i) out[i] = list[(size_t)i];
+  return (int64_t)list.size();
 }
 
 int gmb_blk_covariance(gmb_engine* e, double* out, int64_t ldo) {

@@ -1,0 +1,635 @@
+// eval_tiles.hpp -- the matrix work of ONE MAP-objective evaluation as ONE persistent launch: the tile Cholesky of
+// chol_tiles.hpp, the triangular inverse and Sigma^-1, all as 128 x 128 tile tasks served from one ticket counter.
+//
+// Why: after round 3 the gradient was two thirds of a C2 evaluation (11.9 of 18.0 ms at N = 10k): a tree of ~35 GEMM
+// launches for L^-1 (quantisation-bound: 56 TF/s) behind a factorisation whose first and last ~11 block columns are
+// bound by the latency chain with the machine mostly idle.  Here the three phases share the chip at TILE granularity:
+//
+//   CHOL (I, J), I >= J   L tile of chol_tiles.hpp (left-looking contraction, leaf / strip solve, publication)
+//   INV  (r, c), c >= r   U = L^-T BY ROWS:  U(r,c) = (delta_rc I - sum_{k=r}^{c-1} U(r,k) L(c,k)^T) L(c,c)^-T
+//                         -- the forward substitution of block row r of the identity; the nct rows are INDEPENDENT
+//                         chains (unlike the Cholesky there is no serial diagonal), and U(., c) only needs block row c of
+//                         L, which is final as soon as the factorisation has passed column c: the inverse runs BESIDE
+//                         the factorisation and fills its chain-bound ends;
+//   ZZ   (I, J), I >= J   Sigma^-1(I,J) = sum_{k >= I} U(I,k) U(J,k)^T -- no dependencies among themselves, ticketed
+//                         longest contraction first after everything else.
+//
+// Both operands of every contraction are k-major, as everywhere in the engine (gemm_f64.hpp): U is kept by rows
+// precisely so that Sigma^-1 = U U^T contracts over the slow index.  U's strictly upper tiles live in the (free) upper
+// triangle of the factor buffer, its diagonal tiles in a side buffer (`udiag`): L stays intact, predict() after a
+// gradient needs no restore.  INV tasks also leave the partial products U(r,c) v_c (v = L^-1 y, row N of the factor) so
+// that alpha = U v = Sigma^-1 y costs one tiny fixed-order reduction afterwards.
+//
+// Tickets come from a host-built task list (kind, I, J) in a topological order of the dependency graph (CHOL column c,
+// then INV column c - lag, ..., ZZ last): a task only ever waits for tasks with smaller tickets, which are finished or
+// held by a running workgroup -- no deadlock whatever the residency of the workgroups; every wait is bounded by the
+// abort word of chol_tiles.hpp.  Every tile is written once by its owner, every contraction runs in k order in one
+// accumulator: same bits run to run.
+//
+// Replaces, per evaluation, the reverse-mode sweep through PyTensor's Cholesky op inside pm.find_MAP
+// (gumbi/regression/pymc/GP.py:811).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "chol_tiles.hpp"
+
+namespace gmb {
+
+constexpr uint32_t ET_CHOL = 0u, ET_INV = 1u, ET_ZZ = 2u;
+__host__ __device__ inline uint32_t et_pack(uint32_t kind, int I, int J) { return (kind << 30) | ((uint32_t)I << 15) | (uint32_t)J; }
+
+struct EvalTilesArgs {
+  const uint32_t* tasks;  // et_pack(kind, I, J), in ticket order
+  int32_t ntasks;
+  uint32_t* uflags;       // nct x nct words (zeroed before the launch): U tile (r, c) is final when [r * nct + c] != 0
+  double* udiag;          // nct tiles of 128 x 128 (leading dimension 128): the diagonal tiles U(r, r)
+  double* Z;              // Sigma^-1 out: lower block triangle (diagonal tiles in full), column-major
+  int64_t ldz;
+  double* apart;          // [(r * nct + c) * 128 + i]: (U(r,c) v_c)_i -- alpha_r = sum_c of these, added up in c order afterwards
+  int32_t yb;             // block row of the factor buffer that holds row N (v = L^-1 y)
+};
+
+// One block row of a k-major operand: k-block kb lives at base + kb * 128 * ld, except k-block diag_kb, which lives in a
+// side tile with leading dimension 128 (U's diagonal tiles).
+struct EtOperand {
+  const double* base;
+  int64_t ld;
+  const double* diag;
+  int diag_kb;
+};
+
+// Arguments of a non-inlined task function arrive in vector registers: tell the compiler they are wave-uniform, so that
+// loop control and address arithmetic stay on the scalar unit (no exec-mask branches inside the k loop).
+__device__ __forceinline__ int et_uni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* et_uni_ptr(T* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (T*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int64_t et_uni64(const int64_t x) {
+  const uint64_t v = (uint64_t)x;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// ONE wave: wait until k-block kb0 of both flag rows is final; returns the end of the run of final k-blocks that starts
+// there (<= kb_end, at most 32 further) after one agent-scope acquire; -1 = the launch is being abandoned.
+__device__ __forceinline__ int et_wait_rows(const CholTilesArgs& g, const uint32_t* pm, const uint32_t* pn, const int kb0, const int kb_end,
+                                            const bool urgent) {
+  const int lane = threadIdx.x & 63;
+  const int idx = kb0 + (lane & 31);
+  const bool mine = idx < kb_end;
+  const uint32_t* p = (lane < 32 ? pn : pm) + (mine ? idx : kb0);
+  unsigned spins = 0;
+  unsigned long long t0 = 0ull;
+  for (;;) {
+    const uint32_t v = __hip_atomic_load(p, CT_RLX_AGENT);
+    const unsigned long long m = __ballot(v != 0u || !mine);
+    const uint32_t both = (uint32_t)m & (uint32_t)(m >> 32);
+    const int n = both == 0xffffffffu ? 32 : __builtin_ctz(~both);
+    if (n > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const int e = kb0 + n;
+      return e < kb_end ? e : kb_end;
+    }
+    if (ct_give_up(g, spins, t0)) return -1;
+    if (urgent) __builtin_amdgcn_s_sleep(2);
+    else __builtin_amdgcn_s_sleep(40);
+  }
+}
+
+// out(128 x 128) = (NEG ? - : +) sum_{kb in [kb_lo, kb_hi)} N(kb) M(kb)^T: the k loop of ct_ksum (same staging, same pinned
+// instruction order), accumulators starting at zero, operands addressed per k-block (EtOperand), cut into segments at the
+// k-blocks whose tiles were not final yet.  Rows of `out` follow the n operand, columns the m operand.  Every thread of the
+// workgroup calls it; false = the launch is being abandoned (uniform).
+template <int NW, bool NEG>
+__device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand mop, const EtOperand nop, const uint32_t* mflags,
+                                        const uint32_t* nflags, const int kb_lo, const int kb_hi, double* __restrict__ out, const int64_t ldo,
+                                        double* __restrict__ lds, int* s_i) {
+  constexpr int WGN = 2, WGM = NW / WGN;
+  constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);
+  constexpr int KT = ct_kt(NW);
+  constexpr int PA = PITCH;
+  constexpr int LA = TILE / 2, RA = 64 * NW / LA, NA = KT / RA;
+  constexpr int KPB = TILE / KT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int s_row = tid / LA, s_col = 2 * (tid % LA);
+
+  d4 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  d2 ra[NA], rb[NA];
+
+  auto gload = [&](int kt) {
+    const int kb = kt / KPB;
+    const int krow = (kt - kb * KPB) * KT + s_row;
+    const bool md = kb == mop.diag_kb, nd = kb == nop.diag_kb;
+    const int64_t lda = md ? (int64_t)TILE : mop.ld, ldb = nd ? (int64_t)TILE : nop.ld;
+    const double* pa = (md ? mop.diag + (int64_t)krow * TILE : mop.base + ((int64_t)kt * KT + s_row) * mop.ld) + s_col;
+    const double* pb = (nd ? nop.diag + (int64_t)krow * TILE : nop.base + ((int64_t)kt * KT + s_row) * nop.ld) + s_col;
+#pragma unroll
+    for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const d2*>(pa + (int64_t)(RA * p) * lda);
+#pragma unroll
+    for (int p = 0; p < NA; ++p) rb[p] = *reinterpret_cast<const d2*>(pb + (int64_t)(RA * p) * ldb);
+  };
+  auto lstore = [&](int st) {
+    double* As = lds + st * (KT * 2 * PA);
+    double* Bs = As + KT * PA;
+#pragma unroll
+    for (int p = 0; p < NA; ++p) *reinterpret_cast<d2*>(&As[(s_row + RA * p) * PA + s_col]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < NA; ++p) *reinterpret_cast<d2*>(&Bs[(s_row + RA * p) * PA + s_col]) = rb[p];
+  };
+  auto compute = [&](int st) {
+    const double* As = lds + st * (KT * 2 * PA);
+    const double* Bs = As + KT * PA;
+#pragma unroll
+    for (int k4 = 0; k4 < KT; k4 += 4) {
+      double a[WTM], b[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) a[i] = As[(k4 + kq) * PA + wm * (16 * WTM) + i * 16 + r16];
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) b[j] = Bs[(k4 + kq) * PA + wn * (16 * WTN) + j * 16 + r16];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int kt_end = kb_hi * KPB;
+  int ktc = kb_lo * KPB;
+  while (ktc < kt_end) {
+    const int kb = ktc / KPB;
+    if (wave == 0) {
+      int r = et_wait_rows(g, mflags, nflags, kb, kb_hi, kb + 1 >= kb_hi);
+      if (r >= 0) r *= KPB;
+      s_i[1] = r;
+    }
+    __syncthreads();
+    const int kt1 = __builtin_amdgcn_readfirstlane(s_i[1]);
+    if (kt1 < 0) return false;
+    const int kt0 = ktc;
+    gload(kt0);
+    lstore(0);
+    __syncthreads();
+    int st = 0;
+    constexpr int NMFMA = WTM * WTN * (KT / 4), NMEM = 2 * NA;
+    constexpr int SLOT = NMFMA / (4 * NMEM);
+    static_assert(SLOT >= 1 && 2 * SLOT * NMEM <= NMFMA, "not enough MFMAs to interleave the staging with");
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
+      gload(kt + 1);
+      compute(st);
+      lstore(st ^ 1);
+#pragma unroll
+      for (int q = 0; q < NMEM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * SLOT * NMEM, 0);
+#pragma unroll
+      for (int q = 0; q < NMEM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+      }
+      __syncthreads();
+      st ^= 1;
+    }
+    compute(st);
+    __syncthreads();
+    ktc = kt1;
+  }
+
+  // D layout of v_mfma_f64_16x16x4_f64: n = lane & 15, m = (lane >> 4) + 4 reg
+  double* __restrict__ Cg = out + wn * (16 * WTN) + r16;
+  const int64_t m0 = wm * (16 * WTM) + kq;
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* row = Cg + (m0 + i * 16 + 4 * r) * ldo;
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) row[j * 16] = NEG ? -acc[i][j][r] : acc[i][j][r];
+    }
+  return true;
+}
+
+// ---- the same contraction with LDS-DMA staging (eight-wave workgroups) --------------------------------------------------
+// One eight-wave workgroup per compute unit has nobody else's MFMAs to fill its barrier bubbles with, and the register-staged
+// loop above stops at ~88 % of the matrix pipe: every wave meets the same barrier at the end of a k-tile, then waits for its
+// first fragments.  Here the operands go global -> LDS directly (global_load_lds_dwordx4: one wave instruction per 128-double
+// k-row, 1 KiB contiguous, which is exactly a row of the padded [k][row] image), into a ring of FOUR 16-deep stages:
+//
+//   tile kt, steps k4 = 0 .. 3 (8 MFMAs per wave each; the fragments of step s + 1 are read while step s computes, across
+//   tile boundaries too):
+//       step 0, step 1, step 2 (reads the last fragments of tile kt)
+//       s_waitcnt lgkmcnt(0) vmcnt(8) -- this wave's reads of tile kt have returned; its four DMAs of tile kt + 1 have landed
+//                                        (those of kt + 2 and kt + 3 stay in flight)
+//       s_barrier                     -- ... everybody's
+//       DMA of tile kt + 4 into the stage of tile kt
+//       step 3 (reads the first fragments of tile kt + 1)
+//
+// The one barrier per tile sits INSIDE the tile's MFMA stream (the wave arrives with eight MFMAs queued and its next
+// fragments in registers), three tiles of DMA are in flight across it (raw s_barrier: __syncthreads() would drain them), a
+// DMA has three tile times (~5 us) to land -- 96 KB in flight per compute unit, what 16 GB/s per compute unit needs at the
+// loaded HBM latency -- and no staging registers or ds_writes are left in the loop.
+template <bool NEG>
+__device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOperand mop_in, const EtOperand nop_in, const uint32_t* mflags,
+                                            const uint32_t* nflags, const int kb_lo_in, const int kb_hi_in, double* __restrict__ out,
+                                            const int64_t ldo, ct_lds_double* l3, int* s_i) {
+  constexpr int WGN = 2, WGM = 4;
+  constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);  // 2 x 4 MFMA tiles per wave
+  constexpr int KT = 16, NS = 4;
+  constexpr int PA = PITCH;
+  constexpr int STAGE = KT * 2 * PA;  // doubles
+  constexpr int KPB = TILE / KT;
+  static_assert(NS * STAGE <= ct_lds_doubles(8), "the DMA ring must fit the workgroup's LDS");
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void g_void;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const EtOperand mop{et_uni_ptr(mop_in.base), et_uni64(mop_in.ld), et_uni_ptr(mop_in.diag), et_uni(mop_in.diag_kb)};
+  const EtOperand nop{et_uni_ptr(nop_in.base), et_uni64(nop_in.ld), et_uni_ptr(nop_in.diag), et_uni(nop_in.diag_kb)};
+  const int kb_lo = et_uni(kb_lo_in), kb_hi = et_uni(kb_hi_in);
+
+  d4 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // This wave's share of a tile: k-rows wave and wave + 8 of both operands.  The DMAs walk the contraction tile by tile, so the
+  // source is a RUNNING pointer per operand (scalar registers; + 16 k-rows per tile), with one switch where an operand leaves
+  // its diagonal side tile -- always the first k-block of the range.  A call past the end of the current segment (`real`
+  // false) re-reads the operand's first tile instead: the ring then always has exactly two tiles in flight behind the one
+  // being waited for, and the loop body needs no conditionals (the garbage lands in stages nobody reads before the segment's
+  // closing wait).
+  struct Run {
+    const double* p;      // k-row `wave` of the next tile
+    int64_t ld;           // doubles between k-rows there
+    int diag_left;        // tiles left in the diagonal side tile (0: not in it)
+    const double* after;  // k-row `wave` of the first tile behind the diagonal k-block
+  };
+  auto run_init = [&](const EtOperand& op) {
+    Run r;
+    if (op.diag_kb == kb_lo) {
+      r.p = op.diag + (int64_t)wave * TILE;
+      r.ld = TILE;
+      r.diag_left = KPB;
+      r.after = op.base + ((int64_t)(kb_lo + 1) * TILE + wave) * op.ld;
+    } else {
+      r.p = op.base + ((int64_t)kb_lo * TILE + wave) * op.ld;
+      r.ld = op.ld;
+      r.diag_left = 0;
+      r.after = nullptr;
+    }
+    return r;
+  };
+  Run ra = run_init(mop), rb = run_init(nop);
+  const double* const dummy_a = mop.base + (int64_t)wave * mop.ld;
+  const double* const dummy_b = nop.base + (int64_t)wave * nop.ld;
+  const int lane2 = 2 * lane;
+  [[maybe_unused]] int fake_ctr = 0;
+  auto dma = [&](const int stage, bool real) {
+#ifdef GMB_ET_FAKE_LOADS  // tuning probe: every DMA re-reads the operand's first tile (cache-resident) -- timing only, garbage out
+    real = false;
+#endif
+    ct_lds_double* As = l3 + stage * STAGE + wave * PA;
+    ct_lds_double* Bs = As + KT * PA;
+#if defined(GMB_ET_FAKE_LOADS) && GMB_ET_FAKE_LOADS == 2  // ... or walks the first k-block of block row 0 round and round (L2-resident, not L1)
+    static_assert(KPB == 8, "");
+    const double* pa = g.A + ((int64_t)(fake_ctr & 7) * KT + wave) * mop.ld;
+    const double* pb = g.A + (int64_t)TILE + ((int64_t)(fake_ctr & 7) * KT + wave) * nop.ld;
+    ++fake_ctr;
+#else
+    const double* pa = real ? ra.p : dummy_a;
+    const double* pb = real ? rb.p : dummy_b;
+#endif
+    const int64_t lda = real ? ra.ld : mop.ld, ldb = real ? rb.ld : nop.ld;
+    __builtin_amdgcn_global_load_lds((g_void*)(pa + lane2), (lds_void*)As, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g_void*)(pb + lane2), (lds_void*)Bs, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g_void*)(pa + 8 * lda + lane2), (lds_void*)(As + 8 * PA), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g_void*)(pb + 8 * ldb + lane2), (lds_void*)(Bs + 8 * PA), 16, 0, 0);
+    if (real) {
+      ra.p += KT * ra.ld;
+      rb.p += KT * rb.ld;
+      if (ra.diag_left > 0 && --ra.diag_left == 0) {
+        ra.p = ra.after;
+        ra.ld = mop.ld;
+      }
+      if (rb.diag_left > 0 && --rb.diag_left == 0) {
+        rb.p = rb.after;
+        rb.ld = nop.ld;
+      }
+    }
+  };
+  double fa[2][WTM], fb[2][WTN];
+  auto frags = [&](const int kt, const int k4, const int buf) {
+    const ct_lds_double* As = l3 + (kt & (NS - 1)) * STAGE + (4 * k4 + kq) * PA + r16;
+    const ct_lds_double* Bs = As + KT * PA;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) fa[buf][i] = As[wm * (16 * WTM) + i * 16];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) fb[buf][j] = Bs[wn * (16 * WTN) + j * 16];
+  };
+  auto mfmas = [&](const int buf) {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+  };
+  // one step's issue order: the next step's three fragment reads go out behind the first MFMAs of this one
+  auto pin_step = [&]() {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, WTM * WTN - 3, 0);
+  };
+
+  const int kt_end = kb_hi * KPB;
+  int ktc = kb_lo * KPB;
+  while (ktc < kt_end) {
+    const int kb = ktc / KPB;
+    if (wave == 0) {
+      int r = et_wait_rows(g, mflags, nflags, kb, kb_hi, kb + 1 >= kb_hi);
+      if (r >= 0) r *= KPB;
+      s_i[1] = r;
+    }
+    __syncthreads();  // (no DMA in flight here)
+    const int kt1 = __builtin_amdgcn_readfirstlane(s_i[1]);
+    if (kt1 < 0) return false;
+    const int kt0 = ktc;
+    // prologue: four tiles on their way, the first one landed
+    dma(kt0 & (NS - 1), true);
+    dma((kt0 + 1) & (NS - 1), kt0 + 1 < kt1);
+    dma((kt0 + 2) & (NS - 1), kt0 + 2 < kt1);
+    dma((kt0 + 3) & (NS - 1), kt0 + 3 < kt1);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    frags(kt0, 0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      frags(kt, 1, 1);
+      mfmas(0);
+      pin_step();
+      frags(kt, 2, 0);
+      mfmas(1);
+      pin_step();
+      frags(kt, 3, 1);
+      mfmas(0);
+      pin_step();
+      // every read of tile kt has returned (this wave); its DMAs of tile kt + 1 have landed (kt + 2, kt + 3 stay in flight)
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // ... everybody's: tile kt + 1 may be read, the stage of tile kt may be overwritten
+      dma(kt & (NS - 1), kt + 4 < kt1);
+      frags(kt + 1, 0, 0);  // (behind the last tile of a segment: a stage of garbage, never used)
+      mfmas(1);
+      pin_step();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the next segment's (or the next task's) first writes must not overtake slow waves' reads
+    ktc = kt1;
+  }
+
+  double* __restrict__ Cg = out + wn * (16 * WTN) + r16;
+  const int64_t m0 = wm * (16 * WTM) + kq;
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* row = Cg + (m0 + i * 16 + 4 * r) * ldo;
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) row[j * 16] = NEG ? -acc[i][j][r] : acc[i][j][r];
+    }
+  return true;
+}
+
+// the contraction of a task: LDS-DMA staging for eight-wave workgroups (ET_DMA), the register-staged loop otherwise
+#ifndef ET_DMA
+#define ET_DMA 1
+#endif
+template <int NW, bool NEG>
+__device__ __forceinline__ bool et_contract(const CholTilesArgs& g, const EtOperand mop, const EtOperand nop, const uint32_t* mflags,
+                                            const uint32_t* nflags, const int kb_lo, const int kb_hi, double* __restrict__ out, const int64_t ldo,
+                                            ct_lds_double* l3, int* s_i) {
+  if constexpr (NW == 8 && ET_DMA) return et_ksum_dma<NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, l3, s_i);
+  else return et_ksum<NW, NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, (double*)l3, s_i);
+}
+
+// INV task (r, c): tile (r, c) of U = L^-T.  Contraction over the tiles (r, k) of its own row and block row c of L, strip solve
+// against L(c, c), publication for the later tiles of the row and for the ZZ tasks; then the partial product with v_c.
+template <int NW>
+__device__ __noinline__ bool et_inv_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* udiag, ct_g_double* apart,
+                                         ct_g_u32* flags, ct_g_u32* uflags, ct_g_u32* ctl, ct_g_u64* dbg, const int r, const int c, const int t,
+                                         const int yb, ct_lds_double* l3, ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, nullptr, nullptr, flags, nullptr, ctl, dbg);
+  const uint32_t* uf = (const uint32_t*)uflags;
+  double* ud = (double*)udiag;
+  int* s_i = (int*)s3;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  TrsmArgs ta;
+  ta.B = c == r ? ud + (int64_t)r * TILE * TILE : g.A + (int64_t)r * TILE + (int64_t)c * TILE * g.ld;
+  ta.ldb = c == r ? (int64_t)TILE : g.ld;
+  ta.nrows = TILE;
+  ta.L = g.A + (int64_t)c * TILE * (g.ld + 1);
+  ta.ldl = g.ld;
+  ta.dinv16 = g.dinv16 + (int64_t)c * 8 * 256;
+  ta.nvalid = (int)(g.N - (int64_t)c * TILE < TILE ? g.N - (int64_t)c * TILE : TILE);
+  strip_d4 X0[8], X1[8];
+  if (c > r) {
+    const EtOperand mop{g.A + (int64_t)c * TILE, g.ld, nullptr, -1};                       // block row c of L
+    const EtOperand nop{g.A + (int64_t)r * TILE, g.ld, ud + (int64_t)r * TILE * TILE, r};  // block row r of U
+    if (!et_contract<NW, true>(g, mop, nop, g.flags + (int64_t)c * g.nct, uf + (int64_t)r * g.nct, r, c, ta.B, ta.ldb, l3, s_i)) return false;
+    if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own epilogue stores are read back by other lanes
+    __syncthreads();
+    trsm_strip_load(ta, 16 * wave, X0);
+    if constexpr (NW == 4) trsm_strip_load(ta, 16 * (wave + 4), X1);
+  } else {
+    // block row r of the identity
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        X0[s][q] = (16 * wave + r16 == 16 * s + kq + 4 * q) ? 1.0 : 0.0;
+        if constexpr (NW == 4) X1[s][q] = (16 * (wave + 4) + r16 == 16 * s + kq + 4 * q) ? 1.0 : 0.0;
+      }
+  }
+  // L(c, c)
+  if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)c * g.nct + c, false);
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+  trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+  if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  if (ta.nvalid < TILE) {
+    // last block column of a ragged matrix: columns >= nvalid went through the solve as identity padding and carry the y row's
+    // products -- Sigma^-1 = U U^T must not see them
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 16 * s + kq + 4 * q;
+        if (col >= ta.nvalid) {
+          X0[s][q] = 0.0;
+          __hip_atomic_store(&ta.B[16 * wave + r16 + (int64_t)col * ta.ldb], 0.0, CT_RLX_AGENT);
+          if constexpr (NW == 4) {
+            X1[s][q] = 0.0;
+            __hip_atomic_store(&ta.B[16 * (wave + 4) + r16 + (int64_t)col * ta.ldb], 0.0, CT_RLX_AGENT);
+          }
+        }
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave == 0) {
+    __hip_atomic_store(uflags + (int64_t)r * g.nct + c, 1u, CT_RLX_AGENT);
+    if (g.dbg) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
+  }
+  // (U(r,c) v_c)_i for the rows of this wave, in a fixed order: 32 columns per lane, then the four lane groups.  Row N of the
+  // factor sits in block row yb: the LAST tile of column c in ticket order -- waited for here, behind the publication, so
+  // that it never holds up the row's chain.
+  if (yb != c) {
+    if (wave == 0) s_i[1] = ct_wait_one(g, g.flags + (int64_t)yb * g.nct + c, false);
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
+  }
+  {
+    const double* vrow = g.A + g.N + (int64_t)c * TILE * g.ld;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 16 * s + kq + 4 * q;
+        const double vv = col < ta.nvalid ? vrow[(int64_t)col * g.ld] : 0.0;
+        s0 = fma(X0[s][q], vv, s0);
+        if constexpr (NW == 4) s1 = fma(X1[s][q], vv, s1);
+      }
+    s0 += __shfl_xor(s0, 16);
+    s0 += __shfl_xor(s0, 32);
+    double* ap = (double*)apart + ((int64_t)r * g.nct + c) * TILE;
+    if (kq == 0) ap[16 * wave + r16] = s0;
+    if constexpr (NW == 4) {
+      s1 += __shfl_xor(s1, 16);
+      s1 += __shfl_xor(s1, 32);
+      if (kq == 0) ap[16 * (wave + 4) + r16] = s1;
+    }
+  }
+  return true;
+}
+
+// ZZ task (I, J), I >= J: tile (I, J) of Sigma^-1 = U U^T, contraction over k >= I.
+template <int NW>
+__device__ __noinline__ bool et_zz_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* udiag, ct_g_double* Z, const int64_t ldz,
+                                        ct_g_u32* uflags, ct_g_u32* ctl, ct_g_u64* dbg, const int I, const int J, const int t, ct_lds_double* l3,
+                                        ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, nullptr, nullptr, nullptr, nullptr, nullptr, ctl, dbg);
+  const uint32_t* uf = (const uint32_t*)uflags;
+  const double* ud = (const double*)udiag;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const EtOperand mop{g.A + (int64_t)J * TILE, g.ld, ud + (int64_t)J * TILE * TILE, J};
+  const EtOperand nop{g.A + (int64_t)I * TILE, g.ld, ud + (int64_t)I * TILE * TILE, I};
+  double* out = (double*)Z + (int64_t)I * TILE + (int64_t)J * TILE * ldz;
+  if (!et_contract<NW, false>(g, mop, nop, uf + (int64_t)J * g.nct, uf + (int64_t)I * g.nct, I, g.nct, out, ldz, l3, (int*)s3)) return false;
+  if (g.dbg && wave == 0) {
+    const unsigned long long now = wall_clock64();
+    g.dbg[4 * (int64_t)t + 1] = now;
+    g.dbg[4 * (int64_t)t + 2] = now;
+    g.dbg[4 * (int64_t)t + 3] = now;
+  }
+  return true;
+}
+
+// The persistent loop: tickets index the host-built task list.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void eval_tiles_kernel(CholTilesArgs g, EvalTilesArgs x) {
+  __shared__ __attribute__((aligned(16))) double lds[ct_lds_doubles(NW)];
+  __shared__ int s_i[4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto draw_ticket = [&]() {  // (see chol_tiles_body: wave-uniform, every lane the same operands)
+    const unsigned old = atomicAdd(g.ctl, lane == 0 ? 1u : 0u);
+    s_i[0] = __builtin_amdgcn_readfirstlane((int)old);
+  };
+  if (wave == 0) draw_ticket();
+  __syncthreads();
+  for (;;) {
+    const int t = __builtin_amdgcn_readfirstlane(s_i[0]);
+    if (t >= x.ntasks) return;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(x.tasks[t]);
+    const uint32_t kind = w >> 30;
+    const int I = (int)((w >> 15) & 0x7fffu), J = (int)(w & 0x7fffu);
+    if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 0] = wall_clock64();
+    bool ok;
+    if (kind == ET_CHOL) {
+      if (I == J)
+        ok = ct_diag_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.logdet, (ct_g_i32*)g.info, (ct_g_u32*)g.flags,
+                              (ct_g_u32*)g.half, (ct_g_u32*)g.prog, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+      else
+        ok = ct_offdiag_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)g.logdet, (ct_g_i32*)g.info, (ct_g_u32*)g.flags,
+                                 (ct_g_u32*)g.half, (ct_g_u32*)g.prog, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds,
+                                 (ct_lds_int*)s_i);
+    } else if (kind == ET_INV) {
+      ok = et_inv_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)x.udiag, (ct_g_double*)x.apart, (ct_g_u32*)g.flags,
+                           (ct_g_u32*)x.uflags, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, x.yb, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+    } else {
+      ok = et_zz_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)x.udiag, (ct_g_double*)x.Z, x.ldz, (ct_g_u32*)x.uflags, (ct_g_u32*)g.ctl,
+                          (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
+    __syncthreads();  // every thread is done with s_i and the staging buffers of the task
+    if (wave == 0) draw_ticket();
+    __syncthreads();
+  }
+}
+
+// alpha_i = sum_{c >= r} apart[(r * nct + c) * 128 + i mod 128], r = i / 128, added in c order (same bits run to run)
+__global__ __launch_bounds__(128) void alpha_from_parts_kernel(const double* __restrict__ apart, int nct, int64_t n, double* __restrict__ alpha) {
+  const int r = blockIdx.x, i = threadIdx.x;
+  double s = 0.0;
+  for (int c = r; c < nct; ++c) s += apart[((int64_t)r * nct + c) * TILE + i];
+  const int64_t row = (int64_t)r * TILE + i;
+  if (row < n) alpha[row] = s;
+}
+
+// Host side: the task list.  `with_chol`: the factorisation's tile tasks are part of the launch (column c's tasks, then the
+// INV tasks of column c - lag); otherwise the factor is final and only INV / ZZ tasks are listed.  INV column c: r = 0 .. c
+// (longest contraction first); ZZ: block rows I ascending (longest first), J = 0 .. I inside.
+inline void et_build_tasks(int nct, int nrt, bool with_chol, int lag, std::vector<uint32_t>& out) {
+  out.clear();
+  auto inv_col = [&](int c) {
+    for (int r = 0; r <= c; ++r) out.push_back(et_pack(ET_INV, r, c));
+  };
+  int next_inv = 0;
+  if (with_chol) {
+    for (int c = 0; c < nct; ++c) {
+      for (int I = c; I < nrt; ++I) out.push_back(et_pack(ET_CHOL, I, c));
+      if (c - lag >= 0) {
+        inv_col(c - lag);
+        next_inv = c - lag + 1;
+      }
+    }
+  }
+  for (int c = next_inv; c < nct; ++c) inv_col(c);
+  for (int I = 0; I < nct; ++I)
+    for (int J = 0; J <= I; ++J) out.push_back(et_pack(ET_ZZ, I, J));
+}
+
+}  // namespace gmb

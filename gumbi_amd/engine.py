@@ -98,6 +98,9 @@ class Timings(C.Structure):
         ("total_chol_tile_ms", C.c_double),
         ("total_chol_tile_flops", C.c_double),
         ("total_chol_tile_launches", C.c_int64),
+        ("total_eval_tile_ms", C.c_double),
+        ("total_eval_tile_flops", C.c_double),
+        ("total_eval_tile_launches", C.c_int64),
     ]
 
     def as_dict(self):
@@ -249,6 +252,8 @@ _SIGNATURES = {
     "gmb_debug_chol_task": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gmb_chol_task_trace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "gmb_set_chol_scheme": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gmb_set_grad_scheme": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "gmb_debug_eval_tasks": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int64]),
     "gmb_debug_chol_lose_tickets": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gmb_blk_covariance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -291,8 +296,9 @@ def _preload_hip_runtime():
 #: ``gmb_kernel_spec`` changed with version 2: ``additive``; ``gmb_timings`` grew with version 3; version 4 replaced the block-level
 #: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``, ``gmb_set_y`` and ``gmb_create_sibling``;
 #: version 6 the communication fields of ``gmb_timings`` and ``gmb_rccl_comm_ranks``; version 7 ``gmb_evaluate``, the tile
-#: Cholesky's doors ``gmb_set_chol_scheme`` / ``gmb_chol_task_trace`` / ``gmb_debug_chol_*``)
-ABI_VERSION = 7
+#: Cholesky's doors ``gmb_set_chol_scheme`` / ``gmb_chol_task_trace`` / ``gmb_debug_chol_*``; version 8 the persistent evaluation
+#: launch: ``gmb_set_grad_scheme``, ``gmb_debug_eval_tasks``, ``total_eval_tile_*`` in ``gmb_timings``)
+ABI_VERSION = 8
 
 
 def load_library():
@@ -490,6 +496,17 @@ class Engine:
             self._check(prev, "gmb_set_chol_scheme")
         return prev - 1
 
+    #: schedules of the gradient's inverse / Sigma^-1 (``set_grad_scheme``)
+    GRAD_BY_SIZE, GRAD_LAUNCH_TREE, GRAD_TILES, GRAD_FUSED = -1, 0, 1, 2
+
+    def set_grad_scheme(self, scheme: int, lag: int = -1) -> int:
+        """Schedule of the gradient's inverse and Sigma^-1 for the following evaluations (``lag``: block columns the inverse
+        follows the factorisation by in the fused launch's ticket order); returns the previous setting."""
+        prev = int(self._lib.gmb_set_grad_scheme(self._h, int(scheme), int(lag)))
+        if prev < 0:
+            self._check(prev, "gmb_set_grad_scheme")
+        return prev - 1
+
     def debug_lose_tickets(self, n: int):
         """Fault injection (tests): the next tile factorisation never computes the tiles of tickets 0 .. n-1."""
         self._check(self._lib.gmb_debug_chol_lose_tickets(self._h, int(n)), "gmb_debug_chol_lose_tickets")
@@ -509,6 +526,25 @@ class Engine:
         tiles = np.array([chol_task(t, nct, nrt) for t in range(n)], dtype=np.int32)
         t0 = raw[raw > 0].min() if (raw > 0).any() else 0
         return tiles, (raw.astype(np.int64) - int(t0)) * 1e-8
+
+    def eval_task_trace(self, with_chol: bool = True, lag: int = -1):
+        """Per-task stamps of the last persistent EVALUATION launch (csrc/eval_tiles.hpp; switch them on with
+        ``chol_task_trace(1)``): ``(tasks, stamps)`` with ``tasks`` an (ntasks, 3) array of (kind, I, J) in ticket order and
+        ``stamps`` as in ``chol_task_trace``; ``None`` when nothing was recorded or the task count does not match."""
+        n = int(self._lib.gmb_chol_task_trace(self._h, -1, None, 0))
+        if n <= 0:
+            return None
+        nct = (self.N + 127) // 128
+        nrt = (self.N + 1 + 127) // 128
+        if lag < 0:
+            lag = max(2, min(24, nct // 4))  # the engine's default (csrc/engine.hip: eval_tiles)
+        tasks = np.array(eval_task_list(nct, nrt, with_chol, lag), dtype=np.int32)
+        if len(tasks) != n:
+            return None
+        raw = np.zeros((n, 4), dtype=np.uint64)
+        self._check(min(0, int(self._lib.gmb_chol_task_trace(self._h, -1, _ptr(raw), n))), "gmb_chol_task_trace")
+        t0 = raw[raw > 0].min() if (raw > 0).any() else 0
+        return tasks, (raw.astype(np.int64) - int(t0)) * 1e-8
 
     def copy_factor(self, r0=0, nr=None, c0=0, nc=None):
         nr = self.N if nr is None else nr
@@ -589,6 +625,18 @@ def chol_task(t: int, nct: int, nrt: int):
     if n < 0:
         raise ValueError("gmb_debug_chol_task: bad arguments")
     return i.value, j.value
+
+
+def eval_task_list(nct: int, nrt: int, with_chol: bool = True, lag: int = 1) -> list:
+    """[(kind, I, J), ...] of the persistent evaluation launch in ticket order (host-only; kind 0 = Cholesky tile,
+    1 = tile of U = L^-T, 2 = tile of Sigma^-1)."""
+    lib = load_library()
+    n = lib.gmb_debug_eval_tasks(int(nct), int(nrt), int(bool(with_chol)), int(lag), None, 0)
+    if n < 0:
+        raise ValueError("gmb_debug_eval_tasks: bad arguments")
+    buf = (C.c_uint32 * n)()
+    lib.gmb_debug_eval_tasks(int(nct), int(nrt), int(bool(with_chol)), int(lag), buf, n)
+    return [(w >> 30, (w >> 15) & 0x7FFF, w & 0x7FFF) for w in buf]
 
 
 def chol_task_count(nct: int, nrt: int) -> int:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 7
+#define GMB_ABI_VERSION 8
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -158,6 +158,12 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
   double total_chol_tile_ms;
   double total_chol_tile_flops;
   int64_t total_chol_tile_launches;
+  /* The persistent evaluation launch (csrc/eval_tiles.hpp: L^-T by rows and Sigma^-1 = U U^T as tile tasks -- in gmb_evaluate
+     together with the factorisation's own tile tasks, ONE launch for the matrix work of a MAP evaluation), cumulative:
+     launch durations, contraction flops (factorisation included when it rode along), launches. */
+  double total_eval_tile_ms;
+  double total_eval_tile_flops;
+  int64_t total_eval_tile_launches;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;
@@ -296,6 +302,18 @@ int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n);
  * look-ahead, 3 = persistent tile kernel.  Returns the previous setting PLUS ONE (0 = by size, 1 = recursion, 3, 4), so
  * that no valid answer collides with a negative gmb_status. */
 int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme);
+/* Schedule of the gradient's inverse and Sigma^-1 for the following evaluations: -1 = by size (default: tile tasks for the
+ * matrices the tile Cholesky factors, fused into the factorisation's launch by gmb_evaluate), 0 = the launch tree (recursive
+ * block inversion, GEMM launches), 1 = tile tasks in a launch of their own behind the factorisation, 2 = fused whenever the
+ * tile Cholesky runs.  `lag` >= 0: in the fused launch the inverse's tasks of block column c - lag follow the factorisation's
+ * tasks of column c in the ticket order (negative: keep the current value).  Returns the previous scheme plus one, or a
+ * negative gmb_status. */
+int gmb_set_grad_scheme(gmb_engine* e, int32_t scheme, int32_t lag);
+/* Host-only: the task list of the persistent evaluation launch for an nrt x nct block grid (csrc/eval_tiles.hpp):
+ * word = kind << 30 | I << 15 | J, kind 0 = Cholesky tile (I, J), 1 = tile (I, J) of U = L^-T, 2 = tile (I, J) of
+ * Sigma^-1; `with_chol` = the factorisation's tasks are part of the launch, `lag` = how many block columns the inverse
+ * follows the factorisation by.  Writes at most `cap` words, returns the number of tasks. */
+int64_t gmb_debug_eval_tasks(int32_t nct, int32_t nrt, int32_t with_chol, int32_t lag, uint32_t* out, int64_t cap);
 /* The covariance build alone: what gmb_factorize factors -- the lower-triangle 128 x 128 tiles of
  * Sigma = K + noise + jitter (pymc/GP.py:580), row N = y, identity padding -- written column-major into `out`
  * (device memory; ceil((N+1)/128)*128 rows x ceil(N/128)*128 columns, leading dimension ldo >= the row count).

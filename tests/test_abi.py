@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"\b(?:double|int64_t)\s+([a-z_0-9]+)\s*;", body)
     assert fields == [n for n, _ in engine.Timings._fields_]
-    assert engine.C.sizeof(engine.Timings) == 8 * len(fields) == 46 * 8
+    assert engine.C.sizeof(engine.Timings) == 8 * len(fields) == 49 * 8
     # gmb_comm {int32 rank, world; void* ctx; fn* all_gather} and gmb_dist_step {9 x int32, pad, int64}
     assert engine.C.sizeof(engine.GmbComm) == 24 and engine.C.sizeof(engine.DistStep) == 48
     spec = engine.KernelSpec(D=6, idx_cont=[0, 1, 2], idx_lin=[1], coreg=[(3, 4)], out_col=5, n_out=2)
@@ -185,4 +185,36 @@ def test_tile_cholesky_tickets_enumerate_every_tile_once_in_a_topological_order(
             deps += [(i, k) for k in range(j)] + [(j, k) for k in range(j)]
             assert all(pos[dep] < t for dep in deps)
     assert engine.chol_task(10 ** 6, 3, 4) == (-1, -1)
+
+
+def test_evaluation_task_list_is_a_topological_order_of_its_dependency_graph():
+    """The host-built ticket list of the persistent evaluation launch (csrc/eval_tiles.hpp, gmb_debug_eval_tasks): every Cholesky
+    tile, every tile of U = L^-T and every tile of Sigma^-1 exactly once, and every task AFTER the tasks it waits for -- a
+    task then only ever waits for smaller tickets, which are finished or held by a running workgroup: the launch cannot
+    deadlock whatever the residency of its workgroups.  With and without the factorisation's own tasks, several lags."""
+    from gumbi_amd import engine
+
+    CHOL, INV, ZZ = 0, 1, 2
+    for nct, nrt, lag in [(1, 1, 1), (1, 2, 0), (2, 2, 1), (3, 4, 5), (6, 6, 2), (20, 21, 5), (41, 41, 10), (79, 79, 19), (80, 81, 24)]:
+        for with_chol in (True, False):
+            tasks = engine.eval_task_list(nct, nrt, with_chol, lag)
+            pos = {t: i for i, t in enumerate(tasks)}
+            assert len(pos) == len(tasks)
+            n_tri = nct * (nct + 1) // 2
+            assert sum(1 for k, _, _ in tasks if k == INV) == n_tri and sum(1 for k, _, _ in tasks if k == ZZ) == n_tri
+            assert sum(1 for k, _, _ in tasks if k == CHOL) == (nct * nrt - nct * (nct - 1) // 2 if with_chol else 0)
+            assert all((k == CHOL and j <= i < nrt and j < nct) or (k == INV and i <= j < nct) or (k == ZZ and j <= i < nct) for k, i, j in tasks)
+            yb = nrt - 1 if nrt > nct else nct - 1  # the block row that holds row N
+            step = max(1, len(tasks) // 500)
+            for t in range(0, len(tasks), step):
+                k, i, j = tasks[t]
+                if k == CHOL:
+                    deps = ([(CHOL, j, j)] if i != j else []) + [(CHOL, i, q) for q in range(j)] + [(CHOL, j, q) for q in range(j)]
+                elif k == INV:  # tile (r, c) = (i, j): its own row up to c, block row c of L, the tile of column c with row N
+                    deps = [(INV, i, q) for q in range(i, j)]
+                    if with_chol:
+                        deps += [(CHOL, j, q) for q in range(j + 1)] + [(CHOL, yb, j)]
+                else:  # Sigma^-1 (I, J): rows I and J of U from column I on
+                    deps = [(INV, i, q) for q in range(i, nct)] + [(INV, j, q) for q in range(i, nct)]
+                assert all(pos[dep] < t for dep in deps), (nct, nrt, lag, with_chol, tasks[t])
 

@@ -160,6 +160,21 @@ def test_roofline_block_quotes_the_tile_kernel_when_the_factorisation_is_one_lau
     assert r["traffic_source"].startswith("profiles/") and r["traffic_is_stale"] == pt["stale"]
 
 
+def test_roofline_block_quotes_the_evaluation_launch_when_the_gradient_rides_with_the_factorisation():
+    """C2-class sizes under find_MAP: one persistent launch per evaluation (csrc/eval_tiles.hpp) is the roofline's kernel; the
+    same time also priced on the unpadded N^3."""
+    bench = load_bench()
+    tm = {"total_chol_gemm_flops": 0.0, "total_chol_gemm_ms": 0.0, "total_chol_gemm_launches": 0, "total_chol_gemm_wall_ms": 0.0,
+          "total_gemm_flops": 6.0e12, "total_gemm_ms": 100.0, "total_gemm_launches": 300, "total_gemm_wall_ms": 90.0,
+          "total_chol_panel_gemm_flops": 0.0, "total_chol_panel_gemm_ms": 0.0, "masked_gemm_flops": 0.0,
+          "total_chol_tile_ms": 7.0, "total_chol_tile_flops": 3.4e11, "total_chol_tile_launches": 1,
+          "total_eval_tile_ms": 64.0, "total_eval_tile_flops": 4.0 * 1.034e12, "total_eval_tile_launches": 4}
+    r = bench.roofline_block(tm, "c2")
+    assert "eval_tiles_kernel" in r["kernel"] and r["launches"] == 4 and abs(r["achieved"] - 4.0 * 1.034e12 / 64.0 / 1e9) < 1e-3
+    assert abs(r["achieved_on_unpadded_N3"] - 4.0e12 / 64.0 / 1e9) < 1e-3 and r["achieved_on_unpadded_N3"] < r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / bench.FP64_MFMA_PEAK_TFLOPS) < 1e-4 and "in_panel_products" not in r
+
+
 def test_tile_trace_summary_reads_the_chain_off_the_stamps():
     """summarize_tile_trace: chain step = distance between the publications of consecutive diagonal tiles; k-block time from
     the bulk tiles (I >= J + 2) of the columns with at least 8 k-blocks."""

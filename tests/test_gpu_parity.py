@@ -666,6 +666,100 @@ def test_tile_cholesky_gives_up_on_a_lost_tile_instead_of_hanging(gpu):
     eng.close()
 
 
+# ----------------------------------------------------------------------------------------------
+# persistent evaluation launch (csrc/eval_tiles.hpp): Cholesky + L^-T + Sigma^-1 as tile tasks of ONE launch
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,kind", [(130, "ExpQuad"), (1000, "Matern52"), (1024, "ExpQuad"), (2689, "Matern32"), (5200, "ExpQuad")])
+def test_evaluation_schedules_agree_with_each_other_and_the_oracle(gpu, N, kind):
+    """The gradient's inverse and Sigma^-1 as a tree of GEMM launches (scheme 0), as tile tasks behind the factorisation (1) and
+    fused into the factorisation's launch (2): NLML, gradient and alpha against the oracle and against each other; ragged
+    sizes and a size with a separate y block row (N % 128 == 0); the factor serves a prediction afterwards (L is left intact);
+    the tile schedules give the same bits whether the gradient rode with the factorisation or followed it."""
+    d = 3
+    X, y, ls = O.synthetic_table(N, d, seed=31)
+    spec = O.make_spec(d, range(d), kind=kind)
+    theta = O.pack_theta(spec, ls, 1.15, 0.22)
+    Xs = np.random.default_rng(2).standard_normal((150, d))
+    val_r, grad_r = O.nlml_and_grad(spec, theta, X, y)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+    L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
+    import scipy.linalg
+
+    alpha_r = scipy.linalg.solve_triangular(L_ref, v_ref, lower=True, trans="T")
+    eng = make_engine(spec, theta, X, y)
+    eng.set_chol_scheme(eng.CHOL_TILES)
+    got = {}
+    for scheme in (eng.GRAD_LAUNCH_TREE, eng.GRAD_TILES, eng.GRAD_FUSED):
+        eng.set_grad_scheme(scheme)
+        val, g = eng.evaluate(theta)
+        alpha = eng.copy_alpha()
+        assert eng.factor_is_current()
+        mu, var = eng.predict(Xs)
+        assert abs(val - val_r) < 1e-10 * max(1.0, abs(val_r)) and rel(g, grad_r) < 1e-8 and rel(alpha, alpha_r) < 1e-8
+        assert rel(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-9
+        got[scheme] = (val, g, alpha, mu, var)
+        if scheme != eng.GRAD_LAUNCH_TREE:  # the launch behind a factor that is final: same task bodies, same bits
+            eng.factorize()
+            val2, g2 = eng.nlml(grad=True)
+            assert np.float64(val2).tobytes() == np.float64(val).tobytes() and g2.tobytes() == g.tobytes()
+            assert eng.copy_alpha().tobytes() == alpha.tobytes()
+    a, b, c = (got[s] for s in (eng.GRAD_LAUNCH_TREE, eng.GRAD_TILES, eng.GRAD_FUSED))
+    assert rel(a[1], b[1]) < 1e-10 and b[1].tobytes() == c[1].tobytes() and b[2].tobytes() == c[2].tobytes()
+    assert b[3].tobytes() == c[3].tobytes() and b[4].tobytes() == c[4].tobytes()
+    eng.close()
+
+
+def test_fused_evaluation_is_bit_reproducible_and_survives_a_lost_tile(gpu):
+    """Whatever order the workgroups draw the tickets of the fused launch in, NLML / gradient / alpha come out with the same
+    bits (every tile written once, contractions in k order); with the first diagonal tile withheld the launch gives up after
+    its time-out (GumbiHipError), and the next evaluation is bit-identical to the ones before."""
+    import time
+
+    from gumbi_amd.engine import GumbiHipError
+
+    N, d = 3300, 4
+    X, y, ls = O.synthetic_table(N, d, seed=12)
+    spec = O.make_spec(d, range(d), kind="Matern52")
+    theta = O.pack_theta(spec, ls, 0.9, 0.3)
+    runs = []
+    for _ in range(2):
+        eng = make_engine(spec, theta, X, y)
+        for _ in range(3):
+            val, g = eng.evaluate(theta)
+            runs.append((np.float64(val).tobytes(), g.tobytes(), eng.copy_alpha().tobytes()))
+        eng.close()
+    assert all(r == runs[0] for r in runs[1:])
+    eng = make_engine(spec, theta, X, y)
+    eng.debug_lose_tickets(1)
+    t0 = time.time()
+    with pytest.raises(GumbiHipError, match="time-out"):
+        eng.evaluate(theta)
+    assert 1.0 < time.time() - t0 < 30.0
+    val, g = eng.evaluate(theta)
+    assert (np.float64(val).tobytes(), g.tobytes(), eng.copy_alpha().tobytes()) == runs[0]
+    eng.close()
+
+
+def test_composite_model_gradient_through_the_fused_launch(gpu):
+    """Linear x coregion x two outputs x heteroskedastic noise at a size the fused launch takes by itself: every partial of the
+    gradient (tables included) against the oracle -- the reductions read Sigma^-1 and alpha as the tile tasks left them."""
+    rng = np.random.default_rng(5)
+    n, d = 700, 2
+    Xc = rng.standard_normal((n, d))
+    cat = rng.integers(0, 3, size=n).astype(float)
+    X = np.vstack([np.column_stack([Xc, cat, np.zeros(n)]), np.column_stack([Xc, cat, np.ones(n)])])
+    y = np.sin(X[:, 0]) + 0.3 * X[:, 3] + 0.1 * rng.standard_normal(2 * n)
+    spec = golden_spec("composite_N140")  # the golden case's model (and its hyper-parameters) on a table ten times the size
+    theta = GOLD["composite_N140/theta"]
+    val_r, grad_r = O.nlml_and_grad(spec, theta, X, y)
+    eng = make_engine(spec, theta, X, y)
+    for scheme in (eng.GRAD_LAUNCH_TREE, eng.GRAD_FUSED):
+        eng.set_grad_scheme(scheme)
+        val, g = eng.evaluate(theta)
+        assert abs(val - val_r) < 1e-10 * max(1.0, abs(val_r)) and rel(g, grad_r) < 1e-8
+    eng.close()
+
+
 @pytest.mark.parametrize("N", [300, 3000])
 def test_fused_evaluation_equals_the_three_calls(gpu, N):
     """gmb_evaluate = gmb_set_theta + gmb_factorize + gmb_nlml with the gradient enqueued right behind the factorisation: the
