@@ -266,22 +266,154 @@ def cpu_baseline(cfg, target_seconds=20.0):
         Ns = nxt
         dt = run(Ns)
     flops = step_flops(Ns, len(Xs), 1)
-    cores = os.cpu_count() or 1
-    try:
-        from threadpoolctl import threadpool_info
-
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        pass
+    cores, blas = host_blas()
     return {
         "value": round(flops / dt / 1e9, 2),
         "unit": "GFLOP/s",
         "cores": int(cores),
+        "blas": blas,
         "kind": "port",
         "sample": f"1 MAP objective+gradient evaluation + predict(M={len(Xs)}) at N={Ns}, d={d}, {cfg['kernel']} "
                   f"(numpy/LAPACK oracle, {dt:.1f} s)",
         "seconds": round(dt, 2),
     }
+
+
+def host_blas():
+    """(threads, "vendor version (threading layer)") of the BLAS numpy / scipy call on this host."""
+    cores, blas = os.cpu_count() or 1, "unknown"
+    try:
+        from threadpoolctl import threadpool_info
+
+        pools = [p for p in threadpool_info() if p.get("user_api") == "blas"] or threadpool_info()
+        cores = max([p.get("num_threads", 1) for p in pools] + [1])
+        if pools:
+            p = pools[0]
+            blas = f"{p.get('internal_api', '?')} {p.get('version', '?')} ({p.get('threading_layer', '?')}, {p.get('architecture', '?')})"
+    except Exception:
+        pass
+    return cores, blas
+
+
+def cpu_config_size_sections(budget, gpu_c2=None):
+    """The host beside the GPU at the CONFIG's own sizes, each only while the time budget lasts:
+
+    c2  -- the oracle behind the SAME host code (HipGP.find_MAP / predict with tests/oracle_engine.OracleEngine standing in
+           for the HIP engine: same priors, same L-BFGS-B, same declaration): one objective + gradient evaluation and one
+           grid prediction at N = 10k always (~12 s); the whole fit to convergence + prediction in a SUBPROCESS when ~6
+           minutes are left (the evaluation count is then the optimiser's own), otherwise evaluations x seconds as an
+           estimate, labelled as one;
+    c3  -- LAPACK dpotrf alone on a 50,000 x 50,000 SPD matrix (20 GB; the factorisation of ONE of the fit's ~30
+           evaluations);
+    c5  -- N = 100k: never run, the N^3 extrapolation of the c3 figure, labelled as one."""
+    import subprocess
+
+    out = {}
+    cfg = CONFIGS["c2"]
+    est_eval = 25.0
+    if budget.allows(est_eval):
+        one = cpu_baseline(cfg, target_seconds=1e9)  # (target beyond reach: grows straight to the full N)
+        out["c2_one_evaluation_plus_predict_seconds"] = one["seconds"]
+        out["c2_sample"] = one["sample"]
+        n_eval = int(gpu_c2["n_eval"]) if gpu_c2 and gpu_c2.get("n_eval") else 29
+        est_fit = 1.1 * n_eval * one["seconds"] + 30.0
+        out["c2_seconds_estimate"] = round(n_eval * one["seconds"], 1)
+        out["c2_seconds_estimate_note"] = f"{n_eval} evaluations (the GPU fit's count) x the measured evaluation; NOT a measured fit"
+        if budget.allows(est_fit):
+            try:
+                r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-fit", "c2"], cwd=str(ROOT), capture_output=True, text=True,
+                                   timeout=est_fit * 1.5 + 60.0, env=dict(os.environ, GUMBI_BENCH_NO_CPU="1"))
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode == 0 and line:
+                    fit = json.loads(line[-1])
+                    out["c2_seconds"] = fit["fit_predict_seconds"]
+                    out["c2_fit"] = fit
+                else:
+                    out["c2_seconds"] = None
+                    out["c2_fit"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as err:  # noqa: BLE001
+                out["c2_seconds"] = None
+                out["c2_fit"] = {"error": f"{type(err).__name__}: {err}"[:300]}
+        else:
+            out["c2_seconds"] = None
+            out["c2_fit"] = budget.skipped(est_fit)
+    else:
+        out["c2_seconds"] = None
+        out["c2_fit"] = budget.skipped(est_eval)
+    est_c3 = 150.0
+    if budget.allows(est_c3):
+        try:
+            out.update(cpu_dpotrf_seconds(CONFIGS["c3"]["N"]))
+        except Exception as err:  # noqa: BLE001
+            out["c3_cholesky_seconds"] = None
+            out["c3_cholesky"] = {"error": f"{type(err).__name__}: {err}"[:300]}
+    else:
+        out["c3_cholesky_seconds"] = None
+        out["c3_cholesky"] = budget.skipped(est_c3)
+    if out.get("c3_cholesky_seconds"):
+        out["c5_cholesky_seconds_extrapolated"] = round(out["c3_cholesky_seconds"] * (CONFIGS["c5"]["N"] / CONFIGS["c3"]["N"]) ** 3, 1)
+        out["c5_note"] = "N = 100k is not run on the host: c3's dpotrf time x (100k / 50k)^3, an extrapolation (BASELINE.md section 3)"
+    return out
+
+
+def cpu_dpotrf_seconds(N):
+    """LAPACK dpotrf (scipy.linalg.cholesky, in place, all BLAS threads) on an N x N SPD matrix -- what PyTensor's Cholesky op
+    dispatches to once per objective evaluation.  The values do not matter for the time; the matrix is N I + 0.5."""
+    import scipy.linalg
+
+    need = 8.0 * N * N * 1.15
+    try:
+        import psutil
+
+        avail = float(psutil.virtual_memory().available)
+    except Exception:
+        avail = need * 2
+    if avail < need * 1.3:
+        return {"c3_cholesky_seconds": None, "c3_cholesky": {"skipped": f"host memory: {avail / 1e9:.0f} GB available, {need / 1e9:.0f} GB needed"}}
+    W = np.full((2048, 2048), 0.5, order="F")  # wake the BLAS threads up first
+    W[np.diag_indices(2048)] += 2048.0
+    scipy.linalg.cholesky(W, lower=True, overwrite_a=True, check_finite=False)
+    A = np.full((N, N), 0.5, order="F")
+    A[np.diag_indices(N)] += float(N)
+    t0 = time.perf_counter()
+    scipy.linalg.cholesky(A, lower=True, overwrite_a=True, check_finite=False)
+    dt = time.perf_counter() - t0
+    del A
+    cores, blas = host_blas()
+    return {"c3_cholesky_seconds": round(dt, 2),
+            "c3_cholesky": {"N": N, "gflops": round(N**3 / 3.0 / dt / 1e9, 1), "cores": cores, "blas": blas,
+                            "what": f"scipy.linalg.cholesky(lower=True, overwrite_a=True) = LAPACK dpotrf on a {8.0 * N * N / 1e9:.1f} GB SPD matrix, once"}}
+
+
+def cpu_fit_subprocess(config_name):
+    """``python bench.py --cpu-fit c2``: the whole step -- fit to convergence + grid prediction -- of the config on the HOST: the
+    product's host code (HipGP: priors, L-BFGS-B, declaration with ls_bounds) with the numpy / LAPACK oracle standing in for
+    the HIP engine (tests/oracle_engine.py).  Runs in a process of its own so that nothing of the stand-in can leak into the
+    measured GPU path; prints one JSON line."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from oracle_engine import OracleEngine
+
+    import gumbi_amd as gmb
+    from gumbi_amd.regression import hip_gp
+
+    hip_gp.Engine = OracleEngine
+    cfg = CONFIGS[config_name]
+    t0 = time.perf_counter()
+    ds, cols = make_dataset(cfg)
+    gp = gmb.GP(ds, outputs=["y"], device=0)
+    gp.fit(continuous_dims=cols, continuous_kernel=cfg["kernel"], ls_bounds=ls_bounds_for(ds, cols, LS_LOWER_Z), MAP_kwargs={"maxeval": 200})
+    t_fit = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    if cfg["d"] > 2:
+        gp.prepare_grid(at=gp.parray(**{c: 0.0 for c in cols[2:]}, stdzd=True), resolution=cfg["res"])
+    else:
+        gp.prepare_grid(resolution=cfg["res"])
+    gp.predict_grid()
+    t_pred = time.perf_counter() - t1
+    cores, blas = host_blas()
+    print(json.dumps({"fit_predict_seconds": round(t_fit + t_pred, 2), "fit_seconds": round(t_fit, 2), "predict_seconds": round(t_pred, 2),
+                      "n_eval": int(gp.n_eval), "nlml_final": round(float(gp.nlml_trace[-1]), 3), "cores": cores, "blas": blas,
+                      "what": "HipGP host code over the numpy/LAPACK oracle (tests/oracle_engine.py), same declaration as the GPU fit"}), flush=True)
 
 
 def tile_chain_summary(eng):
@@ -585,10 +717,11 @@ def c2_side_section(local_rank, clock):
     ph = res["phases"]
     return {
         "workload": cfg["label"],
-        "ms_per_step": round(1e3 * elapsed, 3), "map_evals": res["n_evals"], "value": round(res["flops"] / elapsed / 1e9, 2),
-        "unit": "GFLOP/s", "fit_quality": {k: res["quality"][k] for k in ("corr", "sigma_rel_err", "converged") if k in res["quality"]},
+        "ms_per_step": round(1e3 * elapsed, 3), "fit_predict_seconds": round(elapsed, 4), "map_evals": res["n_evals"],
+        "value": round(res["flops"] / elapsed / 1e9, 2),
+        "unit": "GFLOP/s", "fit_quality": {k: res["quality"][k] for k in ("corr", "sigma_rel_err", "converged", "n_eval") if k in res["quality"]},
         "phases": {k: ph[k] for k in ("factorize_ms", "factorize_plus_gradient_ms", "predict_ms", "rates_tflops", "tile_cholesky") if k in ph},
-        "factorisation_roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "frac", "launches", "avg_launch_ms", "traffic", "traffic_source", "traffic_is_stale") if k in r},
+        "factorisation_roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "frac", "achieved_on_unpadded_N3", "frac_on_unpadded_N3", "launches", "avg_launch_ms", "traffic", "traffic_source", "traffic_is_stale") if k in r},
     }
 
 
@@ -815,7 +948,12 @@ def main():
                     help="one GPU: cap on L-BFGS objective evaluations per fit (0 = run to convergence, cap 200); c5 / several "
                          "GPUs: 0 = fixed hyper-parameters, k > 0 = a (distributed) find_MAP(maxeval=k) per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-fit", default=None, choices=["c1", "c2"],
+                    help="internal (cpu_baseline): the config's whole step on the HOST -- HipGP's host code over the numpy/LAPACK oracle")
     args = ap.parse_args()
+    if args.cpu_fit:
+        cpu_fit_subprocess(args.cpu_fit)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -916,6 +1054,11 @@ def main():
                 out["config"]["warmup_step"] = f"same code path, evaluation budget {WARMUP_EVALS} (untimed)"
                 out["fit_quality"] = res["quality"]
                 out["seconds_per_map_evaluation"] = round(elapsed / max(sum(res["n_evals"]), 1), 4)
+            if config_name == "c5":
+                out["config"]["step"] = (f"a distributed find_MAP(maxeval={args.map_evals}) + grid prediction" if args.map_evals > 0 else
+                                         "ONE MAP objective + gradient evaluation + fit at fixed theta (re-factorisation) + grid prediction")
+                out["config"]["not_like_for_like_with"] = ("the one-GPU default line (config c3: a MAP fit to convergence at N = 50k); the one-GPU "
+                                                           "point of THIS curve is strong_scaling_base_gflops / `python bench.py --config c5`")
             if res.get("comm") is not None:
                 out["comm"] = res["comm"]
                 out["transport"], out["rccl_ranks"] = res["comm"]["transport"], res["comm"]["rccl_ranks"]
@@ -971,6 +1114,17 @@ def main():
                     out["end_to_end"] = {"error": f"{type(err).__name__}: {err}"[:300]}
             else:
                 out["end_to_end"] = budget.skipped(est)
+        if "cpu_baseline" in out and os.environ.get("GUMBI_BENCH_NO_CPU_CONFIG_SIZE") != "1":
+            # the host at the configs' own sizes (lowest priority: minutes of host time), beside fit_predict_seconds
+            gpu_c2 = out.get("fit_quality") if config_name == "c2" else (out.get("c2_single_gpu") or {}).get("fit_quality")
+            try:
+                out["cpu_baseline"].update(cpu_config_size_sections(budget, gpu_c2))
+            except Exception as err:  # noqa: BLE001
+                out["cpu_baseline"]["config_size_error"] = f"{type(err).__name__}: {err}"[:300]
+            gpu_c2_s = out.get("fit_predict_seconds") if config_name == "c2" else (out.get("c2_single_gpu") or {}).get("fit_predict_seconds")
+            out["cpu_baseline"]["gpu_c2_fit_predict_seconds"] = gpu_c2_s
+            if config_name == "c3":
+                out["cpu_baseline"]["gpu_c3_cholesky_seconds"] = round(out["phases"].get("factorize_ms", 0.0) / 1e3, 4) or None
     # several GPUs: the same step on ONE GPU of this node, by rank 0 (the other ranks wait at the final barrier)
     if world > 1 and out is not None and "error" not in out and healthy and os.environ.get("GUMBI_BENCH_NO_BASE") != "1":
         base, _ = run_with_deadline(lambda: c5_on_one_gpu(1, 1), 500.0)

@@ -142,8 +142,16 @@ struct DistProbe {
   int group = -1;
 };
 
+// one more collective in this engine's issue log (see gmb_engine::coll_hash; 52 bits, so that it travels exactly in a double)
+void dist_log_collective(gmb_engine* e, int64_t count, hipStream_t st) {
+  const uint64_t tag = st == e->stream ? 0u : st == e->aux[0] ? 1u : 2u;
+  e->coll_count += 1;
+  e->coll_hash = (e->coll_hash * 1099511628211ull + (uint64_t)count * 4u + tag + 1u) & ((1ull << 52) - 1);
+}
+
 int dist_all_gather(gmb_engine* e, const gmb_comm* comm, hipStream_t st, const double* send, double* recv, int64_t count,
                     DistProbe* probe = nullptr, bool exposed = false) {
+  dist_log_collective(e, count, st);
   DistProbe::Coll c{};
   if (probe) {
     c.a = next_time_event(e);
@@ -213,12 +221,15 @@ int dist_agree(gmb_engine* e, const gmb_comm* comm, int mine, const char* where,
                int npayload = 0, int64_t* repairs = nullptr) {
   if (comm->world == 1) return mine;
   if (npayload > DIST_MAX_PAYLOAD) npayload = DIST_MAX_PAYLOAD;
-  const int w = 1 + npayload;  // words per rank: [status | payload]
+  const int w = DIST_HEADER + npayload;  // words per rank: [status | collectives issued | hash of their sequence | payload]
   std::vector<double> mineb((size_t)w), all((size_t)w * comm->world);
   mineb[0] = (double)mine;
-  for (int i = 0; i < npayload; ++i) mineb[1 + i] = payload[i];
+  mineb[1] = (double)e->coll_count;
+  mineb[2] = (double)e->coll_hash;
+  for (int i = 0; i < npayload; ++i) mineb[DIST_HEADER + i] = payload[i];
+  dist_log_collective(e, w, e->stream);  // (this exchange itself: the same on every rank)
   double* dsend = e->dstat;
-  double* drecv = e->dstat + (1 + DIST_MAX_PAYLOAD);
+  double* drecv = e->dstat + (DIST_HEADER + DIST_MAX_PAYLOAD);
   hipError_t st = hipMemcpyAsync(dsend, mineb.data(), w * sizeof(double), hipMemcpyHostToDevice, e->stream);
   if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
   int32_t tr = comm->all_gather(comm->ctx, dsend, drecv, w, (void*)e->stream);
@@ -238,11 +249,16 @@ int dist_agree(gmb_engine* e, const gmb_comm* comm, int mine, const char* where,
       return fail(e, code, "%s: rank %d of %d failed with status %d; no rank has a usable result", where, q, comm->world,
                   code);
     }
+  // every rank must have issued the same collectives in the same order on this transport (RCCL pairs them by issue order)
+  for (int q = 1; q < comm->world; ++q)
+    if (all[(size_t)q * w + 1] != all[1] || all[(size_t)q * w + 2] != all[2])
+      return fail(e, GMB_EHIP, "%s: rank %d issued a different sequence of collectives than rank 0 (%.0f vs %.0f calls, hash %.0f vs %.0f): "
+                  "the ranks' calls on this engine have diverged", where, q, all[(size_t)q * w + 1], all[1], all[(size_t)q * w + 2], all[2]);
   if (npayload > 0) {
     int64_t differ = 0;
     for (int q = 1; q < comm->world; ++q)
-      if (std::memcmp(&all[(size_t)q * w + 1], &all[1], npayload * sizeof(double)) != 0) ++differ;
-    for (int i = 0; i < npayload; ++i) payload[i] = all[1 + i];
+      if (std::memcmp(&all[(size_t)q * w + DIST_HEADER], &all[DIST_HEADER], npayload * sizeof(double)) != 0) ++differ;
+    for (int i = 0; i < npayload; ++i) payload[i] = all[DIST_HEADER + i];
     if (repairs) *repairs += differ;
   }
   return GMB_OK;
@@ -279,6 +295,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
     for (const gmb_dist_step& s : plan) need = std::max(need, s.elems);
     if (!(rc = ensure(e, &e->dsend, &e->cap_send, need))) rc = ensure(e, &e->drecv, &e->cap_recv, need * G);
   }
+  e->coll_count = e->coll_hash = 0;  // the issue log covers this call: its closing agreement compares the ranks' sequences
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_factorize (set-up)"))) return rc;
   e->factored = false;
   e->factor_consumed = false;
@@ -503,6 +520,7 @@ int dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
   if (!rc) rc = grad_workspace(e);
   if (!rc) rc = ensure(e, &e->dsend, &e->cap_send, send_need);
   if (!rc) rc = ensure(e, &e->drecv, &e->cap_recv, send_need * G);
+  e->coll_count = e->coll_hash = 0;  // the issue log covers this call: its closing agreement compares the ranks' sequences
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_nlml (set-up)"))) return rc;
   *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
   gmb_timings& tm = e->tm;
@@ -634,6 +652,7 @@ int dist_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t 
   const int64_t stage = std::max<int64_t>(std::max<int64_t>(2 * width, width * std::max(e->D, 1)), 1);
   if (!rc) rc = ensure(e, &e->dsend, &e->cap_send, stage);
   if (!rc) rc = ensure(e, &e->drecv, &e->cap_recv, stage * G);
+  e->coll_count = e->coll_hash = 0;  // the issue log covers this call: its closing agreement compares the ranks' sequences
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_predict (set-up)"))) return rc;
   if (M == 0) return GMB_OK;  // the same M on every rank by contract
   DistDeferred bad;

@@ -42,6 +42,7 @@ namespace {
 
 constexpr int DIST_MAX_WORLD = 64;   // ranks one GP can be spread over (status words of gmb_dist_*)
 constexpr int DIST_MAX_PAYLOAD = 7;  // scalars that travel with a status word (dist_agree)
+constexpr int DIST_HEADER = 3;       // words in front of them: status | collectives issued so far | hash of their sequence
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -227,6 +228,11 @@ struct gmb_engine {
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
   double* dstat = nullptr;  // status words (+ payload) the ranks exchange: this rank's, then everybody's (dist_agree)
+  // Every collective this engine has issued on a transport, in host issue order: count and a running hash of (element count,
+  // stream).  RCCL matches the collectives of a communicator by ISSUE ORDER on every rank -- and gmb_dist_nlml issues them on
+  // two streams -- so the ranks compare these two words whenever they agree on a status: a rank that issued a different
+  // sequence is reported instead of silently pairing the wrong buffers.
+  uint64_t coll_count = 0, coll_hash = 0;
   std::vector<hipEvent_t> time_pool;  // timing events of the multi-GPU driver's communication probes
   size_t time_next = 0;
 };
@@ -1878,7 +1884,7 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->wg_slots = 2LL * prop.multiProcessorCount;
   if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&e->dstat, (size_t)(1 + DIST_MAX_PAYLOAD) * (1 + DIST_MAX_WORLD) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&e->dstat, (size_t)(DIST_HEADER + DIST_MAX_PAYLOAD) * (1 + DIST_MAX_WORLD) * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
     gmb_destroy(e);
     return GMB_ENOMEM;
