@@ -672,15 +672,14 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
             best = min(best, time.perf_counter() - t_)
         return round(1e3 * best, 3)
 
-    def fact_then_grad():
-        eng.factorize()
-        eng.nlml(grad=True)
+    def fact_then_grad():  # what find_MAP calls per evaluation: ONE C call (gmb_evaluate), for <= 224 block columns ONE tile launch
+        eng.evaluate(theta_fit)
 
     eng.set_theta(theta_fit)
     phases = {
         "specify_plus_build_model_s": round(t_build, 3),  # DataSet -> specify_model -> build_model (ls priors, H2D copy)
         "factorize_ms": wall_ms(eng.factorize),          # K-build + Cholesky + L^-1 y + log-det
-        "factorize_plus_gradient_ms": wall_ms(fact_then_grad),  # one MAP objective evaluation
+        "factorize_plus_gradient_ms": wall_ms(fact_then_grad, reps=3),  # one MAP objective evaluation (gmb_evaluate)
     }
     eng.factorize()
     phases["predict_ms"] = wall_ms(lambda: eng.predict_device(xs_dev.data_ptr(), M, cfg["d"], mean_dev.data_ptr(),

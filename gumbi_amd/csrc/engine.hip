@@ -211,6 +211,7 @@ struct gmb_engine {
   double* dApart = nullptr;    // partial products U(r,c) v_c
   int64_t cap_apart = 0;
   bool et_fused = false;       // the factorisation in flight carries INV / ZZ tasks: Sigma^-1 (dW) and the alpha parts come with it
+  int et_min_blocks = 2;       // smallest matrix (in 128-blocks) whose MAP evaluation runs as the fused launch by default
   int tiles_min_blocks = 6, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default (measured faster from N = 768 on)
   int tiles_trsm_min_blocks = 16;                    // ... and the tile triangular solve of the predict path (measured from N = 2560 on)
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
@@ -1406,15 +1407,30 @@ int winv_level_batched(gmb_engine* e, const gmb_engine::InvLevelPlan& lp) {
 }
 
 template <int KIND>
-int launch_grad_nc(gmb_engine* e, const GradArgs& a, int nblocks) {
+int launch_grad_nc(gmb_engine* e, const GradArgs& a_in, int nblocks) {
   const dim3 grid(nblocks), block(256);
-  const size_t lds = grad_lds_bytes(e->nc_pad, a.p.n_lin, a.p.n_tab);
+  const size_t lds = grad_lds_bytes(e->nc_pad, a_in.p.n_lin, a_in.p.n_tab);
+  GradArgs a = a_in;
+  a.part_block0 = 0;
+  const dim3 grid0(a.split ? a.general_tiles : nblocks);  // (split: one tile of the general-tile list per workgroup)
   switch (e->nc_pad) {
-    case 1: hipLaunchKernelGGL((grad_tile_kernel<KIND, 1>), grid, block, lds, e->stream, a); break;
-    case 2: hipLaunchKernelGGL((grad_tile_kernel<KIND, 2>), grid, block, lds, e->stream, a); break;
-    case 4: hipLaunchKernelGGL((grad_tile_kernel<KIND, 4>), grid, block, lds, e->stream, a); break;
-    case 8: hipLaunchKernelGGL((grad_tile_kernel<KIND, 8>), grid, block, lds, e->stream, a); break;
-    default: hipLaunchKernelGGL((grad_tile_kernel<KIND, 16>), grid, block, lds, e->stream, a); break;
+    case 1: hipLaunchKernelGGL((grad_tile_kernel<KIND, 1>), grid0, block, lds, e->stream, a); break;
+    case 2: hipLaunchKernelGGL((grad_tile_kernel<KIND, 2>), grid0, block, lds, e->stream, a); break;
+    case 4: hipLaunchKernelGGL((grad_tile_kernel<KIND, 4>), grid0, block, lds, e->stream, a); break;
+    case 8: hipLaunchKernelGGL((grad_tile_kernel<KIND, 8>), grid0, block, lds, e->stream, a); break;
+    default: hipLaunchKernelGGL((grad_tile_kernel<KIND, 16>), grid0, block, lds, e->stream, a); break;
+  }
+  if constexpr (KIND <= 2) {
+    if (a.split) {  // the interior tiles on the matrix pipe: runs of the full enumeration, the partial vectors behind the first set
+      a.part_block0 = a.general_tiles;
+      switch (e->nc_pad) {
+        case 1: hipLaunchKernelGGL((grad_interior_kernel<KIND, 1>), grid, block, 0, e->stream, a); break;
+        case 2: hipLaunchKernelGGL((grad_interior_kernel<KIND, 2>), grid, block, 0, e->stream, a); break;
+        case 4: hipLaunchKernelGGL((grad_interior_kernel<KIND, 4>), grid, block, 0, e->stream, a); break;
+        case 8: hipLaunchKernelGGL((grad_interior_kernel<KIND, 8>), grid, block, 0, e->stream, a); break;
+        default: hipLaunchKernelGGL((grad_interior_kernel<KIND, 16>), grid, block, 0, e->stream, a); break;
+      }
+    }
   }
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
@@ -1511,8 +1527,18 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
       if (tr.cp.tab_levels[j] > 8) big += LL;
     }
     a.big_stride = big;
+    // smooth stationary terms: the full tiles strictly below the diagonal go to grad_interior_kernel (gradient.hpp)
+    a.split = (tr.cp.kind == GMB_EXPQUAD || tr.cp.kind == GMB_MATERN52 || tr.cp.kind == GMB_MATERN32) && tr.cp.n_lin == 0 &&
+                      tr.cp.n_tab == 0 && !e->naive_leaf
+                  ? 1 : 0;
+    // the tiles the interior launch leaves: the diagonal tile of every owned block row + a ragged last row's other tiles
+    a.n_owned_rows = shard < nt ? (nt - shard + nshards - 1) / nshards : 0;
+    const bool last_ragged_owned = e->Np > e->N && (nt - 1 - shard) % nshards == 0 && nt - 1 >= shard;
+    a.general_tiles = a.n_owned_rows + (last_ragged_owned ? nt - 1 : 0);
+    if (a.general_tiles == 0) a.split = 0;
+    const int nvec = a.split ? a.general_tiles + grid : grid;  // partial vectors the pass leaves
     if (grid > 0) {
-      if ((rc = ensure(e, &e->dgred, &e->cap_gred, (int64_t)grid * a.part_stride))) return rc;
+      if ((rc = ensure(e, &e->dgred, &e->cap_gred, (int64_t)nvec * a.part_stride))) return rc;
       a.part = e->dgred;
       if (big > 0) {
         if ((rc = ensure(e, &e->dgbig, &e->cap_gbig, (int64_t)grid * 4 * big))) return rc;
@@ -1541,7 +1567,7 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
       add(ncp, 2 + tr.cp.n_lin, n_ls);                        // eta | tau | c..
       for (int j = 0; j < tr.cp.n_tab; ++j)
         if (tr.cp.tab_levels[j] <= 8) add(n_small + j * 64, tr.cp.tab_levels[j] * tr.cp.tab_levels[j], tab_acc_off[j]);
-      hipLaunchKernelGGL(grad_sum_partials_kernel, dim3(a.part_stride), dim3(256), 0, e->stream, e->dgred, grid,
+      hipLaunchKernelGGL(grad_sum_partials_kernel, dim3(a.part_stride), dim3(256), 0, e->stream, e->dgred, nvec,
                          (int64_t)a.part_stride, r, acc);
       if (!s.ard) hipLaunchKernelGGL(grad_fold_ls_kernel, dim3(1), dim3(64), 0, e->stream, acc, s.n_cont, tmp);
       if (big > 0) {
@@ -2120,7 +2146,11 @@ int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
   e->ct_traced = false;
   e->cur = e->stream;
   e->et_fused = false;
-  if (tiles && with_grad && grad_by_tiles(e) && e->grad_scheme != 1) {
+  // the fused evaluation launch pays from two block columns on (N = 200: 0.32 -> 0.30 ms per evaluation, N = 392: 0.50 -> 0.39,
+  // N = 640: 0.58 -> 0.42; tools/gpu_small_eval.py), the tile Cholesky on its own only from six
+  const bool fused = with_grad && !e->naive_leaf && (e->chol_scheme == 3 || e->chol_scheme < 0) && e->grad_scheme != 0 && e->grad_scheme != 1 &&
+                     nblocks <= e->tiles_max_blocks && (e->grad_scheme == 2 ? nblocks >= 1 : nblocks >= e->et_min_blocks);
+  if (fused) {
     // the gradient's inverse and Sigma^-1 ride in the factorisation's launch (eval_tiles.hpp)
     if ((rc = eval_tiles(e, true))) return rc;
     e->et_fused = true;

@@ -52,6 +52,11 @@ struct GradArgs {
   int32_t row_first, row_stride;
   // z_packed: Z holds ONLY the owned block rows, packed (row block t of Z = block row row_first + t*row_stride)
   int32_t z_packed;
+  // split: the interior tiles (full tiles strictly below the diagonal) are grad_interior_kernel's, the rest grad_tile_kernel's;
+  // part_block0: first partial vector of this launch (the two launches of a split pass write grid vectors each)
+  int32_t split, part_block0;
+  int32_t n_owned_rows;  // split, MODE 0: block rows of this shard (its diagonal tiles lead the general-tile list)
+  int32_t general_tiles; // ... and the length of that list = grid of the MODE 0 launch
 };
 
 constexpr int GRAD_SMALL = 16 + 2 + MAX_LIN;                 // ls.. | eta | tau | c..
@@ -62,8 +67,275 @@ inline size_t grad_lds_bytes(int nc, int n_lin, int n_tab) {
          sizeof(int32_t) * 2 * (size_t)n_tab * TILE;
 }
 
+// ---- interior tiles: the per-dimension sums on the matrix pipe --------------------------------------------------
+// For a full 128 x 128 tile strictly below the diagonal of a stationary model every entry stands for (i,j) and (j,i):
+//     g_eta   += mm_ij * 2 eta k_ij,                       mm = Sigma^-1_ij - alpha_i alpha_j  (= 2 M_ij)
+//     g_ls[k] += -2/ls_k * mm_ij eta^2 k'_ij * ((x_ik - x_jk)/ls_k)^2
+// The round-3 loop spent ~83 double-precision instructions per entry on this (differences, squares and two multiply-adds per
+// dimension, at 233 registers and two waves per SIMD): 6.9 ms for the 10 GB of C3's Sigma^-1, 0.18 of the HBM roofline.
+// Here, as in cov_interior_tile, r^2 comes off the matrix pipe (PyMC's own expansion |x|^2 + |x'|^2 - 2 x.x'), ONE value
+//     G_ij = mm_ij eta^2 k'(r^2_ij)
+// is formed per entry, and the per-dimension sums are taken apart as
+//     sum_ij G_ij (x_ik - x_jk)^2 = sum_i [ x_ik^2 R_i - 2 x_ik P_ik + S_ik ],
+//     R_i = sum_j G_ij,   P_ik = sum_j G_ij x_jk,   S_ik = sum_j G_ij x_jk^2:
+// P and S are a skinny product G . [X | X^2] -- the G values sit in the accumulator layout of the r^2 contraction, which IS
+// the B-operand layout of v_mfma_f64_16x16x4_f64 with the column index as contraction index, so four MFMAs per 16 x 16
+// entries (one per accumulator register, A operand = the 2 NC features of four column points) add them into an accumulator
+// that belongs to the wave's 32 ROWS and stays in registers along the whole tile row; R is one add per entry.  The rows'
+// own coordinates enter once per tile row (grad_rows_flush).  ~60 issue-slot equivalents per entry for Matern-5/2, d = 8.
+// The expansion carries ~eps |x/ls|^2 of absolute rounding per term (as the covariance build's interior tiles do).
+template <int KIND>
+__device__ __forceinline__ void stationary_pair_interior(const double q, const double eta2, double& ks, double& dk) {
+  if constexpr (KIND == 0) {  // q = -r^2 / 2
+    const double e = eta2 * exp_interior(fmin(q, 0.0));
+    ks = e;
+    dk = -0.5 * e;
+  } else {
+    const double p = fmax(q, 1e-12);  // q = r^2 + 1e-12 (see stationary_interior)
+    const double r = sqrt_interior(p);
+    if constexpr (KIND == 1) {
+      const double s5 = 2.23606797749978969641;
+      const double e = exp_interior(-s5 * r);
+      const double lin = fma(eta2 * s5, r, eta2);  // eta^2 (1 + sqrt5 r)
+      ks = fma(eta2 * (5.0 / 3.0), p, lin) * e;
+      dk = (-5.0 / 6.0) * lin * e;
+    } else {
+      const double s3 = 1.73205080756887729353;
+      const double e = eta2 * exp_interior(-s3 * r);
+      ks = fma(s3, r, 1.0) * e;
+      dk = -1.5 * e;
+    }
+  }
+}
+
+template <int NC>
+struct GradRowAcc {  // what a wave has summed for its 32 rows since the last flush
+  static constexpr int ND = (2 * NC + 15) / 16;  // accumulators of 16 features x 16 rows
+  d4 D[2][ND];
+  double R[2];
+};
+
+template <int NC>
+__device__ __forceinline__ void grad_rows_reset(GradRowAcc<NC>& s) {
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    s.R[ib] = 0.0;
+#pragma unroll
+    for (int n = 0; n < GradRowAcc<NC>::ND; ++n) s.D[ib][n] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+}
+
+// the rows' side of the sums: g[k] += x_ik^2 R_i - 2 x_ik P_ik + S_ik for this lane's pieces (feature kq + 4 r of row slot r16)
+template <int NC>
+__device__ __forceinline__ void grad_rows_flush(const GradArgs& a, const int64_t gi0, GradRowAcc<NC>& s, double (&g)[NC]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    const double* src = a.pts.xs + gi0 + 32 * wave + 2 * r16 + ib;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const double x = src[(int64_t)k * a.pts.npad];
+      double add = (x * x) * s.R[ib];  // (this lane's share of R_i: its column groups)
+#pragma unroll
+      for (int n = 0; n < GradRowAcc<NC>::ND; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * n + kq + 4 * r;  // feature index: f < NC -> P_ik (k = f), NC <= f < 2 NC -> S_ik (k = f - NC)
+          add += (f == k) ? -2.0 * x * s.D[ib][n][r] : (f == NC + k) ? s.D[ib][n][r] : 0.0;
+        }
+      g[k] += add;
+    }
+  }
+  grad_rows_reset(s);
+}
+
+// A run of interior tiles of ONE tile row: rows gi0 = 128 tix .. (this wave: 32 of them), column tiles tj0 .. tj1-1 (all left of
+// the diagonal, all rows and columns real).  What the columns contribute -- coordinates, their squares, norms, alpha: 10 KB per
+// tile -- is staged in LDS once per tile by the whole workgroup (requested while the previous tile computes) in the two layouts
+// the two contractions read: F[k][col] (k-major, pitch 144: the A operand of the r^2 contraction) and FT[col][feature]
+// (pitch 16 ND + 1: the A operand of G . [X | X^2]); as per-lane global loads these 14 gathers per 16-column block were half of
+// the kernel (probe: 2.1 of 3.7 ms at C3 with neither the Sigma^-1 stream nor the transcendental work).  Sigma^-1 itself streams
+// from HBM straight into registers, three 16-column blocks ahead and continuously across the tiles of the run.
+#ifndef GMB_GRI_WAVES
+#define GMB_GRI_WAVES 2  // waves per SIMD grad_interior_kernel is compiled for
+#endif
+template <int NC>
+struct GradInteriorLds {
+  static constexpr int ND = GradRowAcc<NC>::ND;
+  static constexpr int FP = TILE + 16;    // pitch of F: 144 doubles == 32 banks mod 64 (the two k rows of a half-wave on disjoint banks)
+  static constexpr int TP = 16 * ND + 1;  // pitch of FT: odd, so that the staging writes of 32 consecutive columns hit 32 different banks
+  static constexpr int DOUBLES = NC * FP + TILE * TP + 2 * TILE;
+};
+
 template <int KIND, int NC>
-__global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
+__device__ __forceinline__ void grad_interior_segment(const GradArgs& a, const int tix, const int tj0, const int tj1, double* lds,
+                                                      double (&g_ls2)[NC], double& g_eta2) {
+  using L = GradInteriorLds<NC>;
+  constexpr bool NORM_IN_C = (NC + 2 + 3) / 4 > (NC + 3) / 4;
+  constexpr int KA = NORM_IN_C ? NC : NC + 2;
+  constexpr int NG = (KA + 3) / 4;
+  constexpr int ND = L::ND, FP = L::FP, TP = L::TP;
+  constexpr double sc = KIND == 0 ? 1.0 : -2.0;
+  constexpr double sn = KIND == 0 ? -0.5 : 1.0;
+  constexpr double off12 = KIND == 0 ? 0.0 : 1e-12;
+  double* const F = lds;
+  double* const FT = F + NC * FP;
+  d2* const NA = reinterpret_cast<d2*>(FT + TILE * TP);  // {sn |x_j|^2, alpha_j}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int64_t npad = a.pts.npad;
+  const int64_t gi0 = (int64_t)tix * TILE;
+  // row side (slot r16 of block ib <-> row 2 r16 + ib: the two rows of a lane are neighbours in memory)
+  double brow[2][NG], nrow[2], ai[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    const double* src = a.pts.xs + gi0 + 32 * wave + 2 * r16 + ib;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int k = 4 * g + kq;
+      double v = k < (NORM_IN_C ? NC : NC + 1) ? src[(int64_t)k * npad] : 0.0;
+      if (!NORM_IN_C && k == NC) v = fma(v, sn, off12);
+      if (!NORM_IN_C && k == NC + 1) v = 1.0;
+      brow[ib][g] = v;
+    }
+    nrow[ib] = NORM_IN_C ? fma(sn, src[(int64_t)NC * npad], off12) : 0.0;
+    ai[ib] = a.alpha[gi0 + 32 * wave + 2 * r16 + ib];
+  }
+  GradRowAcc<NC> s;
+  grad_rows_reset(s);
+  const int64_t zrow0 = a.z_packed ? (int64_t)((tix - a.row_first) / a.row_stride) * TILE : gi0;
+  const double* zsrc = a.Z + zrow0 + 32 * wave + 2 * r16 + ((int64_t)tj0 * TILE + kq) * a.ldz;
+  struct ZBlk {
+    d2 z[4];
+  };
+  constexpr int NB = TILE / 16;
+  const int nblk = NB * (tj1 - tj0);
+  auto load_z = [&](int B, ZBlk& zb) {
+    B = B < nblk ? B : nblk - 1;
+#if defined(GMB_GR_PROBE) && (GMB_GR_PROBE & 1)  // measurement probe: no Sigma^-1 stream (arithmetic alone)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zb.z[r] = d2{1.0 + B, 2.0};
+#else
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zb.z[r] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(zsrc + (int64_t)(16 * B + 4 * r) * a.ldz));
+#endif
+  };
+  // staging: thread (column j = tid & 127, half h = tid >> 7) carries the coordinates k = h KH .. of its column, and the
+  // norm (h = 0) or alpha (h = 1)
+  constexpr int KH = (NC + 1) / 2;
+  const int sj = tid & (TILE - 1), sh = tid >> 7;
+  double sx[KH], sna;
+  auto stage_load = [&](const int t) {
+    const int64_t gj = (int64_t)t * TILE + sj;
+#pragma unroll
+    for (int q = 0; q < KH; ++q) {
+      const int k = sh * KH + q;
+      sx[q] = k < NC ? a.pts.xs[(int64_t)k * npad + gj] : 0.0;
+    }
+    sna = sh == 0 ? sn * a.pts.xs[(int64_t)NC * npad + gj] : a.alpha[gj];
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int q = 0; q < KH; ++q) {
+      const int k = sh * KH + q;
+      if (k < NC) {
+        F[k * FP + sj] = sx[q];
+        FT[sj * TP + k] = sx[q];
+        FT[sj * TP + NC + k] = sx[q] * sx[q];
+      }
+    }
+    reinterpret_cast<double*>(NA)[2 * sj + sh] = sna;
+  };
+  __syncthreads();  // (whoever used the staging area before is done with it)
+  if (2 * NC < 16 * ND)  // features beyond 2 NC: zero, once
+    for (int idx = tid; idx < TILE * (16 * ND - 2 * NC); idx += 256) {
+      const int j = idx / (16 * ND - 2 * NC), f = 2 * NC + idx - j * (16 * ND - 2 * NC);
+      FT[j * TP + f] = 0.0;
+    }
+  stage_load(tj0);
+  stage_store();
+  ZBlk z0, z1, z2, z3;
+  load_z(0, z0);
+  load_z(1, z1);
+  load_z(2, z2);
+  __syncthreads();
+  const double eta2 = a.p.eta2;
+  for (int t = tj0; t < tj1; ++t) {
+    if (t + 1 < tj1) stage_load(t + 1);
+#pragma unroll 1
+    for (int jb = 0; jb < NB; ++jb) {
+      load_z(NB * (t - tj0) + jb + 3, z3);
+      // column side of this 16-column block from LDS
+      double acol[NG], feat[ND][4];
+      d2 na[4];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int k = 4 * g + kq;
+        double v;
+        if constexpr (NORM_IN_C) {
+          v = k < NC ? sc * F[k * FP + 16 * jb + r16] : 0.0;
+        } else {
+          v = k < NC ? sc * F[(k < NC ? k : 0) * FP + 16 * jb + r16] : (k == NC ? 1.0 : (k == NC + 1 ? NA[16 * jb + r16][0] : 0.0));
+        }
+        acol[g] = v;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        na[r] = NA[16 * jb + kq + 4 * r];
+#pragma unroll
+        for (int n = 0; n < ND; ++n) feat[n][r] = FT[(16 * jb + kq + 4 * r) * TP + 16 * n + r16];
+      }
+      d4 acc[2];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        if constexpr (NORM_IN_C) acc[ib] = d4{nrow[ib] + na[0][0], nrow[ib] + na[1][0], nrow[ib] + na[2][0], nrow[ib] + na[3][0]};
+        else acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[g], brow[ib][g], acc[ib], 0, 0, 0);
+      }
+      double G[2][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          double ks, dk;
+#if defined(GMB_GR_PROBE) && (GMB_GR_PROBE & 2)  // measurement probe: no transcendental work (the stream + the MFMAs alone)
+          ks = acc[ib][r];
+          dk = -0.5 * ks;
+#else
+          stationary_pair_interior<KIND>(acc[ib][r], eta2, ks, dk);
+#endif
+          const double mm = fma(-ai[ib], na[r][1], z0.z[r][ib]);
+          g_eta2 = fma(mm, ks, g_eta2);
+          G[ib][r] = mm * dk;
+          s.R[ib] += G[ib][r];
+        }
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s.D[ib][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(feat[n][r], G[ib][r], s.D[ib][n], 0, 0, 0);
+      z0 = z1;
+      z1 = z2;
+      z2 = z3;
+    }
+    __syncthreads();  // every wave is done with this tile's columns
+    if (t + 1 < tj1) {
+      stage_store();
+      __syncthreads();
+    }
+  }
+  grad_rows_flush<NC>(a, gi0, s, g_ls2);
+}
+
+// MODE 0: every tile the interior kernel does not take (all of them when a.split == 0); MODE 1: the interior tiles only.  Two
+// kernels over the same enumeration and the same partition into workgroup runs, so that the matrix-pipe path keeps its own
+// register budget (together the two paths asked for 299 registers: one wave per SIMD); each leaves its own partial vectors
+// (a.part_block0 + blockIdx.x), summed in a fixed order by grad_sum_partials_kernel.
+template <int KIND, int NC, int MODE>
+__device__ __forceinline__ void grad_tile_body(const GradArgs& a) {
   // LDS sized by the model (grad_lds_bytes): the plain stationary case keeps 8 workgroups per compute unit
   // (10 KB each at d = 8); static arrays for the largest model cost 41 KB and two thirds of the occupancy
   extern __shared__ double grad_dsm[];
@@ -93,9 +365,24 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
 
   // this workgroup's run of lower-triangle tile pairs (ti >= tj), enumerated block row by owned block row
   // (closed form: owned row m = (tix - row_first) / row_stride is preceded by m (row_first + 1) + row_stride m (m - 1) / 2 tiles)
-  const long long t_begin = (long long)blockIdx.x * a.per;
+  long long t_begin = (long long)blockIdx.x * a.per;
   long long t_end = t_begin + a.per;
   t_end = t_end < a.total_tiles ? t_end : a.total_tiles;
+  // MODE 0 beside an interior launch: ONE tile per workgroup from the short list of the tiles that launch leaves -- the
+  // diagonal tile of every owned block row, then (a ragged last block row that is owned) its tiles left of the diagonal.
+  // (As runs of the full enumeration the ~390 tiles of C3's last row fell to eight workgroups: 2.7 ms for 0.5 % of the work.)
+  int list_tix = -1, list_tjx = -1;
+  if (MODE == 0 && a.split) {
+    const int b = (int)blockIdx.x;
+    if (b < a.n_owned_rows) {
+      list_tix = list_tjx = a.row_first + b * a.row_stride;
+    } else {
+      list_tix = a.tiles - 1;
+      list_tjx = b - a.n_owned_rows;
+    }
+    t_begin = 0;
+    t_end = 1;
+  }
   auto before = [&](int q) -> long long { return (long long)q * (a.row_first + 1) + (long long)a.row_stride * q * (q - 1) / 2; };
   int m = 0;
   if (t_begin < t_end) {
@@ -107,10 +394,17 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
   }
   int tix = a.row_first + m * a.row_stride;
   int tjx = (int)(t_begin - before(m));
+  if (MODE == 0 && a.split) {
+    tix = list_tix;
+    tjx = list_tjx;
+  }
 
   for (long long tile = t_begin; tile < t_end; ++tile) {
     const int64_t gi0 = (int64_t)tix * TILE, gj0 = (int64_t)tjx * TILE;
     const int64_t gi = gi0 + il;
+    // interior tile of a smooth stationary model (block-uniform test): the matrix-pipe form, nothing staged in LDS
+    const bool interior = a.split && tix > tjx && gi0 + TILE <= a.pts.n;
+    (void)interior;  // (MODE 0 beside an interior launch walks the general-tile list: none of its tiles is interior)
     __syncthreads();  // the previous tile's readers are done with the staged coordinates
     for (int idx = tid; idx < NC * TILE; idx += 256) {
       const int k = idx / TILE, j = idx - k * TILE;
@@ -248,10 +542,74 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
     }
   }
   __syncthreads();
-  double* out = a.part + (int64_t)blockIdx.x * a.part_stride;
+  double* out = a.part + ((int64_t)a.part_block0 + blockIdx.x) * a.part_stride;
   if (tid < n_acc_small) out[tid] = (swave[tid] + swave[GRAD_SMALL + tid]) + (swave[2 * GRAD_SMALL + tid] + swave[3 * GRAD_SMALL + tid]);
   for (int idx = tid; idx < tabw; idx += 256)
     out[n_acc_small + idx] = (stab[idx] + stab[tabw + idx]) + (stab[2 * tabw + idx] + stab[3 * tabw + idx]);
+}
+
+template <int KIND, int NC>
+__global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
+  grad_tile_body<KIND, NC, 0>(a);
+}
+// The interior tiles of the launch's enumeration, run by run (the same partition into workgroup runs as the direct kernel's
+// full enumeration): every run is cut into its tile rows, every row piece is one grad_interior_segment.
+template <int KIND, int NC>
+__global__ __launch_bounds__(256, GMB_GRI_WAVES) void grad_interior_kernel(GradArgs a) {
+  __shared__ __attribute__((aligned(16))) double lds[GradInteriorLds<NC>::DOUBLES];
+  __shared__ double swave[4][GRAD_SMALL];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  double g_ls2[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) g_ls2[k] = 0.0;
+  double g_eta2 = 0.0;
+  long long tile = (long long)blockIdx.x * a.per;
+  long long t_end = tile + a.per;
+  t_end = t_end < a.total_tiles ? t_end : a.total_tiles;
+  auto before = [&](int q) -> long long { return (long long)q * (a.row_first + 1) + (long long)a.row_stride * q * (q - 1) / 2; };
+  int m = 0;
+  if (tile < t_end) {
+    const double sd = (double)a.row_stride, f1 = (double)a.row_first + 1.0 - 0.5 * sd;
+    m = (int)((__builtin_sqrt(f1 * f1 + 2.0 * sd * (double)tile) - f1) / sd);
+    m = m < 0 ? 0 : m;
+    while (before(m) > tile) --m;
+    while (before(m + 1) <= tile) ++m;
+  }
+  int tix = a.row_first + m * a.row_stride;
+  int tjx = (int)(tile - before(m));
+  while (tile < t_end) {
+    const long long left_in_row = (long long)(tix - tjx + 1);  // tiles of this row from tjx on, the diagonal one included
+    const long long nseg = left_in_row < t_end - tile ? left_in_row : t_end - tile;
+    const int tj1 = (int)(tjx + nseg) < tix ? (int)(tjx + nseg) : tix;  // interior tiles end at the diagonal
+    if (tjx < tj1 && (int64_t)(tix + 1) * TILE <= a.pts.n) grad_interior_segment<KIND, NC>(a, tix, tjx, tj1, lds, g_ls2, g_eta2);
+    tile += nseg;
+    tjx += (int)nseg;
+    if (tjx > tix) {
+      tix += a.row_stride;
+      tjx = 0;
+    }
+  }
+  // units of the direct loops: d r2 / d ls_k = -2 d2_k / ls_k; eta^2 k -> 2 eta k.  Wave sums (fixed shuffle tree), waves in order.
+  auto wave_sum = [&](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+  };
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const double v = wave_sum(-2.0 * a.inv_ls[k] * g_ls2[k]);
+    if ((tid & 63) == 0) swave[wave][k] = v;
+  }
+  {
+    const double v = wave_sum((2.0 / a.eta) * g_eta2);
+    if ((tid & 63) == 0) {
+      swave[wave][NC] = v;
+      swave[wave][NC + 1] = 0.0;  // tau: no linear term on this path
+    }
+  }
+  __syncthreads();
+  double* out = a.part + ((int64_t)a.part_block0 + blockIdx.x) * a.part_stride;
+  if (tid < NC + 2) out[tid] = (swave[0][tid] + swave[1][tid]) + (swave[2][tid] + swave[3][tid]);
 }
 
 // Second stage: out[dst(q)] = sum over the nparts partial vectors of slot q, in a FIXED order (thread t adds parts

@@ -43,36 +43,25 @@ class Regressor(ABC):
     categorical dim, always last (reference :180-265).
     """
 
+    #: model description filled in by ``specify_model`` (lists / dicts, empty until then) ...
+    _SPEC_LISTS = ("continuous_dims", "linear_dims", "categorical_dims")
+    _SPEC_DICTS = ("continuous_levels", "continuous_coords", "categorical_levels", "categorical_coords", "filter_dims", "model_specs")
+    #: ... and what the data / grid / prediction calls leave behind (None until they have run)
+    _RESULT_SLOTS = ("X", "y", "grid_vectors", "grid_parray", "grid_points", "ticks", "predictions", "predictions_X", "_structured_cache")
+
     def __init__(self, dataset: DataSet, outputs=None, seed=2021):
         if not isinstance(dataset, DataSet):
             raise TypeError("Learner instance must be initialized with a DataSet object")
-        self.data = dataset
-        self.stdzr = dataset.stdzr
-        outputs = outputs if outputs is not None else dataset.outputs
-        self.outputs = outputs if isinstance(outputs, list) else [outputs]
-        self.out_col = dataset.names_column
-        self.seed = seed
-
-        self.continuous_dims = []
-        self.linear_dims = []
-        self.continuous_levels = {}
-        self.continuous_coords = {}
-        self.categorical_dims = []
-        self.categorical_levels = {}
-        self.categorical_coords = {}
-        self.filter_dims = {}
+        self.data, self.stdzr, self.out_col, self.seed = dataset, dataset.stdzr, dataset.names_column, seed
+        wanted = dataset.outputs if outputs is None else outputs
+        self.outputs = list(wanted) if isinstance(wanted, list) else [wanted]
+        for name in self._SPEC_LISTS:
+            setattr(self, name, [])
+        for name in self._SPEC_DICTS:
+            setattr(self, name, {})
+        for name in self._RESULT_SLOTS:
+            setattr(self, name, None)
         self.additive = False
-        self.model_specs = {}
-
-        self.X = None
-        self.y = None
-        self.grid_vectors = None
-        self.grid_parray = None
-        self.grid_points = None
-        self.ticks = None
-        self.predictions = None
-        self.predictions_X = None
-        self._structured_cache = None
 
     # ------------------------------------------------------------------------------------------
     @abstractmethod
@@ -335,72 +324,69 @@ class Regressor(ABC):
         self.predictions = self.mvuparray(*parts, cor=B / (sd.T @ sd))
         return self.predictions
 
-    def prepare_grid(self, limits=None, at=None, resolution=100):
-        """Regular grid over the continuous dims not pinned by ``at`` (reference :603-728)."""
-        self.predictions = None
-        self.predictions_X = None
-        if at is None:
-            at = self.parray(none=[])
-        elif not isinstance(at, ParameterArray):
-            raise TypeError('"at" must be a ParameterArray')
-        elif at.ndim != 0:
-            raise ValueError('"at" must be single point, potentially with multiple layers')
+    def _default_grid_limits(self, free_dims):
+        """Standardized limits of the free continuous dims when the caller gives none: the range of the data, never
+        narrower than [-2, 2], widened by a tenth of its width on either side."""
+        X, _ = self.get_structured_data("mean")  # (cached since build_model)
+        z = np.atleast_2d(X.z.values()).T        # one column per model dim, in ``dims`` order
+        low, high = np.minimum(z.min(axis=0), -2.0), np.maximum(z.max(axis=0), 2.0)
+        margin = 0.1 * (high - low)
+        spans = {dim: (low[i] - margin[i], high[i] + margin[i]) for i, dim in enumerate(self.dims) if dim in free_dims}
+        return self.parray(**{dim: np.asarray(span) for dim, span in spans.items()}, stdzd=True)
 
-        at_dims = set(at.names)
-        continuous = set(self.continuous_dims)
-        limit_dims = continuous - at_dims
-        if not limit_dims:
+    def _grid_resolution(self, resolution):
+        if isinstance(resolution, dict):
+            assert_is_subset("continuous dimensions", resolution.keys(), self.continuous_dims)
+            return resolution
+        if isinstance(resolution, int):
+            return dict.fromkeys(self.continuous_dims, resolution)
+        raise TypeError('"resolution" must be a dictionary or an integer')
+
+    def prepare_grid(self, limits=None, at=None, resolution=100):
+        """Regular grid over the continuous dims not pinned by ``at``; every other continuous dim is held at its value in
+        ``at`` (one point, any number of layers).  Counterpart of the reference's :603-728 -- same arguments, same
+        attributes left behind (``grid_vectors``, ``grid_parray``, ``grid_points``, ``prediction_dims``)."""
+        self.predictions = self.predictions_X = None
+        pinned = {}
+        if at is not None:
+            if not isinstance(at, ParameterArray):
+                raise TypeError('"at" must be a ParameterArray')
+            if at.ndim != 0:
+                raise ValueError('"at" must be single point, potentially with multiple layers')
+            pinned = at.as_dict()
+        free = set(self.continuous_dims) - set(pinned)
+        if not free:
             raise ValueError("At least one dimension must be non-degenerate to generate grid.")
 
-        # default limits: data range widened to at least [-2, 2] (standardized) plus 10 % padding
-        X, _ = self.get_structured_data("mean")
-        Xz = np.atleast_2d(X.z.values()).T
-        lo = np.minimum(Xz.min(0), -2.0)
-        hi = np.maximum(Xz.max(0), 2.0)
-        pad = (hi - lo) * 0.1
-        defaults = np.stack([lo - pad, hi + pad]).T
-        default_parray = self.parray(
-            **{dim: rng for dim, rng in zip(self.dims, defaults) if dim in limit_dims}, stdzd=True
-        )
+        defaults = self._default_grid_limits(free)
         if limits is None:
-            limits = default_parray
+            limits = defaults
+        elif not isinstance(limits, ParameterArray):
+            raise TypeError('"limits" must be a ParameterArray')
         else:
-            if not isinstance(limits, ParameterArray):
-                raise TypeError('"limits" must be a ParameterArray')
-            remaining = limit_dims - set(limits.names)
-            if remaining:
-                limits = limits.add_layers(**default_parray[list(remaining)].as_dict())
-
-        limit_dims = set(limits.names)
-        if limit_dims & at_dims:
+            missing = free - set(limits.names)
+            if missing:  # dims the caller left out keep their default range
+                limits = limits.add_layers(**defaults[list(missing)].as_dict())
+        gridded = set(limits.names)
+        if gridded & set(pinned):
             raise ValueError('Dimensions specified via "limits" and in "at" must not overlap.')
-        if not continuous.issubset((at_dims | limit_dims) - {"none"}):
+        if not set(self.continuous_dims) <= (gridded | set(pinned)):
             raise ValueError('Not all continuous dimensions are specified by "limits" or "at".')
 
-        if isinstance(resolution, int):
-            resolution = {dim: resolution for dim in self.continuous_dims}
-        elif not isinstance(resolution, dict):
-            raise TypeError('"resolution" must be a dictionary or an integer')
-        else:
-            assert_is_subset("continuous dimensions", resolution.keys(), self.continuous_dims)
-
+        per_dim = self._grid_resolution(resolution)
         lz = limits.z
-        grid_vectors = {
-            dim: self.parray(**{dim: np.linspace(*lz[dim + "_z"].values(), resolution[dim])[:, None]}, stdzd=True)
-            for dim in limit_dims
-        }
-        ordered = [dim for dim in self.dims if dim in limit_dims]
-        grids = np.meshgrid(*[grid_vectors[dim] for dim in ordered], indexing="ij")
-        grid_parray = self.parray(**{g.names[0]: g.values() for g in grids})
-        if at.names != ["none"]:
-            grid_parray = grid_parray.add_layers(
-                **{dim: np.full(grid_parray.shape, val) for dim, val in at.as_dict().items()}
-            )
-        self.prediction_dims = ordered
-        self.grid_vectors = grid_vectors
-        self.grid_parray = grid_parray
-        self.grid_points = grid_parray.ravel()
-        return grid_parray
+        axes = {}
+        for dim in gridded:
+            start, stop = lz[dim + "_z"].values()
+            axes[dim] = self.parray(**{dim: np.linspace(start, stop, per_dim[dim])[:, None]}, stdzd=True)
+        order = [dim for dim in self.dims if dim in gridded]  # grid axes follow the model's dimension order
+        mesh = np.meshgrid(*(axes[dim] for dim in order), indexing="ij")
+        grid = self.parray(**{m.names[0]: m.values() for m in mesh})
+        if pinned:
+            grid = grid.add_layers(**{dim: np.full(grid.shape, value) for dim, value in pinned.items()})
+        self.prediction_dims, self.grid_vectors = order, axes
+        self.grid_parray, self.grid_points = grid, grid.ravel()
+        return grid
 
     def marginal_grids(self, *dims):
         if self.grid_points is None:
@@ -411,25 +397,25 @@ class Regressor(ABC):
         return [grids[ordered.index(d)] for d in dims]
 
     def predict_grid(self, output=None, categorical_levels=None, with_noise=True, **kwargs):
-        """Predict on the prepared grid and reshape to it (reference :751-783)."""
+        """Predictions on the grid ``prepare_grid`` left behind, in the grid's shape (reference :751-783); for models with
+        categorical dims ``categorical_levels`` names the level of each."""
         if self.grid_points is None:
             raise ValueError("Grid must first be specified with `prepare_grid`")
-        points = self.grid_points
-        if self.categorical_dims:
-            points = self.append_categorical_points(points, categorical_levels=categorical_levels)
-        self.predict_points(points, output=output, with_noise=with_noise, **kwargs)
-        self.predictions = self.predictions.reshape(self.grid_parray.shape)
-        self.predictions_X = self.predictions_X.reshape(self.grid_parray.shape)
+        shape = self.grid_parray.shape
+        where = self.append_categorical_points(self.grid_points, categorical_levels) if self.categorical_dims else self.grid_points
+        flat = self.predict_points(where, output=output, with_noise=with_noise, **kwargs)
+        self.predictions, self.predictions_X = flat.reshape(shape), self.predictions_X.reshape(shape)
         return self.predictions
 
     def append_categorical_points(self, continuous_parray, categorical_levels):
+        """``continuous_parray`` with one constant layer per categorical dim: the coordinate of the level named for it."""
         if categorical_levels is None:
             return continuous_parray
-        if set(categorical_levels) != set(self.categorical_dims) - {self.out_col}:
+        needed = set(self.categorical_dims) - {self.out_col}
+        if set(categorical_levels) != needed:
             raise AttributeError("Must specify level for every categorical dimension")
-        return continuous_parray.fill_with(
-            **{dim: self.categorical_coords[dim][lv] for dim, lv in categorical_levels.items()}
-        )
+        coords = {dim: self.categorical_coords[dim][level] for dim, level in categorical_levels.items()}
+        return continuous_parray.fill_with(**coords)
 
     def get_conditional_prediction(self, **dim_values):
         """Slice of the gridded prediction at fixed values of some dims, by linear interpolation

@@ -406,6 +406,26 @@ def test_nlml_gradient_matches_oracle(gpu, kind, ard):
     assert not eng.factor_is_current()
 
 
+@pytest.mark.parametrize("kind", ["ExpQuad", "Matern52", "Matern32"])
+@pytest.mark.parametrize("d,ard", [(1, True), (2, True), (3, False), (5, True), (8, True), (11, True), (16, False)])
+def test_interior_tiles_of_the_trace_reductions_match_the_oracle(gpu, kind, d, ard):
+    """grad_interior_kernel (csrc/gradient.hpp): on full tiles below the diagonal the per-dimension sums run as r^2 and
+    G . [X | X^2] contractions on the matrix pipe.  Every compile-time dimension count (1, 2: norms in the contraction's spare
+    slots; 4, 8, 16: in the accumulator; 16: two feature accumulators), ARD and shared lengthscales, length scales short enough
+    that the expansion's cancellation would show -- gradient and NLML against the oracle's direct-difference form."""
+    N = 1000
+    X, y, ls = O.synthetic_table(N, d, seed=40 + d)
+    spec = O.make_spec(d, range(d), kind=kind, ard=ard)
+    theta = O.pack_theta(spec, 0.6 * ls if ard else [0.8], 1.3, 0.2)
+    eng = make_engine(spec, theta, X, y)
+    val, g = eng.evaluate(theta)
+    val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+    assert np.isclose(val, val_r, rtol=1e-11) and np.max(np.abs(g - g_r)) < 1e-8 * max(1.0, np.max(np.abs(g_r)))
+    val2, g2 = eng.evaluate(theta)
+    assert g2.tobytes() == g.tobytes()
+    eng.close()
+
+
 @pytest.mark.parametrize("two_outputs,lin,hetero,n", [(True, True, True, 90), (False, True, False, 300), (True, False, False, 200)])
 def test_additive_model_matches_oracle(gpu, two_outputs, lin, hetero, n):
     """specify_model(additive=True) (pymc/GP.py:732-754): a global kernel plus one kernel per categorical

@@ -1,7 +1,7 @@
 """Fused evaluation launch: wall time per gmb_evaluate against the lag of the inverse behind the factorisation in the ticket order.
 ET_SIZES, ET_LAGS."""
 import os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gumbi_amd import engine
 from oracle import gp_oracle as O

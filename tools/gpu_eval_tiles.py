@@ -1,7 +1,7 @@
 """Persistent evaluation launch (csrc/eval_tiles.hpp) against the launch tree: gradient / alpha / NLML agreement with the
 oracle and between the schedules, and wall time per evaluation.  ET_SIZES=10000x4,... picks the cases; ET_LAG the lag."""
 import os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gumbi_amd import engine
 from oracle import gp_oracle as O

@@ -1,7 +1,7 @@
 """Task trace of the persistent evaluation launch: where the time of a fused evaluation goes, by task kind.
 ET_N, ET_D, ET_SCHEME (2 = fused, 1 = behind the factorisation), ET_LAG."""
 import os, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gumbi_amd import engine
 from oracle import gp_oracle as O

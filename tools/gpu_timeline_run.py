@@ -18,7 +18,17 @@ e = engine.Engine(0)
 e.set_data(X, y)
 e.set_kernel(engine.KernelSpec(D=d, idx_cont=list(range(d))))
 e.set_theta(np.concatenate([ls, [1.0, 0.2]]))
+import os  # noqa: E402
+
+theta = np.concatenate([ls, [1.0, 0.2]])
+if os.environ.get("TL_CHOL"):
+    e.set_chol_scheme(int(os.environ["TL_CHOL"]))
+if os.environ.get("TL_GRAD"):
+    e.set_grad_scheme(int(os.environ["TL_GRAD"]))
 for _ in range(3):
+    if what == "evaluate":  # what find_MAP calls: ONE C call per objective + gradient evaluation
+        e.evaluate(theta)
+        continue
     e.factorize()
     if what == "grad":
         e.nlml(grad=True)
