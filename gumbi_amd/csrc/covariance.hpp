@@ -481,37 +481,51 @@ __device__ __forceinline__ void cov_general_tile(const CovTileArgs& a, const int
       for (int jj = 0; jj < TILE / 2; ++jj) outp[(int64_t)jj * a.ldo] = entry(jj);
     }
   } else {
-    for (int jj = 0; jj < TILE / 2; ++jj) {
-      const int j = jh * (TILE / 2) + jj;
-      const int64_t gj = gj0 + j;
-      double r2 = 0.0;
+    // U entries at a time: the distance / sqrt / exp chains of the entries are independent and interleave (one entry after
+    // the other this loop was a single dependent chain per thread: ~35 us per diagonal / boundary tile whatever the size)
+    constexpr int U = NC <= 4 ? 4 : 2;
+    for (int jj0 = 0; jj0 < TILE / 2; jj0 += U) {
+      double v_[U];
 #pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        const double d = xi[k] - xj[k][j];
-        r2 = fma(d, d, r2);
-      }
-      double v = p.eta2 * stationary<KIND>(r2);
-      if (p.n_lin > 0) {
-        double s = 0.0;
-        for (int k = 0; k < p.n_lin; ++k) s = fma(li[k][il], lj[k][j], s);
-        v = fma(p.tau, s, v);
-      }
-      for (int t = 0; t < p.n_tab; ++t)
-        v *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
-      const bool col_real = gj < a.cols.n;
-      if (a.accumulate) {
-        if (row_real && col_real && (a.mode != COV_TRAIN || gi >= gj)) outp[(int64_t)jj * a.ldo] += v;
-      } else if (a.mode == COV_TRAIN) {
-        if (!col_real) {
-          v = (gi == gj) ? 1.0 : 0.0;  // identity padding keeps the padded factor trivial
-        } else if (!row_real) {
-          v = (gi == a.rows.n) ? a.y[gj] : 0.0;  // appended y row: the factor's row n becomes L^-1 y
-        } else if (gi == gj) {
-          v += ndiag;
+      for (int u = 0; u < U; ++u) {
+        const int j = jh * (TILE / 2) + jj0 + u;
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const double d = xi[k] - xj[k][j];
+          r2 = fma(d, d, r2);
         }
-        if (gi >= gj) outp[(int64_t)jj * a.ldo] = v;  // lower triangle only
-      } else {
-        outp[(int64_t)jj * a.ldo] = (row_real && col_real) ? v : 0.0;
+        double v = p.eta2 * stationary<KIND>(r2);
+        if (p.n_lin > 0) {
+          double s = 0.0;
+          for (int k = 0; k < p.n_lin; ++k) s = fma(li[k][il], lj[k][j], s);
+          v = fma(p.tau, s, v);
+        }
+        for (int t = 0; t < p.n_tab; ++t)
+          v *= p.tabs[p.tab_off[t] + ci[t][il] * p.tab_levels[t] + cj[t][j]];
+        v_[u] = v;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = jj0 + u;
+        const int j = jh * (TILE / 2) + jj;
+        const int64_t gj = gj0 + j;
+        double v = v_[u];
+        const bool col_real = gj < a.cols.n;
+        if (a.accumulate) {
+          if (row_real && col_real && (a.mode != COV_TRAIN || gi >= gj)) outp[(int64_t)jj * a.ldo] += v;
+        } else if (a.mode == COV_TRAIN) {
+          if (!col_real) {
+            v = (gi == gj) ? 1.0 : 0.0;  // identity padding keeps the padded factor trivial
+          } else if (!row_real) {
+            v = (gi == a.rows.n) ? a.y[gj] : 0.0;  // appended y row: the factor's row n becomes L^-1 y
+          } else if (gi == gj) {
+            v += ndiag;
+          }
+          if (gi >= gj) outp[(int64_t)jj * a.ldo] = v;  // lower triangle only
+        } else {
+          outp[(int64_t)jj * a.ldo] = (row_real && col_real) ? v : 0.0;
+        }
       }
     }
   }
