@@ -159,6 +159,8 @@ struct gmb_engine {
   gmb_timings tm{};
   std::vector<EventPair> evs;
   bool naive_leaf = false;
+  bool gemm_dma = true;   // the 128 x 128 launches stage their operands by LDS-DMA (gemm_f64_dma_kernel); GMB_GEMM_DMA=0: the
+                          // register-staged double buffer (tools/gpu_ab_gemm_dma.py)
   bool small_tiles = true;
   int gemm_variant = 0;
   long long wg_slots = 512;  // resident GEMM workgroups: two per compute unit
@@ -503,7 +505,10 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   const dim3 grid(nblocks);
   const bool pfc = g.beta != 0.0 && g.k <= 1024 && !in_place;
   switch (variant) {
-    case 0: hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, g); break;
+    case 0:
+      if (e->gemm_dma && !in_place) hipLaunchKernelGGL(gemm_f64_dma_kernel, grid, dim3(256), 0, e->cur, g);
+      else hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, g);
+      break;
 #ifdef GMB_TUNING
     case 4: hipLaunchKernelGGL((gemm_f64_kernel<4, 2, 4, 4, 1>), grid, dim3(512), 0, e->cur, g); break;
 #endif
@@ -1846,9 +1851,11 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   //   GMB_CHOL_SCHEME    0 = plain recursion, 2 = masked look-ahead, 3 = persistent tile kernel, for every size
   //                      (tests/test_gpu_parity.py::test_cholesky_schedules_agree; tools/gpu_ab_env.py); default: by size
   //   GMB_TRACE_FILE     per-launch event log while profiling (tools/gpu_trace_run.py, tools/gpu_bulk_trace.py)
+  //   GMB_GEMM_DMA=0     the 128 x 128 GEMM with register staging instead of the LDS-DMA ring (tools/gpu_ab_gemm_dma.py)
   // Everything else is compiled in only with -DGMB_TUNING (GUMBI_BUILD_TUNING=1 python -m gumbi_amd.build writes
   // gumbi_amd/lib/libgumbi_hip_tuning.so; tools/README.md).
   e->naive_leaf = flag("GMB_LEAF_NAIVE", false);
+  e->gemm_dma = flag("GMB_GEMM_DMA", true);
   const char* cs = getenv("GMB_CHOL_SCHEME");
   if (cs) e->chol_scheme = atoi(cs);
   int part = 32;  // compute units the masked bulk stream leaves to the panel chain

@@ -387,6 +387,148 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
   }
 }
 
+// ---- the 128 x 128 tile with LDS-DMA staging (round 4, VERDICT r03 item 4: one attempt) ------------------------------------
+// The register-staged loop above leaves the matrix pipe idle ~7 % of the time at its k-tile seams even with two workgroups
+// per compute unit (eight global loads + eight ds_write_b128 per thread and tile, one barrier at the END of a tile, the first
+// fragment reads behind it).  Here the operands go global -> LDS directly (global_load_lds_dwordx4: one wave instruction per
+// 128-double k-row = one row of the padded [k][row] image), into a ring of FOUR 8-deep stages in the same 73,728 B:
+//     tile kt:  step 0 (16 MFMAs; reads the second half's fragments)
+//               s_waitcnt lgkmcnt(0) vmcnt(8): this wave's reads of tile kt are back, its four DMAs of tile kt + 1 have landed
+//               s_barrier:                     ... everybody's; the stage of tile kt may be overwritten
+//               DMA of tile kt + 4 into it
+//               step 1 (16 MFMAs; reads the first fragments of tile kt + 1)
+// No staging registers, no ds_writes, the barrier inside the MFMA stream, three tiles in flight across it.  A call past the
+// end of the contraction re-reads the last tile (the ring always has the same number of DMAs outstanding; the garbage lands
+// in stages nobody reads).
+template <bool DUMMY = false>
+__device__ __forceinline__ void gemm_f64_dma_body(const GemmArgs& g, const int vbid) {
+  constexpr int WGN = 2, WTM = 4, WTN = 4;  // 2 x 2 waves of 4 x 4 MFMA tiles
+  constexpr int BM = 128, BN = 128, PA = BM + 16, PB = BN + 16;
+  constexpr int KD = 8, NS = 4;             // k-tile depth and stages of the ring
+  constexpr int STAGE = KD * (PA + PB);     // doubles
+  typedef __attribute__((address_space(3))) double lds_double;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void g_void;
+  __shared__ __attribute__((aligned(16))) double lds_[NS * STAGE];
+  lds_double* const lds = (lds_double*)lds_;
+
+  int tm, tn;
+  if (!gemm_decode_tile(g, BM, BN, vbid, tm, tn)) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  const int krow = (int)gemm_noff(tn, BN, g.krow_stride > 0 ? g.krow_stride : g.nblk_stride) + g.krow_off;
+  int k_lo = g.klo_m * tm * BM + g.klo_n * krow;
+  int k_hi = g.k;
+  if (g.khi_n) k_hi = min(k_hi, krow + BN);
+  if (k_lo < 0) k_lo = 0;
+  if (k_lo > k_hi) k_lo = k_hi;
+  const int64_t noff = gemm_noff(tn, BN, g.nblk_stride);
+  const int kt0 = k_lo / KD, kt1 = k_hi / KD;
+
+  d4 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // this wave's share of a tile: k-rows wave and wave + 4 of both operands; running pointers (scalar), + KD k-rows per tile
+  const double* pa = g.A + (int64_t)tm * BM + ((int64_t)kt0 * KD + wave) * g.lda;
+  const double* pb = g.B + noff + ((int64_t)kt0 * KD + wave) * g.ldb;
+  const int lane2 = 2 * lane;
+  int issued = kt0;  // tile the running pointers stand at
+  auto dma = [&](const int stage) {
+    lds_double* As = lds + stage * STAGE + wave * PA;
+    lds_double* Bs = lds + stage * STAGE + KD * PA + wave * PB;
+    __builtin_amdgcn_global_load_lds((g_void*)(pa + lane2), (lds_void*)As, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g_void*)(pb + lane2), (lds_void*)Bs, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g_void*)(pa + 4 * g.lda + lane2), (lds_void*)(As + 4 * PA), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g_void*)(pb + 4 * g.ldb + lane2), (lds_void*)(Bs + 4 * PB), 16, 0, 0);
+    if (issued + 1 < kt1) {  // (past the end: stay on the last tile)
+      pa += (int64_t)KD * g.lda;
+      pb += (int64_t)KD * g.ldb;
+      ++issued;
+    }
+  };
+  double fa[2][WTM], fb[2][WTN];
+  auto frags = [&](const int kt, const int k4, const int buf) {
+    const lds_double* As = lds + (kt & (NS - 1)) * STAGE + (4 * k4 + kq) * PA + r16;
+    const lds_double* Bs = lds + (kt & (NS - 1)) * STAGE + KD * PA + (4 * k4 + kq) * PB + r16;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) fa[buf][i] = As[wm * (16 * WTM) + i * 16];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) fb[buf][j] = Bs[wn * (16 * WTN) + j * 16];
+  };
+  auto mfmas = [&](const int buf) {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+  };
+  auto pin_step = [&]() {  // the next step's four fragment reads (ds_read2_b64) go out behind the first MFMAs of this one
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, WTM * WTN - 8, 0);
+  };
+
+  if (kt0 < kt1) {
+    dma(kt0 & (NS - 1));
+    dma((kt0 + 1) & (NS - 1));
+    dma((kt0 + 2) & (NS - 1));
+    dma((kt0 + 3) & (NS - 1));
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    frags(kt0, 0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      frags(kt, 1, 1);
+      mfmas(0);
+      pin_step();
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      dma(kt & (NS - 1));
+      frags(kt + 1, 0, 0);  // (behind the last tile: a stage of garbage, never used)
+      mfmas(1);
+      pin_step();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring may land after this workgroup has left
+  }
+
+  double* __restrict__ Cg = g.C + (g.cblk_stride > 0 ? gemm_noff(tn, BN, g.cblk_stride) : noff) + wn * (16 * WTN) + r16;
+  const int64_t m0 = (int64_t)tm * BM + wm * (16 * WTM) + kq;
+  if (g.beta == 0.0) {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* row = Cg + (m0 + i * 16 + 4 * r) * g.ldc;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) row[j * 16] = g.alpha * acc[i][j][r];
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* row = Cg + (m0 + i * 16 + 4 * r) * g.ldc;
+        double c[WTN];
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) c[j] = row[j * 16];
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) row[j * 16] = g.beta * c[j] + g.alpha * acc[i][j][r];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f64_dma_kernel(GemmArgs g) {
+  gemm_f64_dma_body<>(g, blockIdx.x);
+}
+
 template <int WGM, int WGN, int WTM, int WTN, int OCC, bool PFC = false>
 __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs g) {
   gemm_f64_body<WGM, WGN, WTM, WTN, PFC>(g, blockIdx.x);
