@@ -289,9 +289,19 @@ struct CovTileArgs {
   // enumerates, block row by owned block row row_first, row_first + row_stride, ... (< ti), the tiles
   // tj = 0 .. min(row, tj - 1).  row_stride == 0: off.
   int32_t row_first, row_stride;
+  // rows_packed (with row_first / row_stride): `out` holds ONLY the owned block rows, packed -- block row
+  // row_first + t * row_stride sits at rows 128 t .. of `out` (the multi-GPU driver's capacity mode, where no rank holds the
+  // whole matrix)
+  int32_t rows_packed;
   int32_t stream_stores;  // interior tiles use non-temporal stores (set by launch_cov for outputs of >= 1 GiB)
   int32_t strip;          // tiles per workgroup along the column index (set by launch_cov; see cov_tile_kernel)
 };
+
+// row of `out` where the tile row that starts at global row gi0 begins
+__device__ __forceinline__ int64_t cov_out_row(const CovTileArgs& a, const int64_t gi0) {
+  if (a.rows_packed) return (int64_t)(((int)(gi0 / TILE) - a.row_first) / a.row_stride) * TILE;
+  return gi0 - a.i0;
+}
 
 // A run of interior 128 x 128 tiles of one tile row (every row and column real, strictly below the diagonal of
 // the training matrix, stationary term only, all points finite): the squared distances come off the MATRIX pipe.
@@ -359,7 +369,7 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
   };
   const double eta2 = a.p.eta2;
   const uint64_t col_bytes = (uint64_t)a.ldo * 8u;
-  char* tile = reinterpret_cast<char*>(a.out + (gi0 - a.i0) + (gj0 - a.j0) * a.ldo);  // uniform
+  char* tile = reinterpret_cast<char*>(a.out + cov_out_row(a, gi0) + (gj0 - a.j0) * a.ldo);  // uniform
   const uint32_t lane_off = (uint32_t)((32 * wave + 2 * r16) * 8) + (uint32_t)kq * (uint32_t)col_bytes;
 #if GMB_KB_PROBE >= 2
   double probe_sum = 0.0;
@@ -454,7 +464,7 @@ __device__ __forceinline__ void cov_general_tile(const CovTileArgs& a, const int
   __syncthreads();
 
   const bool row_real = gi < a.rows.n;
-  double* outp = a.out + (gi - a.i0) + (gj0 - a.j0 + jh * (TILE / 2)) * a.ldo;
+  double* outp = a.out + cov_out_row(a, gi0) + il + (gj0 - a.j0 + jh * (TILE / 2)) * a.ldo;
   double ndiag = 0.0;
   if (a.mode == COV_TRAIN && row_real) {
     ndiag = p.sigma2;

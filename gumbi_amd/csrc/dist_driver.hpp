@@ -289,6 +289,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   rc = require_ready(e, false);
   if (!rc && hipSetDevice(e->device) != hipSuccess) rc = fail(e, GMB_EHIP, "hipSetDevice(%d) failed", e->device);
   std::vector<gmb_dist_step> plan;
+  if (!rc) rc = ensure_factor_buffer(e);
   if (!rc) {
     plan = dist_build_plan(e->N, rank, G, panel_blocks > 0 ? panel_blocks : (e->panel_auto ? 0 : e->panel_blocks));
     int64_t need = 0;
@@ -750,21 +751,7 @@ int64_t gmb_dist_plan(int64_t N, int32_t rank, int32_t world, int32_t panel_bloc
   return (int64_t)plan.size();
 }
 
-int gmb_dist_factorize(gmb_engine* e, const gmb_comm* comm, int32_t panel_blocks) {
-  if (!e) return GMB_EINVAL;
-  return dist_factorize(e, comm, panel_blocks);
-}
-
-int gmb_dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
-  if (!e) return GMB_EINVAL;
-  return dist_nlml(e, comm, nlml, grad);
-}
-
-int gmb_dist_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M, int64_t ldxs, int32_t with_noise,
-                     double* mean, double* var, int32_t memspace) {
-  if (!e) return GMB_EINVAL;
-  return dist_predict(e, comm, Xs, M, ldxs, with_noise, mean, var, memspace);
-}
+// (gmb_dist_factorize / gmb_dist_nlml / gmb_dist_predict: engine.hip, behind dist_capacity.hpp -- they pick the mode)
 
 const char* gmb_rccl_last_error(void) { return g_rccl_error.c_str(); }
 

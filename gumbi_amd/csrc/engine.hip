@@ -24,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <functional>
+#include <unordered_map>
 #include <mutex>
 #include <vector>
 
@@ -230,6 +231,23 @@ struct gmb_engine {
   int64_t cap_send = 0, cap_recv = 0;
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
+  // every device buffer obtained through ensure / alloc, with its size (gmb_resident_bytes)
+  std::unordered_map<void*, size_t> allocs;
+  int64_t bytes_resident = 0, bytes_peak = 0;
+  // Multi-GPU driver, CAPACITY mode (gmb_dist_set_mode(e, 1); dist_capacity.hpp): no rank holds the whole factor.  dAown =
+  // this rank's block rows, packed ((owned blocks * 128) rows x Np columns); dPanel = one column panel of L with ALL its rows
+  // (what a panel all-gather delivers), addressed through a virtual full-buffer base so that every kernel written for the
+  // replicated layout works on it unchanged -- two of them (the factorisation's look-ahead; the gradient: one panel of L and
+  // one column chunk of U = L^-T with all its rows).
+  int dist_mode = 0;
+  double* dAown = nullptr;
+  int64_t cap_Aown = 0;
+  int64_t ld_own = 0;
+  int own_world = -1, own_rank = -1;  // what dAown holds the rows of
+  double* dPanel = nullptr;
+  int64_t cap_panel = 0;
+  // gmb_predict's triangular solve V <- V L^-T, when somebody else has to do it (the capacity driver streams L through)
+  std::function<int(double*, int64_t, int)> solve_hook;
   double* dstat = nullptr;  // status words (+ payload) the ranks exchange: this rank's, then everybody's (dist_agree)
   // Every collective this engine has issued on a transport, in host issue order: count and a running hash of (element count,
   // stream).  RCCL matches the collectives of a communicator by ISSUE ORDER on every rank -- and gmb_dist_nlml issues them on
@@ -260,27 +278,45 @@ int fail(gmb_engine* e, int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                \
   } while (0)
 
+// device allocations of an engine go through ensure / alloc / release, which keep the engine's resident byte count
+// (gmb_resident_bytes: what the multi-GPU driver's capacity mode is judged by)
+void release(gmb_engine* e, void* p) {
+  if (!p) return;
+  if (e) {
+    auto it = e->allocs.find(p);
+    if (it != e->allocs.end()) {
+      e->bytes_resident -= (int64_t)it->second;
+      e->allocs.erase(it);
+    }
+  }
+  (void)hipFree(p);
+}
+
 template <typename T>
 int ensure(gmb_engine* e, T** p, int64_t* cap, int64_t need) {
   if (*cap >= need && *p) return GMB_OK;
-  if (*p) (void)hipFree(*p);
+  release(e, (void*)*p);
   *p = nullptr;
   *cap = 0;
+  if (need < 1) need = 1;
   hipError_t s = hipMalloc((void**)p, (size_t)need * sizeof(T));
   if (s != hipSuccess)
     return fail(e, GMB_ENOMEM, "hipMalloc of %lld bytes failed: %s", (long long)(need * sizeof(T)),
                 hipGetErrorString(s));
   *cap = need;
+  if (e) {
+    e->allocs[(void*)*p] = (size_t)need * sizeof(T);
+    e->bytes_resident += (int64_t)((size_t)need * sizeof(T));
+    e->bytes_peak = std::max(e->bytes_peak, e->bytes_resident);
+  }
   return GMB_OK;
 }
 
 template <typename T>
 int alloc(gmb_engine* e, T** p, int64_t need) {
   int64_t cap = 0;
-  if (*p) {
-    (void)hipFree(*p);
-    *p = nullptr;
-  }
+  release(e, (void*)*p);
+  *p = nullptr;
   return ensure(e, p, &cap, need);
 }
 
@@ -787,6 +823,12 @@ int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int6
 }
 
 PointSet train_set(const gmb_engine* e) { return PointSet{e->xs, e->xl, e->cat, e->N, e->Nr}; }
+
+// the full factor buffer (Nr x Np, leading dimension Nr), allocated on first use
+int ensure_factor_buffer(gmb_engine* e) {
+  if (e->dist_mode == 1 && e->dA && e->cap_A == 0) e->dA = nullptr;  // (a virtual base left behind by the capacity driver)
+  return ensure(e, &e->dA, &e->cap_A, e->Nr * e->Np);
+}
 
 // Covariance build: lower-triangular tiles of Sigma = K + noise + jitter, the y row, identity padding, written
 // column-major into `out` (Nr x Np, leading dimension ldo) -- the factor buffer in gmb_factorize.
@@ -1959,7 +2001,9 @@ void gmb_destroy(gmb_engine* e) {
     if (e->aux[a]) (void)hipStreamSynchronize(e->aux[a]);
   void* ptrs[] = {e->dct, e->dct_trace, e->dstat, e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
                   e->dnoise, e->dscal, e->dinfo, e->dv, e->dV, e->dXs, e->txs, e->txl,
-                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart, e->dgred, e->dgbig};
+                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart, e->dgred, e->dgbig, e->det_tasks, e->dUdiag, e->dApart,
+                  e->dAown, e->dPanel};
+  if (e->cap_A == 0) ptrs[11] = nullptr;  // (e->dA may be a virtual base of the capacity driver: nothing of ours to free)
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int a = 0; a < 3; ++a)
@@ -2016,7 +2060,13 @@ int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t l
   int rc;
   if ((rc = alloc(e, &e->dX, N * (int64_t)D))) return rc;
   if ((rc = alloc(e, &e->dy, e->Np))) return rc;
-  if ((rc = ensure(e, &e->dA, &e->cap_A, e->Nr * e->Np))) return rc;
+  // (the factor buffer itself -- Nr x Np doubles -- is allocated by the first factorisation that needs it: in the multi-GPU
+  // driver's capacity mode no rank ever holds it)
+  if (e->cap_A < e->Nr * e->Np && e->dA) {
+    release(e, e->dA);
+    e->dA = nullptr;
+    e->cap_A = 0;
+  }
   if ((rc = ensure(e, &e->dDinv16, &e->cap_dinv16, (e->Np / TILE) * (int64_t)8 * 256))) return rc;
   if ((rc = alloc(e, &e->dv, e->Np))) return rc;
   const hipMemcpyKind kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -2121,6 +2171,7 @@ int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
   e->factor_consumed = false;
   e->have_alpha = false;
   e->notpd = -1;
+  if ((rc = ensure_factor_buffer(e))) return rc;
   gmb_timings& tm = e->tm;
   tm.kbuild_ms = tm.chol_ms = tm.chol_gemm_ms = tm.chol_gemm_flops = 0.0;
   tm.chol_leaf_ms = tm.chol_trsm_ms = 0.0;
@@ -2373,8 +2424,10 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
       const bool tiles = !e->naive_leaf && ntm <= 96 && (e->chol_scheme == 3 || (e->chol_scheme < 0 && by_size));
       e->cur = e->stream;
       e->tt_used = false;
-      if ((rc = tiles ? trsm_tiles(e, e->dV, mpad, (int)(mpad / TILE), 3)
-                      : trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, nblocks, 3, 6)))
+      if (e->solve_hook) {
+        if ((rc = e->solve_hook(e->dV, mpad, (int)(mpad / TILE)))) return rc;
+      } else if ((rc = tiles ? trsm_tiles(e, e->dV, mpad, (int)(mpad / TILE), 3)
+                             : trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, nblocks, 3, 6)))
         return rc;
       if (e->tt_used) {  // a launch that gave up waiting must not be mistaken for a prediction
         uint32_t ab = 0;
@@ -2752,3 +2805,41 @@ int gmb_blk_gemm_nt(gmb_engine* e, double* C, int64_t ldc, const double* A, int6
 }  // extern "C"
 
 #include "dist_driver.hpp"
+#include "dist_capacity.hpp"
+
+extern "C" {
+
+// 0 = replicated factor (default: every rank ends with the complete factor), 1 = capacity (dist_capacity.hpp: owned block rows
+// + panel buffers only).  Takes effect with the next gmb_dist_factorize; returns the previous mode or a negative status.
+int gmb_dist_set_mode(gmb_engine* e, int32_t mode) {
+  if (!e || mode < 0 || mode > 1) return GMB_EINVAL;
+  const int old = e->dist_mode;
+  if (old != mode) e->factored = false;
+  e->dist_mode = mode;
+  return old;
+}
+
+// device bytes this engine holds through its own allocations right now (peak != 0: the largest value so far)
+int64_t gmb_resident_bytes(const gmb_engine* e, int32_t peak) {
+  if (!e) return GMB_EINVAL;
+  return peak ? e->bytes_peak : e->bytes_resident;
+}
+
+int gmb_dist_factorize(gmb_engine* e, const gmb_comm* comm, int32_t panel_blocks) {
+  if (!e) return GMB_EINVAL;
+  return e->dist_mode == 1 ? cap_factorize(e, comm, panel_blocks) : dist_factorize(e, comm, panel_blocks);
+}
+
+int gmb_dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
+  if (!e) return GMB_EINVAL;
+  return e->dist_mode == 1 ? cap_nlml(e, comm, nlml, grad) : dist_nlml(e, comm, nlml, grad);
+}
+
+int gmb_dist_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M, int64_t ldxs, int32_t with_noise,
+                     double* mean, double* var, int32_t memspace) {
+  if (!e) return GMB_EINVAL;
+  return e->dist_mode == 1 ? cap_predict(e, comm, Xs, M, ldxs, with_noise, mean, var, memspace)
+                           : dist_predict(e, comm, Xs, M, ldxs, with_noise, mean, var, memspace);
+}
+
+}  // extern "C"

@@ -205,7 +205,7 @@ class DistributedEngine:
     predict``), executed by the native multi-GPU driver over the ranks of ``group``.  Every rank makes the same
     calls with the same arguments and receives the same results."""
 
-    def __init__(self, device_index: int, group=None, comm=None, panel_blocks: int = 0):
+    def __init__(self, device_index: int, group=None, comm=None, panel_blocks: int = 0, capacity: bool = False):
         import torch
 
         torch.cuda.set_device(device_index)
@@ -214,6 +214,11 @@ class DistributedEngine:
         self.comm = comm if comm is not None else make_comm(device_index, group)
         self.panel_blocks = panel_blocks
         self.spec = None
+        # capacity mode: no rank holds the whole factor -- its own block rows + two panel buffers only, L streamed through
+        # again for the gradient and the prediction (csrc/dist_capacity.hpp); for N beyond one GPU
+        self.capacity = bool(capacity)
+        if self.capacity:
+            self.eng.set_dist_mode(Engine.DIST_CAPACITY)
 
     # -- model definition (replicated) ---------------------------------------------------------------
     def set_data(self, X, y):

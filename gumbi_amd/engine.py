@@ -253,6 +253,8 @@ _SIGNATURES = {
     "gmb_chol_task_trace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "gmb_set_chol_scheme": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_set_grad_scheme": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "gmb_dist_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gmb_resident_bytes": (C.c_int64, [C.c_void_p, C.c_int32]),
     "gmb_debug_eval_tasks": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int64]),
     "gmb_debug_chol_lose_tickets": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_blk_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -565,6 +567,20 @@ class Engine:
         return out
 
     # -- ONE GP over several GPUs (native driver, gumbi_amd/csrc/dist_driver.hpp) -----------------------------
+    #: how the ranks of ``dist_*`` hold the factor (``set_dist_mode``): every rank all of it / owned block rows + panel buffers
+    DIST_REPLICATED, DIST_CAPACITY = 0, 1
+
+    def set_dist_mode(self, mode: int) -> int:
+        """Replicated (0) or capacity (1) mode of the multi-GPU driver for the following ``dist_factorize``; returns the previous mode."""
+        prev = int(self._lib.gmb_dist_set_mode(self._h, int(mode)))
+        if prev < 0:
+            self._check(prev, "gmb_dist_set_mode")
+        return prev
+
+    def resident_bytes(self, peak: bool = False) -> int:
+        """Device bytes the engine holds through its own allocations (``peak``: the largest value so far)."""
+        return int(self._lib.gmb_resident_bytes(self._h, int(bool(peak))))
+
     def dist_factorize(self, comm, panel_blocks: int = 0):
         """Collective: ``gmb_factorize`` over the ranks of ``comm`` (a :class:`gumbi_amd.distributed` comm)."""
         self._check(self._lib.gmb_dist_factorize(self._h, comm.handle, int(panel_blocks)), "gmb_dist_factorize")

@@ -381,8 +381,19 @@ typedef struct gmb_dist_step {
 int64_t gmb_dist_plan(int64_t N, int32_t rank, int32_t world, int32_t panel_blocks, gmb_dist_step* out,
                       int64_t cap);
 
+/* How the ranks of gmb_dist_* hold the factor.  0 (default) = REPLICATED: compute is partitioned by block rows, every rank
+ * ends with the complete factor in a full-size buffer (N = 100k: 80 GB per rank whatever the number of GPUs).  1 = CAPACITY
+ * (csrc/dist_capacity.hpp): a rank keeps only its own block rows + two column-panel buffers; the gradient and the prediction
+ * stream L through again, panel by panel from its owners -- "N beyond one GPU" (N = 200k over 8 GPUs: ~160 GB per rank).
+ * Same results (other grouping of some sums).  Takes effect with the next gmb_dist_factorize; returns the previous mode or a
+ * negative gmb_status.  gmb_copy_factor is not available on a capacity-mode engine (no rank holds the factor). */
+int gmb_dist_set_mode(gmb_engine* e, int32_t mode);
+/* Device bytes the engine holds through its own allocations right now (peak != 0: the largest value so far). */
+int64_t gmb_resident_bytes(const gmb_engine* e, int32_t peak);
+
 /* gmb_factorize over comm->world ranks (collective: every rank calls it with the same state).  Every rank
- * ends with the complete factor, v, log-det and -- on failure -- the same GMB_ENOTPD / gmb_notpd_index. */
+ * ends with the complete factor (replicated mode; its own block rows in capacity mode), v, log-det and -- on failure -- the
+ * same GMB_ENOTPD / gmb_notpd_index. */
 int gmb_dist_factorize(gmb_engine* e, const gmb_comm* comm, int32_t panel_blocks);
 /* gmb_nlml over the ranks; with grad != NULL the inverse, Sigma^-1 and the trace reductions are
  * partitioned by block rows and every rank receives bit-identical (nlml, grad). */

@@ -224,6 +224,101 @@ def test_two_ranks_one_gpu_match_oracle(pool, world, N, model, panel):
     assert len({r[-1] for r in results}) == 1  # bit-identical gradient on every rank (optimisers stay in lock step)
 
 
+def _capacity_task(rank, world, group, out, N, d, M, panel, kind):
+    """The capacity mode of the native driver (csrc/dist_capacity.hpp): no rank holds the factor -- NLML, v, alpha, gradient and
+    predictions against the oracle; the rank's resident bytes against a single engine's doing the same three calls."""
+    from scipy.linalg import solve_triangular
+
+    from gumbi_amd.distributed import DistributedEngine
+    from gumbi_amd.engine import Engine, GumbiHipError, KernelSpec
+    from oracle import gp_oracle as O
+
+    X, y, ls = O.synthetic_table(N, d, seed=5)
+    spec = O.make_spec(d, range(d), kind=kind)
+    theta = O.pack_theta(spec, ls, 1.1, 0.3)
+    Xs = np.random.default_rng(1).standard_normal((M, d))
+    kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind=kind)
+    eng = DistributedEngine(0, group, panel_blocks=panel, capacity=True)
+    eng.set_data(X, y)
+    eng.set_kernel(kspec)
+    eng.set_theta(theta)
+    eng.factorize()
+    v, nl = eng.copy_v(), eng.nlml()
+    mu, var = eng.predict(Xs)
+    val, g = eng.nlml(grad=True)  # (the factor survives: L is never overwritten in this mode)
+    alpha = eng.copy_alpha()
+    if N <= 6000:  # everything against the oracle
+        L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
+        nl_r = O.nlml(spec, theta, X, y, dist_mode="direct")
+        mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+        val_r, g_r = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+        alpha_r = solve_triangular(L_ref, v_ref, lower=True, trans="T")
+    else:  # the oracle for the NLML (one Cholesky on the host), the single engine for the rest
+        nl_r = val_r = O.nlml(spec, theta, X, y) if rank == 0 else nl
+        ref = Engine(0)
+        ref.set_data(X, y)
+        ref.set_kernel(kspec)
+        ref.set_theta(theta)
+        ref.factorize()
+        v_ref = ref.copy_v()
+        mu_r, var_r = ref.predict(Xs)
+        _, g_r = ref.nlml(grad=True)
+        alpha_r = ref.copy_alpha()
+        ref.close()
+    err_v = np.max(np.abs(v - v_ref)) / np.max(np.abs(v_ref))
+    err_nl = abs(nl - nl_r)
+    err_mu = np.max(np.abs(mu - mu_r)) / np.max(np.abs(mu_r))
+    err_var = np.max(np.abs(var - var_r))
+    err_g = max(abs(val - val_r) / abs(val_r), np.max(np.abs(g - g_r)) / max(1.0, np.max(np.abs(g_r))))
+    err_a = float(np.max(np.abs(alpha - alpha_r)) / np.max(np.abs(v_ref)))
+    mu2, var2 = eng.predict(Xs)  # after the gradient, without a re-factorisation
+    same = bool(mu2.tobytes() == mu.tobytes() and var2.tobytes() == var.tobytes())
+    try:
+        eng.copy_factor()
+        no_factor = False
+    except (GumbiHipError, ValueError):
+        no_factor = True  # nobody holds the factor
+    peak = eng.eng.resident_bytes(peak=True)
+    eng.close()
+    single = Engine(0)
+    single.set_data(X, y)
+    single.set_kernel(kspec)
+    single.set_theta(theta)
+    single.factorize()
+    single.predict(Xs)
+    single.nlml(grad=True)
+    peak_single = single.resident_bytes(peak=True)
+    single.close()
+    out.put((rank, err_v, err_nl, err_mu, err_var, err_g, err_a, same, no_factor, peak, peak_single, g.tobytes()))
+
+
+@pytest.mark.parametrize("world,N,panel,kind", [(2, 700, 0, "Matern52"), (3, 1000, 2, "ExpQuad"), (2, 512, 1, "Matern32"), (3, 130, 0, "ExpQuad"),
+                                                (4, 2500, 3, "Matern52"), (2, 5000, 0, "ExpQuad")])
+def test_capacity_mode_matches_the_oracle_without_any_rank_holding_the_factor(pool, world, N, panel, kind):
+    """gmb_dist_set_mode(e, 1): every rank keeps its own block rows (packed) and two panel buffers; the squares are factored on
+    gathered copies, the gradient's forward substitution and the prediction stream L through again from its owners, Sigma^-1
+    is accumulated chunk by chunk.  Against the oracle at the tolerances of the replicated mode; ragged sizes, a separate y
+    block row (N % 128 == 0), more ranks than block rows; the same gradient bits on every rank."""
+    results = pool.run(_capacity_task, world, N, 3, 333, panel, kind)
+    for rank, err_v, err_nl, err_mu, err_var, err_g, err_a, same, no_factor, peak, peak_single, _ in results:
+        assert err_v < 1e-10 and err_nl < 1e-8 and err_mu < 1e-8 and err_var < 1e-9 and err_g < 1e-8 and err_a < 1e-8
+        assert same and no_factor
+    assert len({r[-1] for r in results}) == 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_capacity_mode_at_n_20k_keeps_each_rank_well_below_a_single_engine(pool, world):
+    """N = 20,480 (160 block columns) over two and three ranks sharing the GPU: results against the oracle's NLML and the
+    tolerances of the replicated mode, and each rank's PEAK resident bytes (factorisation + prediction + gradient) at most 0.6
+    of what a single engine allocates for the same three calls."""
+    results = pool.run(_capacity_task, world, 20_480, 4, 1500, 0, "ExpQuad", timeout=1500)
+    for rank, err_v, err_nl, err_mu, err_var, err_g, err_a, same, no_factor, peak, peak_single, _ in results:
+        assert err_v < 1e-9 and err_nl < 1e-6 and err_mu < 1e-8 and err_var < 1e-8 and err_g < 1e-7 and err_a < 1e-7
+        assert same and no_factor
+        assert peak <= 0.6 * peak_single, (peak / 2**30, peak_single / 2**30)
+    assert len({r[-1] for r in results}) == 1
+
+
 def _notpd_task(rank, world, group, out):
     from gumbi_amd.distributed import DistributedEngine
     from gumbi_amd.engine import Engine, KernelSpec
