@@ -138,7 +138,88 @@ class NumpyRank:
             self.A[rows, lo * BLK:top * BLK] -= self.A[rows, c0:c1] @ panel_rows[:(top - lo) * BLK].T
 
 
-def _worker(rank, world, port, N, d, w, out):
+class NumpyRankCapacity(NumpyRank):
+    """The same plan in the driver's CAPACITY mode (csrc/dist_capacity.hpp): a rank stores ONLY its own block rows
+    (``own[i]``: 128 x Np) and two column-panel buffers with all rows (``pan[p & 1]``); squares are factored on gathered copies,
+    a panel buffer is poisoned before it is refilled -- an update that reads a panel after its buffer has been reused (a
+    missing JOIN in the plan) would see NaN."""
+
+    def __init__(self, spec, theta, X, y, rank, world):
+        super().__init__(spec, theta, X, y, rank, world)
+        self.A = None  # nobody holds the matrix
+        self.own, self.pan, self.pan_cols, self.npanel = {}, [None, None], [None, None], -1
+        self.v = np.full(self.Np, np.nan)
+
+    def kbuild(self, s):
+        for i in self.rows(s):
+            self.own[i] = np.tril(self._sigma)[i * BLK:(i + 1) * BLK].copy()
+
+    def _panel_of(self, c0):
+        for k in (0, 1):
+            if self.pan_cols[k] is not None and self.pan_cols[k][0] == c0:
+                return self.pan[k]
+        raise AssertionError("the panel's buffer has been reused")
+
+    def _exchange(self, s, dist, torch):
+        c0, c1, G = s["c0"] * BLK, s["c1"] * BLK, self.G
+        W, mc = c1 - c0, s["maxcount"]
+        send = np.zeros((mc, BLK, W))
+        for t, i in enumerate(self.rows(s)):
+            send[t] = self.own[i][:, c0:c1]
+        assert send.size == s["elems"]
+        t_out = torch.empty(send.size * G, dtype=torch.float64)
+        dist.all_gather_into_tensor(t_out, torch.from_numpy(send.ravel().copy()))
+        recv = t_out.numpy().reshape(G, mc, BLK, W)
+        buf = self._panel_of(s["c0"])
+        for q in range(G):
+            first, cnt = owned_blocks(q, G, s["lo"], s["hi"])
+            for t in range(cnt):
+                i = first + t * G
+                buf[i * BLK:(i + 1) * BLK] = recv[q, t]
+
+    def square(self, s, dist, torch):
+        self.npanel += 1
+        k = self.npanel & 1
+        self.pan[k] = np.full((self.Nr, (s["c1"] - s["c0"]) * BLK), np.nan)  # poison the buffer being reused
+        self.pan_cols[k] = (s["c0"], s["c1"])
+        self._exchange(s, dist, torch)
+        c0, c1 = s["c0"] * BLK, s["c1"] * BLK
+        nv = min(c1, self.N) - c0
+        blk = self.pan[k][c0:c1]
+        L11 = np.linalg.cholesky(np.tril(blk[:nv, :nv]) + np.tril(blk[:nv, :nv], -1).T)
+        blk[:nv, :nv] = L11
+        if nv < c1 - c0:
+            blk[nv:, :nv] = np.linalg.solve(L11, blk[nv:, :nv].T).T
+        self.logdet += float(np.sum(np.log(np.diag(L11))))
+        for i in self.rows(s):  # the owners' copies of the square's rows become L too
+            self.own[i][:, c0:c1] = self.pan[k][i * BLK:(i + 1) * BLK]
+        if s["hi"] * BLK >= self.Nr:
+            self.v[c0:c1] = self.pan[k][self.N]
+
+    def panel(self, s, dist, torch):
+        c0, c1 = s["c0"] * BLK, s["c1"] * BLK
+        nv = min(c1, self.N) - c0
+        buf = self._panel_of(s["c0"])
+        L11 = np.tril(buf[c0:c0 + nv, :nv])
+        for i in self.rows(s):
+            self.own[i][:, c0:c0 + nv] = np.linalg.solve(L11, self.own[i][:, c0:c0 + nv].T).T
+        self._exchange(s, dist, torch)
+        self.v[c0:c1] = buf[self.N]
+
+    def update(self, s):
+        c0, c1, lo, hi = s["c0"] * BLK, s["c1"] * BLK, s["lo"], s["hi"]
+        buf = self._panel_of(s["c0"])
+        panel_rows = buf[lo * BLK:hi * BLK]
+        assert not np.isnan(panel_rows).any()
+        for i in self.rows(s):
+            top = min(i + 1, hi)
+            if top <= lo:
+                continue
+            assert not np.isnan(buf[i * BLK:(i + 1) * BLK]).any()
+            self.own[i][:, lo * BLK:top * BLK] -= buf[i * BLK:(i + 1) * BLK] @ panel_rows[:(top - lo) * BLK].T
+
+
+def _worker(rank, world, port, N, d, w, out, capacity=False):
     import torch
     import torch.distributed as dist
 
@@ -149,7 +230,7 @@ def _worker(rank, world, port, N, d, w, out):
         X, y, ls = O.synthetic_table(N, d, seed=5)
         spec = O.make_spec(d, range(d), kind="Matern52")
         theta = O.pack_theta(spec, ls, 1.1, 0.3)
-        me = NumpyRank(spec, theta, X, y, rank, world)
+        me = (NumpyRankCapacity if capacity else NumpyRank)(spec, theta, X, y, rank, world)
         for s in E.dist_plan(N, rank, world, w):
             if s["op"] == "KBUILD":
                 me.kbuild(s)
@@ -160,6 +241,15 @@ def _worker(rank, world, port, N, d, w, out):
             elif s["op"] == "UPDATE":
                 me.update(s)
         L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
+        if capacity:  # every rank holds its own block rows only: collect them (test only) and look at the whole
+            rows = [None] * world
+            dist.all_gather_object(rows, {i: a for i, a in me.own.items()})
+            me.A = np.full((me.Nr, me.Np), np.nan)
+            for part in rows:
+                for i, a in part.items():
+                    me.A[i * BLK:(i + 1) * BLK] = a
+            assert sorted(i for part in rows for i in part) == list(range(me.Nr // BLK))
+            me.A[N, :N] = me.v[:N]
         got = np.tril(me.A[:N, :N])  # the COMPLETE factor is on every rank
         err_L = np.max(np.abs(got - L_ref)) / np.max(np.abs(L_ref))
         err_v = np.max(np.abs(me.A[N, :N] - v_ref)) / np.max(np.abs(v_ref))
@@ -178,12 +268,23 @@ def _free_port():
 @pytest.mark.parametrize("world,N,w", [(2, 300, 1), (2, 256, 2), (2, 130, 1), (3, 700, 2), (2, 1100, 4), (3, 900, 0),
                                        (3, 100, 0), (2, 128, 1), (4, 130, 2), (3, 384, 8)])
 def test_plan_replayed_with_numpy_blocks_over_gloo(world, N, w):
+    _replay(world, N, w, False)
+
+
+@pytest.mark.parametrize("world,N,w", [(2, 300, 1), (3, 700, 2), (2, 1100, 4), (3, 900, 0), (2, 128, 1), (4, 130, 2), (3, 1300, 3)])
+def test_plan_replayed_in_capacity_mode_with_own_rows_and_two_panel_buffers(world, N, w):
+    """The SAME plan with the capacity mode's storage (csrc/dist_capacity.hpp): own block rows + two panel buffers per rank;
+    the assembled factor, v and log-det against LAPACK -- and no update ever reads a panel buffer that has been refilled."""
+    _replay(world, N, w, True)
+
+
+def _replay(world, N, w, capacity):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, w, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, 3, w, out, capacity)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=180) for _ in range(world)]
