@@ -461,7 +461,8 @@ def roofline_block(tm, config):
     n_chol = max(int(tm["total_chol_gemm_launches"]), 1)
     out = {
         "bound": "mfma",
-        "kernel": "gemm_f64_kernel, the Cholesky's bulk trailing-update launches U1 / U2 (v_mfma_f64_16x16x4_f64 SYRK/GEMM)",
+        "kernel": "gemm_f64_dma_kernel (128 x 128 tiles, LDS-DMA staged): the Cholesky's bulk trailing-update launches "
+                  "(v_mfma_f64_16x16x4_f64 SYRK/GEMM)",
         "subset_note": "achieved / frac cover ONLY the Cholesky's bulk trailing updates (the launches the north star states its "
                        "MFMA target on); all_gemm_launches beside it covers every MFMA GEMM launch of the profiled evaluations",
         "achieved": round(chol_tf, 3),
@@ -560,7 +561,9 @@ def roofline_block(tm, config):
             out["traffic_is_stale"] = pt["stale"]
             out["traffic_kernel_sources_sha16"] = {"then": pt["kernel_sources_sha16_then"], "now": pt["kernel_sources_sha16_now"]}
         return out
-    pt = pmc_traffic(config, "gemm_f64_kernel<2, 2, 4, 4")  # the 128 x 128 instantiation the bulk updates run
+    pt = pmc_traffic(config, "gemm_f64_dma_kernel")  # the 128 x 128 kernel the bulk updates run
+    if pt is None or pt["flops_per_launch"] <= 0:
+        pt = pmc_traffic(config, "gemm_f64_kernel<2, 2, 4, 4")  # (summaries taken before round 4: the register-staged instantiation)
     if pt is not None and pt["flops_per_launch"] > 0:
         # the PMC passes count every launch of the 128x128 instantiation (bulk updates, solves, inverse, Sigma^-1,
         # predict: other launch sizes than the ones `achieved` is quoted on), so the bytes are scaled by flops

@@ -711,7 +711,8 @@ def test_bench_contract_single_process(gpu):
         _POOL[0].close()
         _POOL[0] = None
     root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, GUMBI_BENCH_DIST_N="2304", GUMBI_BENCH_CPU_SECONDS="2")
+    # (the host's config-size sections -- minutes of CPU time: a whole C2 fit over the oracle, a 50k dpotrf -- are switched off here)
+    env = dict(os.environ, GUMBI_BENCH_DIST_N="2304", GUMBI_BENCH_CPU_SECONDS="2", GUMBI_BENCH_NO_CPU_CONFIG_SIZE="1")
     out = subprocess.run([sys.executable, str(root / "bench.py"), "--config", "c2", "--steps", "1", "--warmup", "0",
                           "--map-evals", "4"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
