@@ -295,6 +295,10 @@ struct CovTileArgs {
   int32_t rows_packed;
   int32_t stream_stores;  // interior tiles use non-temporal stores (set by launch_cov for outputs of >= 1 GiB)
   int32_t strip;          // tiles per workgroup along the column index (set by launch_cov; see cov_tile_kernel)
+  // Small grids (launch_cov: <= 128 strips of ONE tile): every tile is shared by `gsplit` workgroups, each with a quarter (half)
+  // of its columns -- a direct-loop tile is a serial chain of 16 entry groups per thread (~30 us whatever the matrix), and a
+  // matrix of four block columns has ten tiles for 256 compute units.  1 = off.
+  int32_t gsplit;
 };
 
 // row of `out` where the tile row that starts at global row gi0 begins
@@ -425,7 +429,7 @@ __device__ __forceinline__ void cov_interior_tile(const CovTileArgs& a, const in
 // under -DGMB_KBUILD_DIRECT (the A/B switch for the matrix-pipe form).  Block-wide; ends with a barrier so that
 // the caller may go on to the next tile of its strip.
 template <int KIND, int NC>
-__device__ __forceinline__ void cov_general_tile(const CovTileArgs& a, const int tix, const int tjx) {
+__device__ __forceinline__ void cov_general_tile(const CovTileArgs& a, const int tix, const int tjx, const int part = 0, const int nparts = 1) {
   __shared__ double xj[NC][TILE];
   __shared__ double lj[MAX_LIN][TILE];
   __shared__ double li[MAX_LIN][TILE];
@@ -465,6 +469,8 @@ __device__ __forceinline__ void cov_general_tile(const CovTileArgs& a, const int
 
   const bool row_real = gi < a.rows.n;
   double* outp = a.out + cov_out_row(a, gi0) + il + (gj0 - a.j0 + jh * (TILE / 2)) * a.ldo;
+  // this workgroup's share of the thread's 64 columns (gsplit)
+  const int jj_lo = part * ((TILE / 2) / nparts), jj_hi = jj_lo + (TILE / 2) / nparts;
   double ndiag = 0.0;
   if (a.mode == COV_TRAIN && row_real) {
     ndiag = p.sigma2;
@@ -485,16 +491,16 @@ __device__ __forceinline__ void cov_general_tile(const CovTileArgs& a, const int
     };
     if (a.accumulate) {  // (tested once per tile, not once per entry)
 #pragma unroll 8
-      for (int jj = 0; jj < TILE / 2; ++jj) outp[(int64_t)jj * a.ldo] += entry(jj);
+      for (int jj = jj_lo; jj < jj_hi; ++jj) outp[(int64_t)jj * a.ldo] += entry(jj);
     } else {
 #pragma unroll 8
-      for (int jj = 0; jj < TILE / 2; ++jj) outp[(int64_t)jj * a.ldo] = entry(jj);
+      for (int jj = jj_lo; jj < jj_hi; ++jj) outp[(int64_t)jj * a.ldo] = entry(jj);
     }
   } else {
     // U entries at a time: the distance / sqrt / exp chains of the entries are independent and interleave (one entry after
     // the other this loop was a single dependent chain per thread: ~35 us per diagonal / boundary tile whatever the size)
     constexpr int U = NC <= 4 ? 4 : 2;
-    for (int jj0 = 0; jj0 < TILE / 2; jj0 += U) {
+    for (int jj0 = jj_lo; jj0 < jj_hi; jj0 += U) {
       double v_[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -605,8 +611,10 @@ __host__ __device__ __forceinline__ bool cov_decode_block(int ti, int tj, int st
 template <int KIND, int NC>
 __global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
   int tix, tj_lo, tj_hi;
+  const int gs = a.gsplit > 1 ? a.gsplit : 1;  // (strip == 1 then: launch_cov)
+  const int part = (int)(blockIdx.x % (unsigned)gs);
   if (!cov_decode_block(a.ti, a.tj, a.strip, a.tri_grid, a.row_first, a.row_stride,
-                        a.mode == COV_TRAIN && a.lower_only, (long long)blockIdx.x, &tix, &tj_lo, &tj_hi))
+                        a.mode == COV_TRAIN && a.lower_only, (long long)(blockIdx.x / (unsigned)gs), &tix, &tj_lo, &tj_hi))
     return;
   int tj_gen = tj_lo;  // first tile of the strip that goes through the direct loop
 #ifndef GMB_KBUILD_DIRECT
@@ -623,20 +631,20 @@ __global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
       const int tj_int = (int)(jend < tj_hi ? (jend > tj_lo ? jend : tj_lo) : tj_hi);
       if (tj_int > tj_lo) {
         const int tid = threadIdx.x;
-        const int64_t gj0 = a.j0 + (int64_t)tj_lo * TILE;
+        const int64_t gj0 = a.j0 + (int64_t)tj_lo * TILE + part * (TILE / gs);  // (gsplit: this workgroup's columns of the one tile)
         bool bad = tid < TILE && !(a.rows.xs[(int64_t)NC * a.rows.npad + gi0 + tid] < 1.0e150);
-        for (int j = tid; j < (tj_int - tj_lo) * TILE; j += 256)
+        for (int j = tid; j < (tj_int - tj_lo) * TILE / gs; j += 256)
           bad |= !(a.cols.xs[(int64_t)NC * a.cols.npad + gj0 + j] < 1.0e150);
         if (!__syncthreads_or(bad)) {  // all norms finite (and no coordinate absurdly far out)
-          if (a.stream_stores) cov_interior_tile<KIND, NC, true>(a, gi0, gj0, 8 * (tj_int - tj_lo));
-          else cov_interior_tile<KIND, NC, false>(a, gi0, gj0, 8 * (tj_int - tj_lo));
+          if (a.stream_stores) cov_interior_tile<KIND, NC, true>(a, gi0, gj0, 8 * (tj_int - tj_lo) / gs);
+          else cov_interior_tile<KIND, NC, false>(a, gi0, gj0, 8 * (tj_int - tj_lo) / gs);
           tj_gen = tj_int;
         }
       }
     }
   }
 #endif
-  for (int tjx = tj_gen; tjx < tj_hi; ++tjx) cov_general_tile<KIND, NC>(a, tix, tjx);
+  for (int tjx = tj_gen; tjx < tj_hi; ++tjx) cov_general_tile<KIND, NC>(a, tix, tjx, part, gs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -724,27 +732,41 @@ __global__ void predict_final_kernel(const double* part_mu, const double* part_s
   var[m] = kss[m] - as;
 }
 
-// v[i] = L[n + i*ld] (the y row of the factor), and |v|^2 -- summed in a fixed order (run to run, the same bits):
-// workgroup b leaves its partial sum in scal[1 + b]; the workgroup that finishes LAST (a counter in scal[40], zeroed
-// with the rest of the scalars at the start of every factorisation) adds the partials in index order into scal[0].
-// Launch with EXTRACT_V_BLOCKS workgroups; scal = the engine's scalar block + 1 ([0] |v|^2, [1..] partials).
+// v[i] = L[n + i*ld] (the y row of the factor), and |v|^2 -- summed in ONE fixed order, the same in every kernel that forms it
+// (this one behind a factorisation, eval_finish_kernel of eval_tiles.hpp inside a fused evaluation: same bits either way):
+// chunk c = rows 128 c .. 128 c + 127 is summed by a fixed two-wave tree (v_chunk_sum); partial b = the chunk sums of the chunks
+// c = b, b + 32, ... added in that order; |v|^2 = partials 0 .. 31 added in that order.  Workgroup b leaves its partial in
+// scal[1 + b]; the workgroup that finishes LAST (a counter in scal[40], zeroed with the rest of the scalars at the start of
+// every factorisation) adds them into scal[0].
+// Launch with EXTRACT_V_BLOCKS workgroups of 128 threads; scal = the engine's scalar block + 1 ([0] |v|^2, [1..] partials).
 constexpr int EXTRACT_V_BLOCKS = 32;
-__global__ __launch_bounds__(256) void extract_v_kernel(const double* L, int64_t ld, int64_t n,
-                                                        double* v, double* scal) {
-  __shared__ double red[4];
-  __shared__ int last;
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const double x = L[n + i * ld];
-    v[i] = x;
-    acc = fma(x, x, acc);
-  }
+// every thread of a 128-thread workgroup calls it with its x^2; thread 0 returns the chunk's sum (ends with a barrier)
+__device__ __forceinline__ double v_chunk_sum(double acc, double* red) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
+  const double s = red[0] + red[1];
+  __syncthreads();
+  return s;
+}
+__global__ __launch_bounds__(128) void extract_v_kernel(const double* L, int64_t ld, int64_t n,
+                                                        double* v, double* scal) {
+  __shared__ double red[2];
+  __shared__ int last;
+  double p = 0.0;
+  const int64_t nchunks = (n + TILE - 1) / TILE;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t i = c * TILE + threadIdx.x;
+    double x = 0.0;
+    if (i < n) {
+      x = L[n + i * ld];
+      v[i] = x;
+    }
+    p += v_chunk_sum(x * x, red);
+  }
   if (threadIdx.x == 0) {
-    atomicExch((unsigned long long*)&scal[1 + blockIdx.x], (unsigned long long)__double_as_longlong((red[0] + red[1]) + (red[2] + red[3])));
+    atomicExch((unsigned long long*)&scal[1 + blockIdx.x], (unsigned long long)__double_as_longlong(p));
     __threadfence();
     last = atomicAdd((unsigned int*)&scal[40], 1u) == gridDim.x - 1;
     if (last) {

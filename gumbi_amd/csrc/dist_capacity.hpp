@@ -255,7 +255,7 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   int32_t info = 0;
   if (!bad.rc) {
     // |v|^2 with the single engine's fixed-order reduction (row "N" of a 1-row matrix: the assembled v itself)
-    hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(256), 0, e->stream, e->dv - e->N, (int64_t)1, e->N, e->dv, e->dscal + 1);
+    hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(TILE), 0, e->stream, e->dv - e->N, (int64_t)1, e->N, e->dv, e->dscal + 1);
     if (tc) tc->stop();
     hipError_t st = hipGetLastError();
     if (st == hipSuccess) st = hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream);

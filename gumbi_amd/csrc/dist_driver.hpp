@@ -413,7 +413,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   double hs[2] = {0.0, 0.0};
   int32_t info = 0;
   if (!bad.rc) {
-    hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv, e->dscal + 1);
+    hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(TILE), 0, e->stream, e->dA, e->ld, e->N, e->dv, e->dscal + 1);
     if (tc) tc->stop();
     hipError_t st = hipGetLastError();
     if (st == hipSuccess) st = hipMemcpyAsync(hs, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream);

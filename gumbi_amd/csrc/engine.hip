@@ -26,6 +26,7 @@
 #include <functional>
 #include <unordered_map>
 #include <mutex>
+#include <memory>
 #include <vector>
 
 #include "../../include/gumbi_hip.h"
@@ -56,6 +57,12 @@ struct EventPair {
 };
 
 }  // namespace
+
+constexpr int GACC_REGION = 64 + MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS + 64;  // gradient accumulators of one covariance term
+constexpr int GACC_DOUBLES = (1 + GMB_MAX_COREG) * GACC_REGION;  // additive models: one region per term
+// the engine's scalar block, ONE allocation (one memset per evaluation): [0, 64) scalars ([0] log-det, [1] |v|^2, [2 ..] the partials
+// and arrival counter of the |v|^2 sum) | [64, 72) the failure index (int32) | [72, ...) the gradient accumulators + 64 of scratch
+constexpr int SCAL_INFO_AT = 64, SCAL_GACC_AT = 72, SCAL_DOUBLES = SCAL_GACC_AT + GACC_DOUBLES + 64;
 
 struct gmb_engine {
   int device = 0;
@@ -98,8 +105,8 @@ struct gmb_engine {
   std::vector<double> hnoise;
 
   // factorisation results
-  double* dscal = nullptr;  // [0] logdet, [1] |v|^2, [2..] gradient partials
-  int32_t* dinfo = nullptr;
+  double* dscal = nullptr;  // the scalar block (SCAL_DOUBLES): [0] logdet, [1] |v|^2, [2..] partials of that sum
+  int32_t* dinfo = nullptr; // = dscal + SCAL_INFO_AT (and dgpart = dscal + SCAL_GACC_AT)
   double* dv = nullptr;
   bool factored = false;
   bool factor_consumed = false;  // U = L^-T sits in the factor buffer's diagonal tiles (multi-GPU gradient; or a failed one)
@@ -198,9 +205,18 @@ struct gmb_engine {
     double scal[2];
     int32_t info;
     uint32_t abort;
+    double gacc[GACC_DOUBLES];  // gmb_evaluate's light path: the gradient accumulators land here too (eval_land_kernel)
   };
   HostLanding* hl = nullptr;
+  HostLanding* hl_dev = nullptr;  // the same memory as the device addresses it
   hipEvent_t fe[4] = {nullptr, nullptr, nullptr, nullptr};  // K-build begin / end, Cholesky begin / end
+  // gmb_evaluate with a gradient on the fused launch (`light`): one memset for scalars + accumulators, no copies in between --
+  // eval_land_kernel writes everything the host wants into hl at the end -- and, below 4096 rows and without gmb_set_profiling,
+  // no phase events (six event records were ~30 us of a 380 us evaluation at N = 392)
+  bool eval_call = false;     // set by gmb_evaluate around its factorize_enqueue
+  bool light = false;         // the evaluation in flight runs that way
+  bool gacc_zeroed = false;   // ... and its memset covered the accumulators (grad_reduce skips its own)
+  bool fe_recorded = false;   // fe[] belong to the factorisation in flight
   // persistent evaluation launch (eval_tiles.hpp): L^-T by rows and Sigma^-1 as tile tasks, fused with the tile Cholesky
   // when the caller asks for the gradient together with the factorisation (gmb_evaluate)
   int grad_scheme = -1;        // -1 = by size; 0 = launch tree (winv_levels); 1 = tile tasks behind the factorisation; 2 = fused
@@ -214,7 +230,7 @@ struct gmb_engine {
   double* dApart = nullptr;    // partial products U(r,c) v_c
   int64_t cap_apart = 0;
   bool et_fused = false;       // the factorisation in flight carries INV / ZZ tasks: Sigma^-1 (dW) and the alpha parts come with it
-  int et_min_blocks = 2;       // smallest matrix (in 128-blocks) whose MAP evaluation runs as the fused launch by default
+  int et_min_blocks = 1;       // smallest matrix (in 128-blocks) whose MAP evaluation runs as the fused launch by default
   int tiles_min_blocks = 6, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default (measured faster from N = 768 on)
   int tiles_trsm_min_blocks = 16;                    // ... and the tile triangular solve of the predict path (measured from N = 2560 on)
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
@@ -608,7 +624,7 @@ long long cov_grid_blocks(int ti, int tj, int strip, int tri_grid, int row_first
 
 template <int KIND>
 int launch_cov_nc(gmb_engine* e, const CovTileArgs& a, int nc) {
-  const long long nb = cov_grid_blocks(a.ti, a.tj, a.strip, a.tri_grid, a.row_first, a.row_stride);
+  const long long nb = cov_grid_blocks(a.ti, a.tj, a.strip, a.tri_grid, a.row_first, a.row_stride) * (a.gsplit > 1 ? a.gsplit : 1);
   if (nb <= 0) return GMB_OK;
   const dim3 grid((unsigned)nb), block(256);
   switch (nc) {
@@ -629,6 +645,8 @@ int launch_cov(gmb_engine* e, const CovTileArgs& a_in) {
   a.stream_stores = tiles * TILE * TILE * 8.0 >= 1073741824.0 / (a.row_stride > 0 ? a.row_stride : 1);  // by the whole matrix
   // tiles per workgroup: enough strips left to fill the chip's ~800 workgroup slots several times over
   a.strip = e->cov_strip > 0 ? e->cov_strip : (tiles >= 32768.0 ? 4 : tiles >= 12288.0 ? 2 : 1);
+  // small grids: four workgroups per tile (N = 392: the build's one launch 29.6 -> 11.8 us; tools/gpu_timeline.sh)
+  a.gsplit = (a.strip == 1 && cov_grid_blocks(a.ti, a.tj, 1, a.tri_grid, a.row_first, a.row_stride) <= 128) ? 4 : 1;
   switch (a.p.kind) {
     case GMB_EXPQUAD: return launch_cov_nc<0>(e, a, e->nc_pad);
     case GMB_MATERN52: return launch_cov_nc<1>(e, a, e->nc_pad);
@@ -1026,7 +1044,7 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
   if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
   if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
   if ((rc = ensure(e, &e->dUdiag, &e->cap_udiag, (int64_t)nct * TILE * TILE))) return rc;
-  if ((rc = ensure(e, &e->dApart, &e->cap_apart, (int64_t)nct * nct * TILE))) return rc;
+  if ((rc = ensure(e, &e->dApart, &e->cap_apart, (int64_t)nct * nct * TILE + nct))) return rc;  // (+ the partials of |v|^2)
   if ((rc = grad_workspace(e))) return rc;
   HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
   // a factor that is final already: every tile flag reads "final" (any non-zero word)
@@ -1087,7 +1105,10 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
 #endif
   ev_end(e);
   HIP_TRY(e, hipGetLastError());
-  hipLaunchKernelGGL(alpha_from_parts_kernel, dim3(nct), dim3(TILE), 0, e->cur, e->dApart, nct, e->N, e->dalpha);
+  if (with_chol)  // ... and v = L^-1 y with |v|^2, which gmb_factorize takes with extract_v_kernel
+    hipLaunchKernelGGL(eval_finish_kernel, dim3(nct), dim3(TILE), 0, e->cur, e->dApart, nct, e->N, e->dalpha, e->dA, e->ld, e->dv,
+                       e->dApart + (int64_t)nct * nct * TILE, e->dscal + 1);
+  else hipLaunchKernelGGL(alpha_from_parts_kernel, dim3(nct), dim3(TILE), 0, e->cur, e->dApart, nct, e->N, e->dalpha);
   HIP_TRY(e, hipGetLastError());
   e->ct_used = true;
   e->ct_ntasks = ntasks;
@@ -1459,7 +1480,8 @@ int launch_grad_nc(gmb_engine* e, const GradArgs& a_in, int nblocks) {
   const size_t lds = grad_lds_bytes(e->nc_pad, a_in.p.n_lin, a_in.p.n_tab);
   GradArgs a = a_in;
   a.part_block0 = 0;
-  const dim3 grid0(a.split ? a.general_tiles : nblocks);  // (split: one tile of the general-tile list per workgroup)
+  const int gs = a.gsplit > 1 ? a.gsplit : 1;
+  const dim3 grid0((a.split ? a.general_tiles : nblocks) * gs);  // (split: one tile of the general-tile list per gs workgroups)
   switch (e->nc_pad) {
     case 1: hipLaunchKernelGGL((grad_tile_kernel<KIND, 1>), grid0, block, lds, e->stream, a); break;
     case 2: hipLaunchKernelGGL((grad_tile_kernel<KIND, 2>), grid0, block, lds, e->stream, a); break;
@@ -1469,7 +1491,7 @@ int launch_grad_nc(gmb_engine* e, const GradArgs& a_in, int nblocks) {
   }
   if constexpr (KIND <= 2) {
     if (a.split) {  // the interior tiles on the matrix pipe: runs of the full enumeration, the partial vectors behind the first set
-      a.part_block0 = a.general_tiles;
+      a.part_block0 = a.general_tiles * gs;
       switch (e->nc_pad) {
         case 1: hipLaunchKernelGGL((grad_interior_kernel<KIND, 1>), grid, block, 0, e->stream, a); break;
         case 2: hipLaunchKernelGGL((grad_interior_kernel<KIND, 2>), grid, block, 0, e->stream, a); break;
@@ -1482,9 +1504,6 @@ int launch_grad_nc(gmb_engine* e, const GradArgs& a_in, int nblocks) {
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
 }
-
-constexpr int GACC_REGION = 64 + MAX_TABS * GMB_MAX_LEVELS * GMB_MAX_LEVELS + 64;  // accumulators of one term
-constexpr int GACC_DOUBLES = (1 + GMB_MAX_COREG) * GACC_REGION;  // additive models: one region per term
 
 // ---- gradient building blocks ---------------------------------------------------------------------
 // (a) grad_sigma_inv_rows: block rows shard, shard + nshards, ... of Sigma^-1 = U U^T (lower triangle) from
@@ -1499,8 +1518,7 @@ int grad_workspace(gmb_engine* e) {
     if ((rc = alloc(e, &e->dalpha, e->Np))) return rc;
     e->cap_pts_alpha = e->Np;
   }
-  if (!e->dgpart && (rc = alloc(e, &e->dgpart, (int64_t)GACC_DOUBLES + 64))) return rc;
-  return GMB_OK;
+  return GMB_OK;  // (the accumulators live in the engine's scalar block)
 }
 
 int grad_sigma_inv_rows(gmb_engine* e, int shard, int nshards, double* Z, int64_t ldz, bool packed) {
@@ -1532,7 +1550,8 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
   const gmb_kernel_spec& s = e->spec;
   const int nt = (int)(e->Np / TILE);
   int rc;
-  HIP_TRY(e, hipMemsetAsync(e->dgpart, 0, (GACC_DOUBLES + 64) * sizeof(double), e->stream));
+  if (!e->gacc_zeroed) HIP_TRY(e, hipMemsetAsync(e->dgpart, 0, (GACC_DOUBLES + 64) * sizeof(double), e->stream));
+  e->gacc_zeroed = false;
   const int n_ls = s.ard ? s.n_cont : 1;
   long long total = 0;
   for (int i = shard; i < nt; i += nshards) total += i + 1;
@@ -1583,13 +1602,16 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
     const bool last_ragged_owned = e->Np > e->N && (nt - 1 - shard) % nshards == 0 && nt - 1 >= shard;
     a.general_tiles = a.n_owned_rows + (last_ragged_owned ? nt - 1 : 0);
     if (a.general_tiles == 0) a.split = 0;
-    const int nvec = a.split ? a.general_tiles + grid : grid;  // partial vectors the pass leaves
+    // small launches: four workgroups per direct-loop tile (GradArgs::gsplit)
+    const int ndirect = a.split ? a.general_tiles : grid;  // runs / list tiles of grad_tile_kernel
+    a.gsplit = ndirect <= 128 ? 4 : 1;
+    const int nvec = a.split ? ndirect * a.gsplit + grid : ndirect * a.gsplit;  // partial vectors the pass leaves
     if (grid > 0) {
       if ((rc = ensure(e, &e->dgred, &e->cap_gred, (int64_t)nvec * a.part_stride))) return rc;
       a.part = e->dgred;
       if (big > 0) {
-        if ((rc = ensure(e, &e->dgbig, &e->cap_gbig, (int64_t)grid * 4 * big))) return rc;
-        HIP_TRY(e, hipMemsetAsync(e->dgbig, 0, (size_t)grid * 4 * big * sizeof(double), e->stream));
+        if ((rc = ensure(e, &e->dgbig, &e->cap_gbig, (int64_t)ndirect * a.gsplit * 4 * big))) return rc;
+        HIP_TRY(e, hipMemsetAsync(e->dgbig, 0, (size_t)ndirect * a.gsplit * 4 * big * sizeof(double), e->stream));
         a.big = e->dgbig;
       }
       switch (tr.cp.kind) {
@@ -1626,7 +1648,7 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
             rb.dst[rb.n] = tab_acc_off[j];
             ++rb.n;
           }
-        hipLaunchKernelGGL(grad_sum_partials_kernel, dim3(big), dim3(256), 0, e->stream, e->dgbig, grid * 4, (int64_t)big, rb, acc);
+        hipLaunchKernelGGL(grad_sum_partials_kernel, dim3(big), dim3(256), 0, e->stream, e->dgbig, ndirect * a.gsplit * 4, (int64_t)big, rb, acc);
       }
       HIP_TRY(e, hipGetLastError());
     }
@@ -1641,6 +1663,29 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
       (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &e->terms[0].pa)))
     return rc;
   h.assign(GACC_DOUBLES, 0.0);
+  if (e->light) {
+    // gmb_evaluate on the fused launch: scalars, failure index, abort word and the used head of every accumulator region go to
+    // the pinned landing in one launch; grad_accumulate hands them on after its synchronisation
+    EvalLandArgs la{};
+    la.scal = e->dscal;
+    la.info = e->dinfo;
+    la.abort = e->ct_used ? e->dct + 1 : nullptr;
+    la.gacc = e->dgpart;
+    la.nterms = (int)e->terms.size();
+    la.region = GACC_REGION;
+    for (size_t t = 0; t < e->terms.size(); ++t) {
+      int used = 64;
+      for (int j = 0; j < e->terms[t].cp.n_tab; ++j) used += e->terms[t].cp.tab_levels[j] * e->terms[t].cp.tab_levels[j];
+      la.used[t] = std::min(used + 64, GACC_REGION);  // (+ the diagonal terms' slots behind the tables)
+    }
+    la.out_scal = e->hl_dev->scal;
+    la.out_info = &e->hl_dev->info;
+    la.out_abort = &e->hl_dev->abort;
+    la.out_gacc = e->hl_dev->gacc;
+    hipLaunchKernelGGL(eval_land_kernel, dim3(1), dim3(256), 0, e->stream, la);
+    HIP_TRY(e, hipGetLastError());
+    return GMB_OK;
+  }
   HIP_TRY(e, hipMemcpyAsync(h.data(), e->dgpart, GACC_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
                             e->stream));
   return GMB_OK;
@@ -1669,7 +1714,9 @@ int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
   if (e->et_fused || grad_by_tiles(e)) {
     // Sigma^-1 and the alpha parts come from the persistent evaluation launch: already enqueued with the factorisation
     // (gmb_evaluate), or launched here behind a factor that is final.  L stays intact: nothing to save or restore.
-    PhaseTimer tgt(e);
+    const bool light = e->light && e->et_fused;  // (gmb_evaluate: results land through eval_land_kernel, see grad_reduce)
+    const bool timed = !(light && !e->fe_recorded);
+    std::unique_ptr<PhaseTimer> tgt(timed ? new PhaseTimer(e) : nullptr);
     bool own_launch = false;
     if (!e->et_fused) {
       e->cur = e->stream;
@@ -1677,13 +1724,22 @@ int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
       own_launch = true;
     }
     e->et_fused = false;
-    if ((rc = grad_reduce(e, 0, 1, e->dW, e->Np, false, h))) return rc;
-    tgt.stop();
+    e->light = light;
+    rc = grad_reduce(e, 0, 1, e->dW, e->Np, false, h);
+    e->light = false;
+    if (rc) return rc;
+    if (tgt) tgt->stop();
     uint32_t ab = 0;
     if (own_launch) HIP_TRY(e, hipMemcpyAsync(&ab, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    tm.grad_ms = tgt.ms();
+    if (tgt) tm.grad_ms = tgt->ms();
     ev_collect(e);
+    if (light) {
+      for (size_t t = 0; t < e->terms.size(); ++t)
+        std::copy(e->hl->gacc + t * GACC_REGION, e->hl->gacc + (t + 1) * GACC_REGION, h.begin() + t * GACC_REGION);
+      e->have_alpha = true;
+      return GMB_OK;  // (abort word, failure index: factorize_finish, which gmb_evaluate calls next)
+    }
     if (ab != 0) return fail(e, GMB_EHIP, "tile inverse: a workgroup waited longer than its time-out for a tile (launch abandoned)");
     e->have_alpha = true;
     return GMB_OK;
@@ -1958,12 +2014,13 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->wg_slots = 2LL * prop.multiProcessorCount;
-  if (hipMalloc((void**)&e->dscal, 64 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&e->dstat, (size_t)(DIST_HEADER + DIST_MAX_PAYLOAD) * (1 + DIST_MAX_WORLD) * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&e->dinfo, sizeof(int32_t)) != hipSuccess) {
+  if (hipMalloc((void**)&e->dscal, (size_t)SCAL_DOUBLES * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&e->dstat, (size_t)(DIST_HEADER + DIST_MAX_PAYLOAD) * (1 + DIST_MAX_WORLD) * sizeof(double)) != hipSuccess) {
     gmb_destroy(e);
     return GMB_ENOMEM;
   }
+  e->dinfo = reinterpret_cast<int32_t*>(e->dscal + SCAL_INFO_AT);
+  e->dgpart = e->dscal + SCAL_GACC_AT;
   *out = e;
   return GMB_OK;
 }
@@ -2000,8 +2057,8 @@ void gmb_destroy(gmb_engine* e) {
   for (int a = 0; a < 3; ++a)
     if (e->aux[a]) (void)hipStreamSynchronize(e->aux[a]);
   void* ptrs[] = {e->dct, e->dct_trace, e->dstat, e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
-                  e->dnoise, e->dscal, e->dinfo, e->dv, e->dV, e->dXs, e->txs, e->txl,
-                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgpart, e->dgred, e->dgbig, e->det_tasks, e->dUdiag, e->dApart,
+                  e->dnoise, e->dscal, e->dv, e->dV, e->dXs, e->txs, e->txl,
+                  e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgred, e->dgbig, e->det_tasks, e->dUdiag, e->dApart,
                   e->dAown, e->dPanel};
   if (e->cap_A == 0) ptrs[11] = nullptr;  // (e->dA may be a virtual base of the capacity driver: nothing of ours to free)
   for (void* p : ptrs)
@@ -2178,16 +2235,6 @@ int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
   tm.chol_gemm_launches = 0;
   for (auto& ev : e->fe)
     if (!ev) HIP_TRY(e, hipEventCreate(&ev));
-  HIP_TRY(e, hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream));
-  HIP_TRY(e, hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream));
-
-  // 1. covariance build: lower-triangular tiles of Sigma, y row, identity padding
-  HIP_TRY(e, hipEventRecord(e->fe[0], e->stream));
-  if ((rc = build_sigma(e, e->dA, e->ld))) return rc;
-  HIP_TRY(e, hipEventRecord(e->fe[1], e->stream));
-  // 2. Cholesky
-  HIP_TRY(e, hipEventRecord(e->fe[2], e->stream));
-  e->chol_update_kind = 7;
   if (e->panel_auto) {
     // wider panels for larger matrices: a k = 1024 trailing update pays its C read-modify-write and
     // epilogue per 1024 of contraction; measured at N = 60k: 8 blocks 58.0, 16: 62.2, 32: 63.9 TF/s
@@ -2200,30 +2247,53 @@ int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
                                                                  nblocks <= e->tiles_max_blocks));
   const bool masked = !tiles && e->lookahead && e->aux_shared && e->Np / TILE > e->panel_blocks &&
                       (e->chol_scheme == 2 || (e->chol_scheme < 0 && e->Np / TILE <= e->masked_max_blocks));
+  // the fused evaluation launch pays at every size (per evaluation, stream schedules -> fused: N = 100: 0.21 -> 0.14 ms, N = 392:
+  // 0.44 -> 0.27, N = 1000: 0.76 -> 0.45; tools/gpu_small_eval.py), the tile Cholesky on its own only from six block columns
+  const bool fused = with_grad && !e->naive_leaf && (e->chol_scheme == 3 || e->chol_scheme < 0) && e->grad_scheme != 0 && e->grad_scheme != 1 &&
+                     nblocks <= e->tiles_max_blocks && (e->grad_scheme == 2 ? nblocks >= 1 : nblocks >= e->et_min_blocks);
+  // gmb_evaluate on the fused launch: everything the host wants lands through eval_land_kernel at the end of the gradient
+  e->light = e->eval_call && fused;
+  const bool events = !(e->light && !e->profiling && e->Np < 4096);
+  e->fe_recorded = events;
+  // scalars + failure index (+ the gradient's accumulators): one memset
+  HIP_TRY(e, hipMemsetAsync(e->dscal, 0, (size_t)(e->light ? SCAL_DOUBLES : SCAL_GACC_AT) * sizeof(double), e->stream));
+  e->gacc_zeroed = e->light;
+
+  // 1. covariance build: lower-triangular tiles of Sigma, y row, identity padding
+  if (events) HIP_TRY(e, hipEventRecord(e->fe[0], e->stream));
+  if ((rc = build_sigma(e, e->dA, e->ld))) return rc;
+  if (events) HIP_TRY(e, hipEventRecord(e->fe[1], e->stream));
+  // 2. Cholesky
+  if (events) HIP_TRY(e, hipEventRecord(e->fe[2], e->stream));
+  e->chol_update_kind = 7;
   e->ct_used = false;
   e->ct_traced = false;
   e->cur = e->stream;
   e->et_fused = false;
-  // the fused evaluation launch pays from two block columns on (N = 200: 0.32 -> 0.30 ms per evaluation, N = 392: 0.50 -> 0.39,
-  // N = 640: 0.58 -> 0.42; tools/gpu_small_eval.py), the tile Cholesky on its own only from six
-  const bool fused = with_grad && !e->naive_leaf && (e->chol_scheme == 3 || e->chol_scheme < 0) && e->grad_scheme != 0 && e->grad_scheme != 1 &&
-                     nblocks <= e->tiles_max_blocks && (e->grad_scheme == 2 ? nblocks >= 1 : nblocks >= e->et_min_blocks);
   if (fused) {
-    // the gradient's inverse and Sigma^-1 ride in the factorisation's launch (eval_tiles.hpp)
+    // the gradient's inverse and Sigma^-1 ride in the factorisation's launch (eval_tiles.hpp); v = L^-1 y (row N of the factor)
+    // and |v|^2 come out of the launch that adds up alpha
     if ((rc = eval_tiles(e, true))) return rc;
     e->et_fused = true;
-  } else if ((rc = tiles ? chol_tiles(e) : masked ? chol_lookahead_masked(e) : chol_cols(e, 0, nblocks, (int)(e->Nr / TILE)))) return rc;
-  // 3. v = L^-1 y is row N of the factor
-  hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(256), 0, e->stream, e->dA, e->ld, e->N, e->dv,
-                     e->dscal + 1);
-  HIP_TRY(e, hipEventRecord(e->fe[3], e->stream));
+  } else {
+    if ((rc = tiles ? chol_tiles(e) : masked ? chol_lookahead_masked(e) : chol_cols(e, 0, nblocks, (int)(e->Nr / TILE)))) return rc;
+    // 3. v = L^-1 y is row N of the factor
+    hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(TILE), 0, e->stream, e->dA, e->ld, e->N, e->dv,
+                       e->dscal + 1);
+  }
+  if (events) HIP_TRY(e, hipEventRecord(e->fe[3], e->stream));
   HIP_TRY(e, hipGetLastError());
-  if (!e->hl) HIP_TRY(e, hipHostMalloc((void**)&e->hl, sizeof(gmb_engine::HostLanding), hipHostMallocDefault));
+  if (!e->hl) {
+    HIP_TRY(e, hipHostMalloc((void**)&e->hl, sizeof(gmb_engine::HostLanding), hipHostMallocDefault));
+    HIP_TRY(e, hipHostGetDevicePointer((void**)&e->hl_dev, e->hl, 0));
+  }
   e->hl->info = 0;
   e->hl->abort = 0;
-  HIP_TRY(e, hipMemcpyAsync(e->hl->scal, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(&e->hl->info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-  if (e->ct_used) HIP_TRY(e, hipMemcpyAsync(&e->hl->abort, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  if (!e->light) {
+    HIP_TRY(e, hipMemcpyAsync(e->hl->scal, e->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&e->hl->info, e->dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (e->ct_used) HIP_TRY(e, hipMemcpyAsync(&e->hl->abort, e->dct + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  }
   e->fact_in_flight = true;
   return GMB_OK;
 }
@@ -2240,8 +2310,8 @@ int factorize_finish(gmb_engine* e) {
     return fail(e, GMB_EHIP, "tile Cholesky: a workgroup waited longer than its time-out for a tile (launch abandoned)");
   }
   float t = 0.f;
-  if (hipEventElapsedTime(&t, e->fe[0], e->fe[1]) == hipSuccess) tm.kbuild_ms = t;
-  if (hipEventElapsedTime(&t, e->fe[2], e->fe[3]) == hipSuccess) tm.chol_ms = t;
+  if (e->fe_recorded && hipEventElapsedTime(&t, e->fe[0], e->fe[1]) == hipSuccess) tm.kbuild_ms = t;
+  if (e->fe_recorded && hipEventElapsedTime(&t, e->fe[2], e->fe[3]) == hipSuccess) tm.chol_ms = t;
   tm.kbuild_bytes = 8.0 * (double)e->N * (double)(e->N + 1) / 2.0 +
                     8.0 * (double)e->N * (double)(e->spec.n_cont + 1);
   ev_collect(e);
@@ -2291,14 +2361,29 @@ int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, do
   if (!e || !nlml) return GMB_EINVAL;
   int rc = gmb_set_theta(e, theta, n);
   if (rc) return rc;
-  if ((rc = factorize_enqueue(e, grad != nullptr))) return rc;
+  e->eval_call = grad != nullptr;
+  rc = factorize_enqueue(e, grad != nullptr);
+  e->eval_call = false;
+  if (rc) {
+    e->light = false;
+    return rc;
+  }
   int rc_grad = GMB_OK;
   std::vector<double> h;
   if (grad) {
     // the gradient's launches follow the factorisation's on the same stream with no host round trip in between; if the
     // factorisation turns out to have failed they ran on garbage and their result is dropped below
     e->factored = true;
+    const bool light = e->light;
     rc_grad = grad_accumulate(e, h);
+    e->light = false;
+    if (rc_grad && light) {  // nothing has landed on the host: there is no factorisation to look at
+      (void)hipStreamSynchronize(e->stream);
+      e->factored = false;
+      e->fact_in_flight = false;
+      e->et_fused = false;
+      return rc_grad;
+    }
   }
   if ((rc = factorize_finish(e))) {
     // the gradient ran on garbage: nothing of it may outlive this call (gmb_copy_alpha checks have_alpha only)

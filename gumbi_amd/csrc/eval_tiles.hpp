@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "chol_tiles.hpp"
+#include "covariance.hpp"
 
 namespace gmb {
 
@@ -607,6 +608,66 @@ __global__ __launch_bounds__(128) void alpha_from_parts_kernel(const double* __r
   for (int c = r; c < nct; ++c) s += apart[((int64_t)r * nct + c) * TILE + i];
   const int64_t row = (int64_t)r * TILE + i;
   if (row < n) alpha[row] = s;
+}
+
+// The same, and in the same launch what extract_v_kernel does behind a factorisation: v = row N of the factor and |v|^2 in
+// extract_v_kernel's summation order (same bits): block r leaves the sum of chunk r in vpart[r]; the block that finishes LAST
+// forms the 32 partials (chunks b, b + 32, ... in order) and adds them in index order into scal[0]; scal[40] is the arrival
+// counter (zeroed with the engine's scalars before the factorisation).
+__global__ __launch_bounds__(128) void eval_finish_kernel(const double* __restrict__ apart, int nct, int64_t n, double* __restrict__ alpha,
+                                                          const double* __restrict__ L, int64_t ld, double* __restrict__ v, double* vpart,
+                                                          double* scal) {
+  __shared__ double red[2];
+  const int r = blockIdx.x, i = threadIdx.x;
+  double s = 0.0;
+  for (int c = r; c < nct; ++c) s += apart[((int64_t)r * nct + c) * TILE + i];
+  const int64_t row = (int64_t)r * TILE + i;
+  double x = 0.0;
+  if (row < n) {
+    alpha[row] = s;
+    x = L[n + row * ld];
+    v[row] = x;
+  }
+  const double chunk = v_chunk_sum(x * x, red);
+  if (i == 0) {
+    atomicExch((unsigned long long*)&vpart[r], (unsigned long long)__double_as_longlong(chunk));
+    __threadfence();
+    if (atomicAdd((unsigned int*)&scal[40], 1u) == gridDim.x - 1) {
+      __threadfence();
+      double t = 0.0;
+      for (unsigned b = 0; b < (unsigned)EXTRACT_V_BLOCKS; ++b) {
+        double p = 0.0;
+        for (unsigned c = b; c < gridDim.x; c += EXTRACT_V_BLOCKS)
+          p += __longlong_as_double((long long)atomicAdd((unsigned long long*)&vpart[c], 0ull));  // read at the L2
+        t += p;
+      }
+      scal[0] = t;
+    }
+  }
+}
+
+// What the host wants from one evaluation, gathered by ONE small launch into pinned host memory the device writes directly
+// (instead of four device-to-host copies, one of them into pageable memory): log-det and |v|^2, the failure index, the tile
+// launch's abort word, and the used head of every term's gradient accumulator region.
+struct EvalLandArgs {
+  const double* scal;    // [0] log-det, [1] |v|^2
+  const int32_t* info;
+  const uint32_t* abort; // may be null
+  const double* gacc;    // accumulator regions, `region` doubles apart
+  int32_t nterms, region;
+  int32_t used[8];       // doubles to take from the head of each region
+  double* out_scal;      // host: 2 doubles
+  int32_t* out_info;
+  uint32_t* out_abort;
+  double* out_gacc;      // host: regions at the same offsets
+};
+__global__ __launch_bounds__(256) void eval_land_kernel(EvalLandArgs a) {
+  const int t = threadIdx.x;
+  if (t < 2) a.out_scal[t] = a.scal[t];
+  if (t == 2) *a.out_info = *a.info;
+  if (t == 3) *a.out_abort = a.abort ? __hip_atomic_load(a.abort, CT_RLX_AGENT) : 0u;
+  for (int q = 0; q < a.nterms; ++q)
+    for (int i = t; i < a.used[q]; i += 256) a.out_gacc[(int64_t)q * a.region + i] = a.gacc[(int64_t)q * a.region + i];
 }
 
 // Host side: the task list.  `with_chol`: the factorisation's tile tasks are part of the launch (column c's tasks, then the

@@ -57,6 +57,10 @@ struct GradArgs {
   int32_t split, part_block0;
   int32_t n_owned_rows;  // split, MODE 0: block rows of this shard (its diagonal tiles lead the general-tile list)
   int32_t general_tiles; // ... and the length of that list = grid of the MODE 0 launch
+  // gsplit (grad_tile_kernel; small launches): every run / list tile of the direct loops is shared by `gsplit` workgroups, each
+  // with its share of the thread's 64 columns (a direct-loop tile is a serial chain of 16 entry groups per thread, ~27 us
+  // whatever the matrix).  Workgroup b = run (b / gsplit), share (b % gsplit); one partial vector per workgroup.  1 = off.
+  int32_t gsplit;
 };
 
 constexpr int GRAD_SMALL = 16 + 2 + MAX_LIN;                 // ls.. | eta | tau | c..
@@ -365,7 +369,10 @@ __device__ __forceinline__ void grad_tile_body(const GradArgs& a) {
 
   // this workgroup's run of lower-triangle tile pairs (ti >= tj), enumerated block row by owned block row
   // (closed form: owned row m = (tix - row_first) / row_stride is preceded by m (row_first + 1) + row_stride m (m - 1) / 2 tiles)
-  long long t_begin = (long long)blockIdx.x * a.per;
+  const int gs = a.gsplit > 1 ? a.gsplit : 1;
+  const int bidx = (int)(blockIdx.x / (unsigned)gs), share = (int)(blockIdx.x % (unsigned)gs);
+  const int jj_lo = share * ((TILE / 2) / gs), jj_hi = jj_lo + (TILE / 2) / gs;
+  long long t_begin = (long long)bidx * a.per;
   long long t_end = t_begin + a.per;
   t_end = t_end < a.total_tiles ? t_end : a.total_tiles;
   // MODE 0 beside an interior launch: ONE tile per workgroup from the short list of the tiles that launch leaves -- the
@@ -373,7 +380,7 @@ __device__ __forceinline__ void grad_tile_body(const GradArgs& a) {
   // (As runs of the full enumeration the ~390 tiles of C3's last row fell to eight workgroups: 2.7 ms for 0.5 % of the work.)
   int list_tix = -1, list_tjx = -1;
   if (MODE == 0 && a.split) {
-    const int b = (int)blockIdx.x;
+    const int b = bidx;
     if (b < a.n_owned_rows) {
       list_tix = list_tjx = a.row_first + b * a.row_stride;
     } else {
@@ -436,7 +443,7 @@ __device__ __forceinline__ void grad_tile_body(const GradArgs& a) {
     if (fast) {
       const int jb = jh * (TILE / 2);
 #pragma unroll 4
-      for (int jj = 0; jj < TILE / 2; ++jj) {
+      for (int jj = jj_lo; jj < jj_hi; ++jj) {
         const double mm = zp[(int64_t)jj * a.ldz] - ai * aj[jb + jj];  // 2 * M_ij
         double d2[NC];
         double r2 = 0.0;
@@ -464,11 +471,11 @@ __device__ __forceinline__ void grad_tile_body(const GradArgs& a) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t gj = gj0 + jh * (TILE / 2) + jj0 + u;
-        znext[u] = (jj0 < TILE / 2 && row_real && gj < a.pts.n && gj <= gi) ? zp[(int64_t)(jj0 + u) * a.ldz] : 0.0;
+        znext[u] = (jj0 < jj_hi && row_real && gj < a.pts.n && gj <= gi) ? zp[(int64_t)(jj0 + u) * a.ldz] : 0.0;
       }
     };
-    load_z_group(fast ? TILE / 2 : 0);
-    for (int jj0 = fast ? TILE / 2 : 0; jj0 < TILE / 2; jj0 += U) {
+    load_z_group(fast ? jj_hi : jj_lo);
+    for (int jj0 = fast ? jj_hi : jj_lo; jj0 < jj_hi; jj0 += U) {
       double mfull_[U], ks_[U], dk_[U], lin_[U], F_[U], d2_[U][NC], zcur[U];
       bool valid_[U];
 #pragma unroll

@@ -401,7 +401,11 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
 
   // ---- factorisation: right-looking over 16-column sub-panels with one-step look-ahead -------
   //      (sub-block 0 was factored by wave 0 during the load)
-  for (int s = 0; s < LB / SB - 1; ++s) {
+  // A ragged block (the last diagonal block of a matrix; never published piecewise) is the identity from column nv on: step s
+  // is needed while sub-panel s holds real columns (its panel rows -- the y row, whatever else the caller put below -- are
+  // solved against it); the sub-panels behind are identity and take no step.  (N = 392, eight real columns: one step, not seven.)
+  const int nsteps = (nv + SB - 1) / SB < LB / SB - 1 ? (nv + SB - 1) / SB : LB / SB - 1;
+  for (int s = 0; s < nsteps; ++s) {
     const int c0 = s * SB;
     double* Sd = &S[pk_off(s)];      // block column s, first row c0
     const int pitch = pk_pitch(s);
@@ -477,7 +481,7 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
 
   LEAF_STAMP(2);
   // ---- remaining block columns back, accumulate log-det --------------------------------------
-  for (int s = pipe ? LB / SB - 1 : LB / SB - 4; s < LB / SB; ++s) write_back(s, tid, NTH);
+  for (int s = pipe ? LB / SB - 1 : (nsteps >= 3 ? nsteps - 3 : 0); s < LB / SB; ++s) write_back(s, tid, NTH);
   {
     double lg = 0.0;
     if (tid < nv) lg = -log(rdiag[tid]);

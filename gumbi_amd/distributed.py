@@ -205,6 +205,9 @@ class DistributedEngine:
     predict``), executed by the native multi-GPU driver over the ranks of ``group``.  Every rank makes the same
     calls with the same arguments and receives the same results."""
 
+    #: the evaluations do not run on the host's BLAS (HipGP.find_MAP keeps OpenBLAS to one thread inside the optimiser's loop)
+    host_blas_free = True
+
     def __init__(self, device_index: int, group=None, comm=None, panel_blocks: int = 0, capacity: bool = False):
         import torch
 

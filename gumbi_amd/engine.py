@@ -343,6 +343,9 @@ def device_count() -> int:
 class Engine:
     """One GP resident on one MI355X: data, covariance / factor, predict workspaces."""
 
+    #: the evaluations do not run on the host's BLAS (HipGP.find_MAP keeps OpenBLAS to one thread inside the optimiser's loop)
+    host_blas_free = True
+
     def __init__(self, device: int = 0, stream: int | None = None, sibling_of: "Engine | None" = None):
         self._lib = load_library()
         self._h = C.c_void_p()

@@ -64,6 +64,29 @@ class HipModel:
         return f"HipModel(kernel={self.spec.kind}, N={len(self.y)}, D={self.X.shape[1]}, params=[{names}])"
 
 
+_BLAS_CONTROLLER = None
+
+
+def _single_threaded_host_blas(engine):
+    """Context for the optimiser's loop when the evaluations run on the GPU: scipy's L-BFGS-B factors its m x m (m <= 10)
+    matrices with LAPACK, and a many-threaded OpenBLAS spends 0.1 - 20 ms per iteration waking its pool for them -- more than a
+    whole MAP evaluation at Gumbi's usual sizes (N = 392: 0.27 ms).  One thread inside ``minimize`` only, and only for engines
+    whose arithmetic is not the host's BLAS (``host_blas_free``); the library scan is done once per process."""
+    import contextlib
+
+    if not getattr(engine, "host_blas_free", False):
+        return contextlib.nullcontext()
+    global _BLAS_CONTROLLER
+    try:
+        if _BLAS_CONTROLLER is None:
+            from threadpoolctl import ThreadpoolController
+
+            _BLAS_CONTROLLER = ThreadpoolController()
+        return _BLAS_CONTROLLER.limit(limits=1, user_api="blas")
+    except Exception:  # noqa: BLE001 -- no threadpoolctl, or a BLAS it cannot steer: the fit is merely slower
+        return contextlib.nullcontext()
+
+
 class HipGP(Regressor):
     """Gaussian-process regression on an MI355X.  Drop-in for ``gumbi.GP`` on the
     ``fit() / prepare_grid() / predict_grid()`` path; see the module docstring."""
@@ -374,8 +397,9 @@ class HipGP(Regressor):
         else:
             u0 = theta0.copy()
             u0[pos] = np.log(theta0[pos])
-            res = minimize(self._objective, u0, args=(pos,), jac=True, method=method,
-                           options={"maxfun": int(maxeval), **kwargs.pop("options", {})}, **kwargs)
+            with _single_threaded_host_blas(self.engine):
+                res = minimize(self._objective, u0, args=(pos,), jac=True, method=method,
+                               options={"maxfun": int(maxeval), **kwargs.pop("options", {})}, **kwargs)
             th = np.where(pos, np.exp(res.x), res.x)
             self.n_eval = int(res.nfev)
             self.opt_result = res

@@ -58,6 +58,9 @@ class IcmEngine:
     """Same calls as :class:`gumbi_amd.engine.Engine` (``set_data / set_kernel / set_theta / factorize /
     nlml / predict / close``) for an aligned multi-output table; ``theta`` keeps the stacked model's layout."""
 
+    #: the evaluations do not run on the host's BLAS (HipGP.find_MAP keeps OpenBLAS to one thread inside the optimiser's loop)
+    host_blas_free = True
+
     #: device memory the P resident systems may take together (factor + gradient workspace each); above it ONE
     #: inner engine serves the systems in turn and every switch re-factorises
     RESIDENT_BYTES = 160e9

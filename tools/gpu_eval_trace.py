@@ -1,5 +1,5 @@
 """Task trace of the persistent evaluation launch: where the time of a fused evaluation goes, by task kind.
-ET_N, ET_D, ET_SCHEME (2 = fused, 1 = behind the factorisation), ET_LAG."""
+ET_N, ET_D, ET_SCHEME (2 = fused, 1 = behind the factorisation), ET_LAG; ET_DUMP=1 lists every task (small launches)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -30,6 +30,9 @@ nct = (N + 127) // 128
 end = st.max()
 print(f"N={N}: {len(tasks)} tasks, launch span {end:.0f} us")
 names = {0: 'CHOL', 1: 'INV', 2: 'ZZ'}
+if os.environ.get('ET_DUMP'):  # small launches: every task -- taken / contraction done / solve input ready / published (us)
+    for (k, I, J), t in sorted(zip(tasks.tolist(), st.tolist()), key=lambda kt: kt[1][3]):
+        print(f"  {names[k]:4s} ({I},{J})  taken {t[0]:7.1f}  contracted {t[1]:7.1f}  input {t[2]:7.1f}  published {t[3]:7.1f}")
 for k in (0, 1, 2):
     m = tasks[:, 0] == k
     if not m.any():
