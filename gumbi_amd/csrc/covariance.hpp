@@ -238,10 +238,18 @@ struct PrepArgs {
   double* xs;
   double* xl;
   int32_t* cat;
+  // gmb_evaluate's first launch also clears what the evaluation's later launches expect zeroed (the engine's scalar block, the
+  // tile launch's control words and flags) -- two memsets less per evaluation; 8-byte words, null = nothing
+  unsigned long long* zero[2];
+  int64_t zero_words[2];
 };
 
 __global__ void prep_points_kernel(PrepArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int z = 0; z < 2; ++z)
+    if (a.zero[z])
+      for (int64_t w = i; w < a.zero_words[z]; w += (int64_t)gridDim.x * blockDim.x) a.zero[z][w] = 0ull;
   if (i >= a.npad) return;
   const bool real = i < a.n;
   const double* row = a.X + i * a.ldx;

@@ -216,6 +216,9 @@ struct gmb_engine {
   bool eval_call = false;     // set by gmb_evaluate around its factorize_enqueue
   bool light = false;         // the evaluation in flight runs that way
   bool gacc_zeroed = false;   // ... and its memset covered the accumulators (grad_reduce skips its own)
+  unsigned long long* prep_zero[2] = {nullptr, nullptr};  // what the NEXT prep_points launch clears besides its own work
+  int64_t prep_zero_words[2] = {0, 0};
+  bool prezeroed = false;     // gmb_evaluate's prep_points launch has cleared the scalar block and the tile launch's words
   bool fe_recorded = false;   // fe[] belong to the factorisation in flight
   // persistent evaluation launch (eval_tiles.hpp): L^-T by rows and Sigma^-1 as tile tasks, fused with the tile Cholesky
   // when the caller asks for the gradient together with the factorisation (gmb_evaluate)
@@ -828,6 +831,11 @@ int apply_theta(gmb_engine* e) {
 int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int64_t npad, double* xs,
                 double* xl, int32_t* cat, const PrepArgs* proto = nullptr) {
   PrepArgs a = proto ? *proto : e->prep_proto;
+  for (int z = 0; z < 2; ++z) {  // (one shot: gmb_set_theta inside gmb_evaluate)
+    a.zero[z] = e->prep_zero[z];
+    a.zero_words[z] = e->prep_zero_words[z];
+    e->prep_zero[z] = nullptr;
+  }
   a.X = dXraw;
   a.n = n;
   a.ldx = ldx;
@@ -1019,6 +1027,16 @@ int trsm_tiles(gmb_engine* e, double* V, int64_t ldv, int ntm, int ev_kind) {
 // One persistent launch for L^-T (rows), Sigma^-1 = U U^T into dW and the alpha parts -- with the factorisation's own tile
 // tasks in the same launch (with_chol) or behind a factorisation that is already final (eval_tiles.hpp).
 int grad_workspace(gmb_engine* e);
+// 32-bit words of the evaluation launch's control block: [4 control | nrt x nct tile flags | 3 nct chain words | nct x nct U flags]
+int64_t eval_tiles_words(int nct, int nrt) { return 4 + (int64_t)nrt * nct + 3 * (int64_t)nct + (int64_t)nct * nct; }
+
+// gmb_evaluate with a gradient runs as the fused launch (the test factorize_enqueue applies)
+bool eval_will_fuse(const gmb_engine* e) {
+  const int nblocks = (int)(e->Np / TILE);
+  return !e->naive_leaf && (e->chol_scheme == 3 || e->chol_scheme < 0) && e->grad_scheme != 0 && e->grad_scheme != 1 &&
+         nblocks <= e->tiles_max_blocks && (e->grad_scheme == 2 ? nblocks >= 1 : nblocks >= e->et_min_blocks);
+}
+
 int eval_tiles(gmb_engine* e, bool with_chol) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
   int rc;
@@ -1040,13 +1058,13 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
   }
   const int ntasks = e->et_ntasks;
   const int64_t chol_words = (int64_t)nrt * nct + 3 * (int64_t)nct;
-  const int64_t words = 4 + chol_words + (int64_t)nct * nct;
-  if ((rc = ensure(e, &e->dct, &e->cap_ct, words))) return rc;
+  const int64_t words = eval_tiles_words(nct, nrt);
+  if ((rc = ensure(e, &e->dct, &e->cap_ct, words + 2))) return rc;
   if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
   if ((rc = ensure(e, &e->dUdiag, &e->cap_udiag, (int64_t)nct * TILE * TILE))) return rc;
   if ((rc = ensure(e, &e->dApart, &e->cap_apart, (int64_t)nct * nct * TILE + nct))) return rc;  // (+ the partials of |v|^2)
   if ((rc = grad_workspace(e))) return rc;
-  HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
+  if (!(with_chol && e->prezeroed)) HIP_TRY(e, hipMemsetAsync(e->dct, 0, (size_t)words * sizeof(uint32_t), e->cur));
   // a factor that is final already: every tile flag reads "final" (any non-zero word)
   if (!with_chol) HIP_TRY(e, hipMemsetAsync(e->dct + 4, 1, (size_t)nrt * nct * sizeof(uint32_t), e->cur));
   e->ct_injected = with_chol && e->ct_lose > 0;
@@ -1602,6 +1620,9 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
     const bool last_ragged_owned = e->Np > e->N && (nt - 1 - shard) % nshards == 0 && nt - 1 >= shard;
     a.general_tiles = a.n_owned_rows + (last_ragged_owned ? nt - 1 : 0);
     if (a.general_tiles == 0) a.split = 0;
+    // small matrices: every tile through the direct loops of ONE launch, four workgroups per tile (N = 392: the interior launch's
+    // 10.8 us behind the general tiles' 10.3 saved; from 129 tiles on the matrix-pipe form wins)
+    if (total <= 128) a.split = 0;
     // small launches: four workgroups per direct-loop tile (GradArgs::gsplit)
     const int ndirect = a.split ? a.general_tiles : grid;  // runs / list tiles of grad_tile_kernel
     a.gsplit = ndirect <= 128 ? 4 : 1;
@@ -2180,6 +2201,17 @@ int gmb_set_theta(gmb_engine* e, const double* theta, int32_t n) {
     if ((rc = alloc(e, &e->cat, (int64_t)MAX_TABS * e->Nr))) return rc;
     e->cap_pts = e->Nr;
   }
+  e->prezeroed = false;
+  if (e->eval_call && eval_will_fuse(e) && e->ct_lose == 0) {
+    // gmb_evaluate: this launch also clears the scalar block and the tile launch's control words (factorize_enqueue, eval_tiles)
+    const int64_t words = eval_tiles_words((int)(e->Np / TILE), (int)(e->Nr / TILE));
+    if ((rc = ensure(e, &e->dct, &e->cap_ct, words + 2))) return rc;
+    e->prep_zero[0] = reinterpret_cast<unsigned long long*>(e->dscal);
+    e->prep_zero_words[0] = SCAL_DOUBLES;
+    e->prep_zero[1] = reinterpret_cast<unsigned long long*>(e->dct);
+    e->prep_zero_words[1] = (words + 1) / 2;
+    e->prezeroed = true;
+  }
   rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat);
   if (rc) return rc;
   e->have_theta = true;
@@ -2249,14 +2281,15 @@ int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
                       (e->chol_scheme == 2 || (e->chol_scheme < 0 && e->Np / TILE <= e->masked_max_blocks));
   // the fused evaluation launch pays at every size (per evaluation, stream schedules -> fused: N = 100: 0.21 -> 0.14 ms, N = 392:
   // 0.44 -> 0.27, N = 1000: 0.76 -> 0.45; tools/gpu_small_eval.py), the tile Cholesky on its own only from six block columns
-  const bool fused = with_grad && !e->naive_leaf && (e->chol_scheme == 3 || e->chol_scheme < 0) && e->grad_scheme != 0 && e->grad_scheme != 1 &&
-                     nblocks <= e->tiles_max_blocks && (e->grad_scheme == 2 ? nblocks >= 1 : nblocks >= e->et_min_blocks);
+  const bool fused = with_grad && eval_will_fuse(e);
   // gmb_evaluate on the fused launch: everything the host wants lands through eval_land_kernel at the end of the gradient
   e->light = e->eval_call && fused;
   const bool events = !(e->light && !e->profiling && e->Np < 4096);
   e->fe_recorded = events;
-  // scalars + failure index (+ the gradient's accumulators): one memset
-  HIP_TRY(e, hipMemsetAsync(e->dscal, 0, (size_t)(e->light ? SCAL_DOUBLES : SCAL_GACC_AT) * sizeof(double), e->stream));
+  // scalars + failure index (+ the gradient's accumulators): one memset -- or none, when the evaluation's prep_points launch
+  // has cleared them already (gmb_evaluate)
+  e->prezeroed = e->prezeroed && e->light;
+  if (!e->prezeroed) HIP_TRY(e, hipMemsetAsync(e->dscal, 0, (size_t)(e->light ? SCAL_DOUBLES : SCAL_GACC_AT) * sizeof(double), e->stream));
   e->gacc_zeroed = e->light;
 
   // 1. covariance build: lower-triangular tiles of Sigma, y row, identity padding
@@ -2359,11 +2392,15 @@ int gmb_factorize(gmb_engine* e) {
 
 int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, double* grad) {
   if (!e || !nlml) return GMB_EINVAL;
-  int rc = gmb_set_theta(e, theta, n);
-  if (rc) return rc;
   e->eval_call = grad != nullptr;
+  int rc = gmb_set_theta(e, theta, n);
+  if (rc) {
+    e->eval_call = false;
+    return rc;
+  }
   rc = factorize_enqueue(e, grad != nullptr);
   e->eval_call = false;
+  e->prezeroed = false;
   if (rc) {
     e->light = false;
     return rc;

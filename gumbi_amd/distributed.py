@@ -167,6 +167,27 @@ class TorchDistComm:
         pass
 
 
+def _handshake(comm, device_index: int) -> bool:
+    """One all-gather of four doubles per rank through ``comm`` (the ``gmb_comm`` the native driver will call), verified:
+    slot r of the result must hold rank r's values."""
+    import torch
+
+    dev = torch.device("cuda", device_index)
+    n = 4
+    try:
+        h = comm.handle.contents
+        send = torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * (h.rank + 1)
+        recv = torch.full((h.world * n,), -1.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = h.all_gather(h.ctx, send.data_ptr(), recv.data_ptr(), n, stream)
+        torch.cuda.synchronize(dev)
+        want = (torch.arange(n, dtype=torch.float64)[None, :] + 1000.0 * (torch.arange(h.world, dtype=torch.float64)[:, None] + 1)).reshape(-1)
+        return rc == 0 and bool(torch.equal(recv.cpu(), want))
+    except Exception:  # noqa: BLE001 -- whatever went wrong, the caller falls back to torch.distributed's collectives
+        return False
+
+
 def make_comm(device_index: int, group=None, prefer: str | None = None):
     """The transport for ``group``: the library's own RCCL communicator when the group runs on ``nccl`` (one
     rank per GPU), the ``torch.distributed`` callback otherwise (``gloo`` tests) or when RCCL cannot be set up
@@ -189,10 +210,24 @@ def make_comm(device_index: int, group=None, prefer: str | None = None):
 
         sys.stderr.write(f"[gumbi_amd] own RCCL communicator unavailable on rank {dist.get_rank(group)}: {err}; "
                          f"using torch.distributed collectives\n")
+    dev = torch.device("cuda", device_index) if backend == "nccl" else "cpu"
     if dist.get_world_size(group) > 1:
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", device_index) if backend == "nccl" else "cpu")
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         ok = int(flag.item())
+    if ok:
+        # first contact: one small all-gather through the new communicator, checked on every rank, before the driver's panel
+        # loop depends on it (a communicator that delivers the wrong ranks' data -- or none -- is replaced, not trusted)
+        ok = 1 if _handshake(comm, device_index) else 0
+        if dist.get_world_size(group) > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = int(flag.item())
+        if not ok:
+            import sys
+
+            sys.stderr.write(f"[gumbi_amd] own RCCL communicator failed its first all-gather on some rank (this is rank "
+                             f"{dist.get_rank(group)}); using torch.distributed collectives\n")
     if ok:
         return comm
     if comm is not None:

@@ -412,8 +412,9 @@ def test_interior_tiles_of_the_trace_reductions_match_the_oracle(gpu, kind, d, a
     """grad_interior_kernel (csrc/gradient.hpp): on full tiles below the diagonal the per-dimension sums run as r^2 and
     G . [X | X^2] contractions on the matrix pipe.  Every compile-time dimension count (1, 2: norms in the contraction's spare
     slots; 4, 8, 16: in the accumulator; 16: two feature accumulators), ARD and shared lengthscales, length scales short enough
-    that the expansion's cancellation would show -- gradient and NLML against the oracle's direct-difference form."""
-    N = 1000
+    that the expansion's cancellation would show -- gradient and NLML against the oracle's direct-difference form.
+    (N = 2200: 171 tiles -- up to 128 tiles every tile goes through the direct loops, four workgroups per tile.)"""
+    N = 2200
     X, y, ls = O.synthetic_table(N, d, seed=40 + d)
     spec = O.make_spec(d, range(d), kind=kind, ard=ard)
     theta = O.pack_theta(spec, 0.6 * ls if ard else [0.8], 1.3, 0.2)
