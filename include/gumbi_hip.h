@@ -84,7 +84,7 @@ typedef struct gmb_kernel_spec {
   double jitter;                     /* 1e-6 to follow pm.gp.Marginal                          */
 } gmb_kernel_spec;
 
-typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEvent pairs) */
+typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEvent pairs); see gmb_evaluate for when they are taken */
   double kbuild_ms;          /* covariance-matrix construction (last gmb_factorize)            */
   double chol_ms;            /* whole Cholesky (leaves + trsm + trailing updates)              */
   double chol_gemm_ms;       /* sum over the MFMA SYRK/GEMM trailing-update launches           */
@@ -220,7 +220,9 @@ int gmb_factor_valid(const gmb_engine* e);
  * launches enqueued right behind the factorisation's -- no host synchronisation or language round trip in between (at
  * N = 2000 that is 0.1 of 1.5 ms per evaluation of pm.find_MAP's objective, gumbi/regression/pymc/GP.py:811).  Same status
  * codes and side effects as the three calls (GMB_ENOTPD with gmb_notpd_index when the covariance is not positive definite;
- * grad may be NULL). */
+ * grad may be NULL), same values bit for bit where the three calls take the same schedules.  One difference: with a gradient,
+ * on matrices below 4096 rows and without gmb_set_profiling, no per-phase events are recorded (they cost a tenth of such an
+ * evaluation) -- gmb_timings' kbuild_ms / chol_ms / grad_ms then read 0 after this call. */
 int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, double* grad);
 /* Negative log marginal likelihood  N/2 log 2pi + sum log L_ii + |v|^2/2  of the last
  * factorisation, and (if grad != NULL, length gmb_theta_size) its gradient w.r.t. natural-scale
