@@ -110,7 +110,7 @@ __device__ __forceinline__ int et_wait_rows(const CholTilesArgs& g, const uint32
 template <int NW, bool NEG>
 __device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand mop, const EtOperand nop, const uint32_t* mflags,
                                         const uint32_t* nflags, const int kb_lo, const int kb_hi, double* __restrict__ out, const int64_t ldo,
-                                        double* __restrict__ lds, int* s_i) {
+                                        double* __restrict__ lds, int* s_i, const int k_last = TILE) {
   constexpr int WGN = 2, WGM = NW / WGN;
   constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);
   constexpr int KT = ct_kt(NW);
@@ -168,7 +168,8 @@ __device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand 
     }
   };
 
-  const int kt_end = kb_hi * KPB;
+  // (k_last < 128: only the first k_last values of the contraction's LAST k-block are non-zero -- the tiles behind them are skipped)
+  const int kt_end = kb_hi * KPB - (KPB - (k_last + KT - 1) / KT);
   int ktc = kb_lo * KPB;
   while (ktc < kt_end) {
     const int kb = ktc / KPB;
@@ -178,7 +179,8 @@ __device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand 
       s_i[1] = r;
     }
     __syncthreads();
-    const int kt1 = __builtin_amdgcn_readfirstlane(s_i[1]);
+    const int kt1r = __builtin_amdgcn_readfirstlane(s_i[1]);
+    const int kt1 = kt1r < kt_end ? kt1r : kt_end;
     if (kt1 < 0) return false;
     const int kt0 = ktc;
     gload(kt0);
@@ -247,7 +249,7 @@ __device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand 
 template <bool NEG>
 __device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOperand mop_in, const EtOperand nop_in, const uint32_t* mflags,
                                             const uint32_t* nflags, const int kb_lo_in, const int kb_hi_in, double* __restrict__ out,
-                                            const int64_t ldo, ct_lds_double* l3, int* s_i) {
+                                            const int64_t ldo, ct_lds_double* l3, int* s_i, const int k_last_in = TILE) {
   constexpr int WGN = 2, WGM = 4;
   constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);  // 2 x 4 MFMA tiles per wave
   constexpr int KT = 16, NS = 4;
@@ -362,7 +364,7 @@ __device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOper
     __builtin_amdgcn_sched_group_barrier(0x008, WTM * WTN - 3, 0);
   };
 
-  const int kt_end = kb_hi * KPB;
+  const int kt_end = kb_hi * KPB - (KPB - (et_uni(k_last_in) + KT - 1) / KT);  // (see et_ksum)
   int ktc = kb_lo * KPB;
   while (ktc < kt_end) {
     const int kb = ktc / KPB;
@@ -372,7 +374,8 @@ __device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOper
       s_i[1] = r;
     }
     __syncthreads();  // (no DMA in flight here)
-    const int kt1 = __builtin_amdgcn_readfirstlane(s_i[1]);
+    const int kt1r = __builtin_amdgcn_readfirstlane(s_i[1]);
+    const int kt1 = kt1r < kt_end ? kt1r : kt_end;
     if (kt1 < 0) return false;
     const int kt0 = ktc;
     // prologue: four tiles on their way, the first one landed
@@ -426,9 +429,9 @@ __device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOper
 template <int NW, bool NEG>
 __device__ __forceinline__ bool et_contract(const CholTilesArgs& g, const EtOperand mop, const EtOperand nop, const uint32_t* mflags,
                                             const uint32_t* nflags, const int kb_lo, const int kb_hi, double* __restrict__ out, const int64_t ldo,
-                                            ct_lds_double* l3, int* s_i) {
-  if constexpr (NW == 8 && ET_DMA) return et_ksum_dma<NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, l3, s_i);
-  else return et_ksum<NW, NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, (double*)l3, s_i);
+                                            ct_lds_double* l3, int* s_i, const int k_last = TILE) {
+  if constexpr (NW == 8 && ET_DMA) return et_ksum_dma<NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, l3, s_i, k_last);
+  else return et_ksum<NW, NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, (double*)l3, s_i, k_last);
 }
 
 // INV task (r, c): tile (r, c) of U = L^-T.  Contraction over the tiles (r, k) of its own row and block row c of L, strip solve
@@ -548,7 +551,9 @@ __device__ __noinline__ bool et_zz_task(const CholTilesArgs g_in, ct_g_double* A
   const EtOperand mop{g.A + (int64_t)J * TILE, g.ld, ud + (int64_t)J * TILE * TILE, J};
   const EtOperand nop{g.A + (int64_t)I * TILE, g.ld, ud + (int64_t)I * TILE * TILE, I};
   double* out = (double*)Z + (int64_t)I * TILE + (int64_t)J * TILE * ldz;
-  if (!et_contract<NW, false>(g, mop, nop, uf + (int64_t)J * g.nct, uf + (int64_t)I * g.nct, I, g.nct, out, ldz, l3, (int*)s3)) return false;
+  // the last block column of U holds zeros from column N on (et_inv_task): a ragged matrix's last k-block is cut there
+  const int k_last = (int)(g.N - (int64_t)(g.nct - 1) * TILE);
+  if (!et_contract<NW, false>(g, mop, nop, uf + (int64_t)J * g.nct, uf + (int64_t)I * g.nct, I, g.nct, out, ldz, l3, (int*)s3, k_last)) return false;
   if (g.dbg && wave == 0) {
     const unsigned long long now = wall_clock64();
     g.dbg[4 * (int64_t)t + 1] = now;

@@ -324,8 +324,8 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
   const int r16 = lane & 15, kq = lane >> 4;
   const int nv = g.nvalid;
   // sub-block inverses go straight to global memory as they are produced (a ragged block
-  // rebuilds them at the end instead)
-  double* gd = (g.dinv16 && nv == LB) ? g.dinv16 : nullptr;
+  // patches them at the end)
+  double* gd = g.dinv16;
   // the block column chain waits for this kernel: its waves go first on a compute unit it shares
   __builtin_amdgcn_s_setprio(3);
   LEAF_STAMP(0);
@@ -437,7 +437,8 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
         for (int r = 0; r < 4; ++r) Sn[(kq + 4 * r) * pn + r16] -= acc[r];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        factor_diag16_mfma<WT>(Sn, pn, dinv, gd ? gd + (s + 1) * SB * SB : nullptr, rdiag, c0 + SB, nv, g.info, g.row0);
+        // (a ragged block's sub-blocks without a real column are the identity as far as anybody else is concerned: not stored)
+        factor_diag16_mfma<WT>(Sn, pn, dinv, gd && c0 + SB < nv ? gd + (s + 1) * SB * SB : nullptr, rdiag, c0 + SB, nv, g.info, g.row0);
       } else {
         // published column by column: block column s (final since the barrier above) goes out FIRST, so that its
         // write-through stores land under the update tiles below and the drain before the next barrier is free
@@ -498,34 +499,25 @@ __device__ __forceinline__ void potrf_leaf_core(const LeafArgs& g, double* __res
   }
   LEAF_STAMP(3);
   if (g.dinv16 && nv < LB) {
-    // Only the last diagonal block of a matrix is ragged.  Its panel rows (the y row, padding)
-    // are not part of the triangular factor and the padding is identity: build the sub-block
-    // inverses of the identity-padded factor the slow way.
-    __syncthreads();
-    for (int idx = tid; idx < LB * LB; idx += NTH) {
-      const int c = idx >> 7, r = idx & 127;
-      if (r >= (c & ~15)) {
-        if (c < nv && r >= nv) S[pk(r, c)] = 0.0;
-        if (c >= nv) S[pk(r, c)] = (r == c) ? 1.0 : 0.0;
-      }
+    // Only the last diagonal block of a matrix is ragged.  What the solves want are the sub-block inverses of the
+    // IDENTITY-PADDED factor: its panel rows (the y row, padding) are not part of the triangle, while the factorisation above
+    // treated them as rows of L (and let its updates run over the padding's diagonal -- discarded, never written back).  Of
+    // the sub-blocks with real columns only the ONE that also holds panel rows differs: it came out as
+    // inv([L_mm 0; P C]) = [L_mm^-1 0; * C^-1] where the padded factor has [L_mm 0; 0 I] -- its rows from m on are reset to
+    // the identity's; the sub-blocks without a real column are the identity.  (Until round 4 all eight were rebuilt by a
+    // 16-step substitution per thread: ~10 us on every ragged matrix.)
+    const int ss = nv / SB, m = nv - ss * SB;
+    const int first_id = m > 0 ? ss + 1 : ss;  // sub-blocks from here on hold no real column
+    for (int idx = tid; idx < (LB / SB - first_id) * SB * SB; idx += NTH) {
+      const int e = idx % (SB * SB);
+      leaf_store<WT>(&g.dinv16[first_id * SB * SB + idx], (e / SB == e % SB) ? 1.0 : 0.0);
     }
-    if (tid >= nv && tid < LB) rdiag[tid] = 1.0;
-    __syncthreads();
-    if (tid < LB) {
-      const int s = tid >> 4, j = tid & 15;
-      const double* Sd = &S[pk_off(s)];
-      const int pitch = pk_pitch(s);
-      double xc[SB];
-#pragma unroll
-      for (int a = 0; a < SB; ++a) {
-        double t = (a == j) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < a; ++k)
-          if (k >= j) t -= Sd[k * pitch + a] * xc[k];
-        xc[a] = (a < j) ? 0.0 : t * rdiag[s * SB + a];
+    if (m > 0 && wave == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own stores of that sub-block (factor_diag16_mfma) first
+      for (int idx = lane; idx < SB * SB; idx += 64) {
+        const int j = idx / SB, a = idx % SB;  // column-major X: X[a][j] at j * 16 + a
+        if (a >= m) leaf_store<WT>(&g.dinv16[ss * SB * SB + idx], a == j ? 1.0 : 0.0);
       }
-#pragma unroll
-      for (int a = 0; a < SB; ++a) leaf_store<WT>(&g.dinv16[s * SB * SB + j * SB + a], xc[a]);
     }
   }
   LEAF_STAMP(4);

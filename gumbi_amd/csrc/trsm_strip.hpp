@@ -107,9 +107,13 @@ __device__ __forceinline__ void trsm_strip_solve_store_pf(const TrsmArgs& g, con
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) o[28 + kk] = g.dinv16[s * 256 + (4 * kk + kq) * 16 + r16];
   };
+  // sub-blocks that are identity padding altogether (a ragged last diagonal block: 16 s >= nvalid) leave their X as it is --
+  // the products below would add exact zeros and multiply by exact ones: same bits, none of the loads and MFMAs
+  const int smax = (g.nvalid + 15) / 16;
   load_step(0, ops[0]);
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
+    if (s >= smax) break;
     if (s < 7) load_step(s + 1, ops[(s + 1) & 1]);
     asm volatile("" ::: "memory");  // keep the requests above the MFMAs below
     const double(&o)[32] = ops[s & 1];
