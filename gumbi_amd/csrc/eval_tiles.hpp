@@ -110,7 +110,7 @@ __device__ __forceinline__ int et_wait_rows(const CholTilesArgs& g, const uint32
 template <int NW, bool NEG>
 __device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand mop, const EtOperand nop, const uint32_t* mflags,
                                         const uint32_t* nflags, const int kb_lo, const int kb_hi, double* __restrict__ out, const int64_t ldo,
-                                        double* __restrict__ lds, int* s_i, const int k_last = TILE) {
+                                        double* __restrict__ lds, int* s_i) {
   constexpr int WGN = 2, WGM = NW / WGN;
   constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);
   constexpr int KT = ct_kt(NW);
@@ -168,8 +168,7 @@ __device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand 
     }
   };
 
-  // (k_last < 128: only the first k_last values of the contraction's LAST k-block are non-zero -- the tiles behind them are skipped)
-  const int kt_end = kb_hi * KPB - (KPB - (k_last + KT - 1) / KT);
+  const int kt_end = kb_hi * KPB;
   int ktc = kb_lo * KPB;
   while (ktc < kt_end) {
     const int kb = ktc / KPB;
@@ -179,8 +178,7 @@ __device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand 
       s_i[1] = r;
     }
     __syncthreads();
-    const int kt1r = __builtin_amdgcn_readfirstlane(s_i[1]);
-    const int kt1 = kt1r < kt_end ? kt1r : kt_end;
+    const int kt1 = __builtin_amdgcn_readfirstlane(s_i[1]);
     if (kt1 < 0) return false;
     const int kt0 = ktc;
     gload(kt0);
@@ -364,7 +362,8 @@ __device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOper
     __builtin_amdgcn_sched_group_barrier(0x008, WTM * WTN - 3, 0);
   };
 
-  const int kt_end = kb_hi * KPB - (KPB - (et_uni(k_last_in) + KT - 1) / KT);  // (see et_ksum)
+  // (k_last < 128: only the first k_last values of the contraction's LAST k-block are non-zero -- the tiles behind them are skipped)
+  const int kt_end = kb_hi * KPB - (KPB - (et_uni(k_last_in) + KT - 1) / KT);
   int ktc = kb_lo * KPB;
   while (ktc < kt_end) {
     const int kb = ktc / KPB;
@@ -431,7 +430,8 @@ __device__ __forceinline__ bool et_contract(const CholTilesArgs& g, const EtOper
                                             const uint32_t* nflags, const int kb_lo, const int kb_hi, double* __restrict__ out, const int64_t ldo,
                                             ct_lds_double* l3, int* s_i, const int k_last = TILE) {
   if constexpr (NW == 8 && ET_DMA) return et_ksum_dma<NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, l3, s_i, k_last);
-  else return et_ksum<NW, NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, (double*)l3, s_i, k_last);
+  else return et_ksum<NW, NEG>(g, mop, nop, mflags, nflags, kb_lo, kb_hi, out, ldo, (double*)l3, s_i);  // (the tuning build's
+  // four-wave form: not cut -- the skipped tiles are zeros, the result is the same; with the cut this compiler's optimiser crashes)
 }
 
 // INV task (r, c): tile (r, c) of U = L^-T.  Contraction over the tiles (r, k) of its own row and block row c of L, strip solve
