@@ -1027,8 +1027,9 @@ int trsm_tiles(gmb_engine* e, double* V, int64_t ldv, int ntm, int ev_kind) {
 // One persistent launch for L^-T (rows), Sigma^-1 = U U^T into dW and the alpha parts -- with the factorisation's own tile
 // tasks in the same launch (with_chol) or behind a factorisation that is already final (eval_tiles.hpp).
 int grad_workspace(gmb_engine* e);
-// 32-bit words of the evaluation launch's control block: [4 control | nrt x nct tile flags | 3 nct chain words | nct x nct U flags]
-int64_t eval_tiles_words(int nct, int nrt) { return 4 + (int64_t)nrt * nct + 3 * (int64_t)nct + (int64_t)nct * nct; }
+// 32-bit words of the evaluation launch's control block:
+// [4 control | nrt x nct tile flags | 3 nct chain words | nct x nct U flags | nct counts of finished INV tasks per block row]
+int64_t eval_tiles_words(int nct, int nrt) { return 4 + (int64_t)nrt * nct + 3 * (int64_t)nct + (int64_t)nct * nct + nct; }
 
 // gmb_evaluate with a gradient runs as the fused launch (the test factorize_enqueue applies)
 bool eval_will_fuse(const gmb_engine* e) {
@@ -1106,6 +1107,12 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
   x.ldz = e->Np;
   x.apart = e->dApart;
   x.yb = (int)(e->N / TILE);
+  x.rowdone = x.uflags + (int64_t)nct * nct;
+  x.alpha = e->dalpha;
+  x.v = e->dv;
+  x.vpart = e->dApart + (int64_t)nct * nct * TILE;
+  x.scal = e->dscal + 1;
+  x.with_v = with_chol ? 1 : 0;  // v = L^-1 y with |v|^2, which gmb_factorize takes with extract_v_kernel
   double flops = 0.0;
   if (with_chol)
     for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (double)(nrt - j);
@@ -1122,11 +1129,6 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
   else hipLaunchKernelGGL(eval_tiles_kernel<4>, dim3(grid), dim3(256), 0, e->cur, a, x);
 #endif
   ev_end(e);
-  HIP_TRY(e, hipGetLastError());
-  if (with_chol)  // ... and v = L^-1 y with |v|^2, which gmb_factorize takes with extract_v_kernel
-    hipLaunchKernelGGL(eval_finish_kernel, dim3(nct), dim3(TILE), 0, e->cur, e->dApart, nct, e->N, e->dalpha, e->dA, e->ld, e->dv,
-                       e->dApart + (int64_t)nct * nct * TILE, e->dscal + 1);
-  else hipLaunchKernelGGL(alpha_from_parts_kernel, dim3(nct), dim3(TILE), 0, e->cur, e->dApart, nct, e->N, e->dalpha);
   HIP_TRY(e, hipGetLastError());
   e->ct_used = true;
   e->ct_ntasks = ntasks;

@@ -12,7 +12,8 @@
 //                         L, which is final as soon as the factorisation has passed column c: the inverse runs BESIDE
 //                         the factorisation and fills its chain-bound ends;
 //   ZZ   (I, J), I >= J   Sigma^-1(I,J) = sum_{k >= I} U(I,k) U(J,k)^T -- no dependencies among themselves, ticketed
-//                         longest contraction first after everything else.
+//                         longest contraction first after everything else;
+//   FIN  (r)              alpha of block row r from the parts its INV tasks left (and v, |v|^2): the last tickets.
 //
 // Both operands of every contraction are k-major, as everywhere in the engine (gemm_f64.hpp): U is kept by rows
 // precisely so that Sigma^-1 = U U^T contracts over the slow index.  U's strictly upper tiles live in the (free) upper
@@ -39,7 +40,7 @@
 
 namespace gmb {
 
-constexpr uint32_t ET_CHOL = 0u, ET_INV = 1u, ET_ZZ = 2u;
+constexpr uint32_t ET_CHOL = 0u, ET_INV = 1u, ET_ZZ = 2u, ET_FIN = 3u;
 __host__ __device__ inline uint32_t et_pack(uint32_t kind, int I, int J) { return (kind << 30) | ((uint32_t)I << 15) | (uint32_t)J; }
 
 struct EvalTilesArgs {
@@ -49,8 +50,17 @@ struct EvalTilesArgs {
   double* udiag;          // nct tiles of 128 x 128 (leading dimension 128): the diagonal tiles U(r, r)
   double* Z;              // Sigma^-1 out: lower block triangle (diagonal tiles in full), column-major
   int64_t ldz;
-  double* apart;          // [(r * nct + c) * 128 + i]: (U(r,c) v_c)_i -- alpha_r = sum_c of these, added up in c order afterwards
+  double* apart;          // [(r * nct + c) * 128 + i]: (U(r,c) v_c)_i -- alpha_r = sum_c of these, added up in c order by FIN (r)
   int32_t yb;             // block row of the factor buffer that holds row N (v = L^-1 y)
+  // FIN (r), r = 0 .. nct-1, the last tickets: alpha of block row r once the row's INV tasks have left their parts
+  // (rowdone[r] counts them; zeroed with the flags) and -- with_v: the factorisation is part of the launch -- v = row N of
+  // the factor with |v|^2 in extract_v_kernel's summation order (vpart[r] = the chunk's sum; scal as in extract_v_kernel)
+  uint32_t* rowdone;
+  double* alpha;
+  double* v;
+  double* vpart;
+  double* scal;
+  int32_t with_v;
 };
 
 // One block row of a k-major operand: k-block kb lives at base + kb * 128 * ld, except k-block diag_kb, which lives in a
@@ -438,8 +448,8 @@ __device__ __forceinline__ bool et_contract(const CholTilesArgs& g, const EtOper
 // against L(c, c), publication for the later tiles of the row and for the ZZ tasks; then the partial product with v_c.
 template <int NW>
 __device__ __noinline__ bool et_inv_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* dinv16, ct_g_double* udiag, ct_g_double* apart,
-                                         ct_g_u32* flags, ct_g_u32* uflags, ct_g_u32* ctl, ct_g_u64* dbg, const int r, const int c, const int t,
-                                         const int yb, ct_lds_double* l3, ct_lds_int* s3) {
+                                         ct_g_u32* flags, ct_g_u32* uflags, ct_g_u32* rowdone, ct_g_u32* ctl, ct_g_u64* dbg, const int r, const int c,
+                                         const int t, const int yb, ct_lds_double* l3, ct_lds_int* s3) {
   const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, nullptr, nullptr, flags, nullptr, ctl, dbg);
   const uint32_t* uf = (const uint32_t*)uflags;
   double* ud = (double*)udiag;
@@ -528,14 +538,78 @@ __device__ __noinline__ bool et_inv_task(const CholTilesArgs g_in, ct_g_double* 
       }
     s0 += __shfl_xor(s0, 16);
     s0 += __shfl_xor(s0, 32);
+    // (write-through: FIN (r) reads them on another compute unit after the row's count)
     double* ap = (double*)apart + ((int64_t)r * g.nct + c) * TILE;
-    if (kq == 0) ap[16 * wave + r16] = s0;
+    if (kq == 0) __hip_atomic_store(&ap[16 * wave + r16], s0, CT_RLX_AGENT);
     if constexpr (NW == 4) {
       s1 += __shfl_xor(s1, 16);
       s1 += __shfl_xor(s1, 32);
-      if (kq == 0) ap[16 * (wave + 4) + r16] = s1;
+      if (kq == 0) __hip_atomic_store(&ap[16 * (wave + 4) + r16], s1, CT_RLX_AGENT);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave == 0 && lane == 0) __hip_atomic_fetch_add((uint32_t*)rowdone + r, 1u, CT_RLX_AGENT);
+  return true;
+}
+
+// FIN task (r): alpha_i = sum_{c >= r} apart[(r * nct + c) * 128 + i] in c order for the rows of block row r; with_v: v_i = row N
+// of the factor and the chunk's share of |v|^2 (the LAST of these tasks adds the chunks up, see eval_finish's order in
+// covariance.hpp: extract_v_kernel).
+template <int NW>
+__device__ __noinline__ bool et_fin_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* apart, ct_g_double* alpha_out, ct_g_double* v_out,
+                                         ct_g_double* vpart, ct_g_double* scal, ct_g_u32* rowdone, ct_g_u32* ctl, ct_g_u64* dbg, const int r,
+                                         const int t, const int with_v, const int nfin, ct_lds_double* l3, ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, nullptr, nullptr, nullptr, nullptr, nullptr, ctl, dbg);
+  int* s_i = (int*)s3;
+  double* red = (double*)l3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t* rd = (const uint32_t*)rowdone + r;
+  if (wave == 0) s_i[1] = ct_wait_two(g, rd, rd, (uint32_t)(g.nct - r), true);
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = g.dbg[4 * (int64_t)t + 2] = wall_clock64();
+  double x = 0.0;
+  if (tid < TILE) {
+    const double* ap = (const double*)apart + (int64_t)r * g.nct * TILE + tid;
+    double s = 0.0;
+    for (int c = r; c < g.nct; ++c) s += ap[(int64_t)c * TILE];
+    const int64_t row = (int64_t)r * TILE + tid;
+    if (row < g.N) {
+      ((double*)alpha_out)[row] = s;
+      if (with_v) {
+        x = g.A[g.N + row * g.ld];
+        ((double*)v_out)[row] = x;
+      }
+    }
+  }
+  if (with_v) {
+    // the chunk's sum as v_chunk_sum forms it in a 128-thread workgroup: waves 0 and 1 hold the values
+    double acc = x * x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0 && wave < 2) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double* vp = (double*)vpart;
+      double* sc = (double*)scal;
+      atomicExch((unsigned long long*)&vp[r], (unsigned long long)__double_as_longlong(red[0] + red[1]));
+      __threadfence();
+      if (atomicAdd((unsigned int*)&sc[40], 1u) == (unsigned)nfin - 1u) {
+        __threadfence();
+        double tot = 0.0;
+        for (unsigned b = 0; b < (unsigned)EXTRACT_V_BLOCKS; ++b) {
+          double p = 0.0;
+          for (unsigned c = b; c < (unsigned)nfin; c += EXTRACT_V_BLOCKS)
+            p += __longlong_as_double((long long)atomicAdd((unsigned long long*)&vp[c], 0ull));  // read at the L2
+          tot += p;
+        }
+        sc[0] = tot;
+      }
+    }
+  }
+  if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 3] = wall_clock64();
   return true;
 }
 
@@ -594,60 +668,20 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_tiles_kernel(CholTilesArgs g,
                                  (ct_lds_int*)s_i);
     } else if (kind == ET_INV) {
       ok = et_inv_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)x.udiag, (ct_g_double*)x.apart, (ct_g_u32*)g.flags,
-                           (ct_g_u32*)x.uflags, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, x.yb, (ct_lds_double*)lds, (ct_lds_int*)s_i);
-    } else {
+                           (ct_g_u32*)x.uflags, (ct_g_u32*)x.rowdone, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, x.yb, (ct_lds_double*)lds,
+                           (ct_lds_int*)s_i);
+    } else if (kind == ET_ZZ) {
       ok = et_zz_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)x.udiag, (ct_g_double*)x.Z, x.ldz, (ct_g_u32*)x.uflags, (ct_g_u32*)g.ctl,
                           (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
+    } else {
+      ok = et_fin_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)x.apart, (ct_g_double*)x.alpha, (ct_g_double*)x.v, (ct_g_double*)x.vpart,
+                           (ct_g_double*)x.scal, (ct_g_u32*)x.rowdone, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, t, x.with_v, g.nct,
+                           (ct_lds_double*)lds, (ct_lds_int*)s_i);
     }
     if (!__builtin_amdgcn_readfirstlane((int)ok)) return;
     __syncthreads();  // every thread is done with s_i and the staging buffers of the task
     if (wave == 0) draw_ticket();
     __syncthreads();
-  }
-}
-
-// alpha_i = sum_{c >= r} apart[(r * nct + c) * 128 + i mod 128], r = i / 128, added in c order (same bits run to run)
-__global__ __launch_bounds__(128) void alpha_from_parts_kernel(const double* __restrict__ apart, int nct, int64_t n, double* __restrict__ alpha) {
-  const int r = blockIdx.x, i = threadIdx.x;
-  double s = 0.0;
-  for (int c = r; c < nct; ++c) s += apart[((int64_t)r * nct + c) * TILE + i];
-  const int64_t row = (int64_t)r * TILE + i;
-  if (row < n) alpha[row] = s;
-}
-
-// The same, and in the same launch what extract_v_kernel does behind a factorisation: v = row N of the factor and |v|^2 in
-// extract_v_kernel's summation order (same bits): block r leaves the sum of chunk r in vpart[r]; the block that finishes LAST
-// forms the 32 partials (chunks b, b + 32, ... in order) and adds them in index order into scal[0]; scal[40] is the arrival
-// counter (zeroed with the engine's scalars before the factorisation).
-__global__ __launch_bounds__(128) void eval_finish_kernel(const double* __restrict__ apart, int nct, int64_t n, double* __restrict__ alpha,
-                                                          const double* __restrict__ L, int64_t ld, double* __restrict__ v, double* vpart,
-                                                          double* scal) {
-  __shared__ double red[2];
-  const int r = blockIdx.x, i = threadIdx.x;
-  double s = 0.0;
-  for (int c = r; c < nct; ++c) s += apart[((int64_t)r * nct + c) * TILE + i];
-  const int64_t row = (int64_t)r * TILE + i;
-  double x = 0.0;
-  if (row < n) {
-    alpha[row] = s;
-    x = L[n + row * ld];
-    v[row] = x;
-  }
-  const double chunk = v_chunk_sum(x * x, red);
-  if (i == 0) {
-    atomicExch((unsigned long long*)&vpart[r], (unsigned long long)__double_as_longlong(chunk));
-    __threadfence();
-    if (atomicAdd((unsigned int*)&scal[40], 1u) == gridDim.x - 1) {
-      __threadfence();
-      double t = 0.0;
-      for (unsigned b = 0; b < (unsigned)EXTRACT_V_BLOCKS; ++b) {
-        double p = 0.0;
-        for (unsigned c = b; c < gridDim.x; c += EXTRACT_V_BLOCKS)
-          p += __longlong_as_double((long long)atomicAdd((unsigned long long*)&vpart[c], 0ull));  // read at the L2
-        t += p;
-      }
-      scal[0] = t;
-    }
   }
 }
 
@@ -676,8 +710,8 @@ __global__ __launch_bounds__(256) void eval_land_kernel(EvalLandArgs a) {
 }
 
 // Host side: the task list.  `with_chol`: the factorisation's tile tasks are part of the launch (column c's tasks, then the
-// INV tasks of column c - lag); otherwise the factor is final and only INV / ZZ tasks are listed.  INV column c: r = 0 .. c
-// (longest contraction first); ZZ: block rows I ascending (longest first), J = 0 .. I inside.
+// INV tasks of column c - lag); otherwise the factor is final and only INV / ZZ / FIN tasks are listed.  INV column c: r = 0 .. c
+// (longest contraction first); ZZ: block rows I ascending (longest first), J = 0 .. I inside; FIN (r), r = 0 .. nct-1, last.
 inline void et_build_tasks(int nct, int nrt, bool with_chol, int lag, std::vector<uint32_t>& out) {
   out.clear();
   auto inv_col = [&](int c) {
@@ -696,6 +730,7 @@ inline void et_build_tasks(int nct, int nrt, bool with_chol, int lag, std::vecto
   for (int c = next_inv; c < nct; ++c) inv_col(c);
   for (int I = 0; I < nct; ++I)
     for (int J = 0; J <= I; ++J) out.push_back(et_pack(ET_ZZ, I, J));
+  for (int r = 0; r < nct; ++r) out.push_back(et_pack(ET_FIN, r, 0));
 }
 
 }  // namespace gmb

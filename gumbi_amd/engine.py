@@ -648,7 +648,7 @@ def chol_task(t: int, nct: int, nrt: int):
 
 def eval_task_list(nct: int, nrt: int, with_chol: bool = True, lag: int = 1) -> list:
     """[(kind, I, J), ...] of the persistent evaluation launch in ticket order (host-only; kind 0 = Cholesky tile,
-    1 = tile of U = L^-T, 2 = tile of Sigma^-1)."""
+    1 = tile of U = L^-T, 2 = tile of Sigma^-1, 3 = alpha (and v) of block row I)."""
     lib = load_library()
     n = lib.gmb_debug_eval_tasks(int(nct), int(nrt), int(bool(with_chol)), int(lag), None, 0)
     if n < 0:

@@ -189,12 +189,12 @@ def test_tile_cholesky_tickets_enumerate_every_tile_once_in_a_topological_order(
 
 def test_evaluation_task_list_is_a_topological_order_of_its_dependency_graph():
     """The host-built ticket list of the persistent evaluation launch (csrc/eval_tiles.hpp, gmb_debug_eval_tasks): every Cholesky
-    tile, every tile of U = L^-T and every tile of Sigma^-1 exactly once, and every task AFTER the tasks it waits for -- a
+    tile, every tile of U = L^-T, every tile of Sigma^-1 and every block row's alpha exactly once, and every task AFTER the tasks it waits for -- a
     task then only ever waits for smaller tickets, which are finished or held by a running workgroup: the launch cannot
     deadlock whatever the residency of its workgroups.  With and without the factorisation's own tasks, several lags."""
     from gumbi_amd import engine
 
-    CHOL, INV, ZZ = 0, 1, 2
+    CHOL, INV, ZZ, FIN = 0, 1, 2, 3
     for nct, nrt, lag in [(1, 1, 1), (1, 2, 0), (2, 2, 1), (3, 4, 5), (6, 6, 2), (20, 21, 5), (41, 41, 10), (79, 79, 19), (80, 81, 24)]:
         for with_chol in (True, False):
             tasks = engine.eval_task_list(nct, nrt, with_chol, lag)
@@ -203,7 +203,9 @@ def test_evaluation_task_list_is_a_topological_order_of_its_dependency_graph():
             n_tri = nct * (nct + 1) // 2
             assert sum(1 for k, _, _ in tasks if k == INV) == n_tri and sum(1 for k, _, _ in tasks if k == ZZ) == n_tri
             assert sum(1 for k, _, _ in tasks if k == CHOL) == (nct * nrt - nct * (nct - 1) // 2 if with_chol else 0)
-            assert all((k == CHOL and j <= i < nrt and j < nct) or (k == INV and i <= j < nct) or (k == ZZ and j <= i < nct) for k, i, j in tasks)
+            assert sorted(i for k, i, _ in tasks if k == FIN) == list(range(nct))
+            assert all((k == CHOL and j <= i < nrt and j < nct) or (k == INV and i <= j < nct) or (k == ZZ and j <= i < nct) or
+                       (k == FIN and i < nct and j == 0) for k, i, j in tasks)
             yb = nrt - 1 if nrt > nct else nct - 1  # the block row that holds row N
             step = max(1, len(tasks) // 500)
             for t in range(0, len(tasks), step):
@@ -214,7 +216,9 @@ def test_evaluation_task_list_is_a_topological_order_of_its_dependency_graph():
                     deps = [(INV, i, q) for q in range(i, j)]
                     if with_chol:
                         deps += [(CHOL, j, q) for q in range(j + 1)] + [(CHOL, yb, j)]
-                else:  # Sigma^-1 (I, J): rows I and J of U from column I on
+                elif k == ZZ:  # Sigma^-1 (I, J): rows I and J of U from column I on
                     deps = [(INV, i, q) for q in range(i, nct)] + [(INV, j, q) for q in range(i, nct)]
+                else:  # alpha of block row i: the parts every tile of U's row i left (and, through them, row N of the factor)
+                    deps = [(INV, i, q) for q in range(i, nct)]
                 assert all(pos[dep] < t for dep in deps), (nct, nrt, lag, with_chol, tasks[t])
 

@@ -29,7 +29,7 @@ st = st * 1e6
 nct = (N + 127) // 128
 end = st.max()
 print(f"N={N}: {len(tasks)} tasks, launch span {end:.0f} us")
-names = {0: 'CHOL', 1: 'INV', 2: 'ZZ'}
+names = {0: 'CHOL', 1: 'INV', 2: 'ZZ', 3: 'FIN'}
 if os.environ.get('ET_DUMP'):  # small launches: every task -- taken / contraction done / solve input ready / published (us)
     for (k, I, J), t in sorted(zip(tasks.tolist(), st.tolist()), key=lambda kt: kt[1][3]):
         print(f"  {names[k]:4s} ({I},{J})  taken {t[0]:7.1f}  contracted {t[1]:7.1f}  input {t[2]:7.1f}  published {t[3]:7.1f}")
