@@ -1581,6 +1581,8 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
   const int per = (int)std::max<long long>(1, (total + want - 1) / want);
   const int grid = (int)((total + per - 1) / per);
   const int ncp = e->nc_pad;
+  bool merged = false;  // the pass ends in grad_finish_kernel (set inside the one term's iteration)
+  GradFinishArgs fin{};
   for (size_t t = 0; t < e->terms.size(); ++t) {
     const gmb_engine::Term& tr = e->terms[t];
     if (t > 0 && (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, &tr.pa))) return rc;
@@ -1654,13 +1656,24 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
         ++r.n;
       };
       double* tmp = e->dgpart + GACC_DOUBLES;  // scratch behind the accumulators
+      merged = e->light && e->terms.size() == 1 && s.ard && big == 0 && nvec <= 8192 && e->N <= 16384;
       if (s.ard) add(0, s.n_cont, 0);
       else add(0, s.n_cont, (int)(tmp - acc));               // per-dimension sums, folded into the one parameter below
       add(ncp, 2 + tr.cp.n_lin, n_ls);                        // eta | tau | c..
       for (int j = 0; j < tr.cp.n_tab; ++j)
         if (tr.cp.tab_levels[j] <= 8) add(n_small + j * 64, tr.cp.tab_levels[j] * tr.cp.tab_levels[j], tab_acc_off[j]);
-      hipLaunchKernelGGL(grad_sum_partials_kernel, dim3(a.part_stride), dim3(256), 0, e->stream, e->dgred, nvec,
-                         (int64_t)a.part_stride, r, acc);
+      if (merged) {
+        // small evaluation: the second stage, the diagonal terms and the landing are ONE launch (grad_finish_kernel)
+        fin.part = e->dgred;
+        fin.nparts = nvec;
+        fin.nslots = a.part_stride;
+        fin.stride = a.part_stride;
+        fin.r = r;
+        fin.acc = acc;
+      } else {
+        hipLaunchKernelGGL(grad_sum_partials_kernel, dim3(a.part_stride), dim3(256), 0, e->stream, e->dgred, nvec,
+                           (int64_t)a.part_stride, r, acc);
+      }
       if (!s.ard) hipLaunchKernelGGL(grad_fold_ls_kernel, dim3(1), dim3(64), 0, e->stream, acc, s.n_cont, tmp);
       if (big > 0) {
         GradRanges rb{};
@@ -1677,9 +1690,19 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
     }
     if (t == 0) {  // diagonal terms (sigma, noise table) with the global term's categories in place
       const double sigma = e->theta[n_ls + 1];
-      hipLaunchKernelGGL(grad_diag_kernel, dim3(1), dim3(1024), 0, e->stream, Z, ldz, e->dalpha, train_set(e),
-                         tr.cp, sigma, e->dgpart + off, shard, nshards, packed ? 1 : 0);
-      HIP_TRY(e, hipGetLastError());
+      if (merged) {
+        fin.Z = Z;
+        fin.ldz = ldz;
+        fin.alpha = e->dalpha;
+        fin.pts = train_set(e);
+        fin.p = tr.cp;
+        fin.sigma = sigma;
+        fin.diag_out = e->dgpart + off;
+      } else {
+        hipLaunchKernelGGL(grad_diag_kernel, dim3(1), dim3(1024), 0, e->stream, Z, ldz, e->dalpha, train_set(e),
+                           tr.cp, sigma, e->dgpart + off, shard, nshards, packed ? 1 : 0);
+        HIP_TRY(e, hipGetLastError());
+      }
     }
   }
   if (e->terms.size() > 1 &&
@@ -1705,7 +1728,10 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
     la.out_info = &e->hl_dev->info;
     la.out_abort = &e->hl_dev->abort;
     la.out_gacc = e->hl_dev->gacc;
-    hipLaunchKernelGGL(eval_land_kernel, dim3(1), dim3(256), 0, e->stream, la);
+    if (merged) {
+      fin.land = la;
+      hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(1024), 0, e->stream, fin);
+    } else hipLaunchKernelGGL(eval_land_kernel, dim3(1), dim3(256), 0, e->stream, la);
     HIP_TRY(e, hipGetLastError());
     return GMB_OK;
   }

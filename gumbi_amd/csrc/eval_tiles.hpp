@@ -37,6 +37,7 @@
 
 #include "chol_tiles.hpp"
 #include "covariance.hpp"
+#include "gradient.hpp"
 
 namespace gmb {
 
@@ -707,6 +708,89 @@ __global__ __launch_bounds__(256) void eval_land_kernel(EvalLandArgs a) {
   if (t == 3) *a.out_abort = a.abort ? __hip_atomic_load(a.abort, CT_RLX_AGENT) : 0u;
   for (int q = 0; q < a.nterms; ++q)
     for (int i = t; i < a.used[q]; i += 256) a.out_gacc[(int64_t)q * a.region + i] = a.gacc[(int64_t)q * a.region + i];
+}
+
+// The tail of a small evaluation as ONE launch of one workgroup (gmb_evaluate's light path, one covariance term, ARD, no
+// table above 8 levels): grad_sum_partials_kernel's fixed-order sums over the partial vectors (four slots at a time, one per
+// 256-thread group: same order of additions, same bits), grad_diag_kernel's diagonal terms, and eval_land_kernel's copy to the
+// pinned landing -- three launches of ~4 us each otherwise.
+struct GradFinishArgs {
+  const double* part;  // grad_sum_partials_kernel's arguments
+  int32_t nparts, nslots;
+  int64_t stride;
+  GradRanges r;
+  double* acc;
+  const double* Z;     // grad_diag_kernel's (shard 0 of 1, Z not packed)
+  int64_t ldz;
+  const double* alpha;
+  PointSet pts;
+  CovParams p;
+  double sigma;
+  double* diag_out;
+  EvalLandArgs land;
+};
+__global__ __launch_bounds__(1024) void grad_finish_kernel(GradFinishArgs a) {
+  __shared__ double red4[4][256];
+  __shared__ double red[16];
+  __shared__ double tab[16][32];
+  const int t = threadIdx.x, grp = t >> 8, lt = t & 255;
+  for (int q0 = 0; q0 < a.nslots; q0 += 4) {
+    const int q = q0 + grp;
+    double s = 0.0;
+    if (q < a.nslots)
+      for (int b = lt; b < a.nparts; b += 256) s += a.part[(int64_t)b * a.stride + q];
+    red4[grp][lt] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+      if (lt < h) red4[grp][lt] += red4[grp][lt + h];
+      __syncthreads();
+    }
+    if (lt == 0 && q < a.nslots)
+      for (int i = 0; i < a.r.n; ++i)
+        if (q >= a.r.dense[i] && q < a.r.dense[i] + a.r.count[i]) {
+          a.acc[a.r.dst[i] + (q - a.r.dense[i])] = red4[grp][0];
+          break;
+        }
+    __syncthreads();
+  }
+  // diagonal-only terms (grad_diag_kernel)
+  const int wave = t >> 6;
+  for (int idx = t; idx < 16 * 32; idx += 1024) (&tab[0][0])[idx] = 0.0;
+  __syncthreads();
+  double gs = 0.0;
+  for (int64_t i = t; i < a.pts.n; i += 1024) {
+    const double al = a.alpha[i];
+    const double m = 0.5 * (a.Z[i + i * a.ldz] - al * al);
+    double mult = 1.0;
+    if (a.p.noise_tab >= 0) {
+      const int c = a.pts.cat[(int64_t)a.p.noise_tab * a.pts.npad + i];
+      mult = a.p.noise_mult[c];
+      atomicAdd(&tab[wave][c], m * a.sigma * a.sigma);
+    }
+    gs = fma(m, 2.0 * a.sigma * mult, gs);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gs += __shfl_down(gs, off);
+  if ((t & 63) == 0) red[wave] = gs;
+  __syncthreads();
+  if (t == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    a.diag_out[0] = s;
+  }
+  if (a.p.noise_tab >= 0 && t < 32) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += tab[w][t];
+    a.diag_out[1 + t] = s;
+  }
+  // everything this workgroup wrote to the accumulators is visible to all of it, then out to the host's landing
+  __threadfence();
+  __syncthreads();
+  if (t < 2) a.land.out_scal[t] = a.land.scal[t];
+  if (t == 2) *a.land.out_info = *a.land.info;
+  if (t == 3) *a.land.out_abort = a.land.abort ? __hip_atomic_load(a.land.abort, CT_RLX_AGENT) : 0u;
+  for (int i = t; i < a.land.used[0]; i += 1024)
+    a.land.out_gacc[i] = __hip_atomic_load(&a.land.gacc[i], CT_RLX_AGENT);  // (past this compute unit's L1)
 }
 
 // Host side: the task list.  `with_chol`: the factorisation's tile tasks are part of the launch (column c's tasks, then the
