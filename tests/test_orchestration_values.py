@@ -219,3 +219,28 @@ def test_propose_and_conditional_prediction_values_hip_vs_oracle(gpu):
     a, b = at_theta(ref["theta"]), _oracle_twin(lambda: at_theta(ref["theta"]))
     for x, y in zip(a, b):
         assert np.allclose(x, y, rtol=1e-8, atol=1e-12)
+
+
+def test_optimiser_loop_keeps_the_host_blas_to_one_thread_only_for_gpu_engines():
+    """HipGP.find_MAP runs scipy's L-BFGS-B -- whose LAPACK calls on m x m matrices (m <= 10) wake a many-threaded OpenBLAS for
+    0.1 ms and more per iteration -- with the host BLAS limited to one thread, but ONLY when the evaluations do not run on that
+    BLAS (engines flagged ``host_blas_free``): the oracle engine of the CPU baseline keeps all its threads."""
+    import contextlib
+
+    from gumbi_amd.regression import hip_gp
+    from gumbi_amd import engine, distributed
+    from gumbi_amd.regression import icm
+
+    assert engine.Engine.host_blas_free and icm.IcmEngine.host_blas_free and distributed.DistributedEngine.host_blas_free
+    assert not getattr(OracleEngine, "host_blas_free", False)
+    assert isinstance(hip_gp._single_threaded_host_blas(OracleEngine.__new__(OracleEngine)), contextlib.nullcontext)
+
+    class Flagged:
+        host_blas_free = True
+
+    threadpoolctl = pytest.importorskip("threadpoolctl")
+    before = [c.num_threads for c in threadpoolctl.ThreadpoolController().select(user_api="blas").lib_controllers]
+    with hip_gp._single_threaded_host_blas(Flagged()):
+        inside = [c.num_threads for c in threadpoolctl.ThreadpoolController().select(user_api="blas").lib_controllers]
+    after = [c.num_threads for c in threadpoolctl.ThreadpoolController().select(user_api="blas").lib_controllers]
+    assert inside and all(n == 1 for n in inside) and after == before
