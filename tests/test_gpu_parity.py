@@ -94,7 +94,7 @@ def test_mfma_gemm_block_op_layouts(gpu):
 
 
 @pytest.mark.parametrize("naive", [False, True])
-@pytest.mark.parametrize("nvalid", [128, 100, 17, 1])
+@pytest.mark.parametrize("nvalid", [128, 127, 112, 100, 17, 16, 8, 1])
 def test_potrf_leaf_block(gpu, naive, nvalid):
     import torch
 
@@ -266,6 +266,28 @@ def test_factor_v_and_nlml_match_oracle(gpu, N, d, kind):
     assert np.isclose(eng.nlml(), O.nlml(spec, theta, X, y, dist_mode="direct"), rtol=1e-11, atol=1e-10)
     tm = eng.timings()
     assert tm["kbuild_ms"] > 0 and tm["chol_ms"] > 0
+
+
+def test_evaluate_records_phase_events_on_small_matrices_only_when_profiling(gpu):
+    """gmb_evaluate with a gradient on a matrix below 4096 rows records no per-phase events (six event records were a tenth of
+    such an evaluation): kbuild_ms / chol_ms / grad_ms read 0 -- unless gmb_set_profiling is on; gmb_factorize always records."""
+    X, y, ls = O.synthetic_table(300, 2, seed=5)
+    spec = O.make_spec(2, range(2))
+    theta = O.pack_theta(spec, ls, 1.0, 0.2)
+    eng = make_engine(spec, theta, X, y)
+    val, g = eng.evaluate(theta)
+    tm = eng.timings()
+    assert tm["kbuild_ms"] == 0 and tm["chol_ms"] == 0 and tm["grad_ms"] == 0
+    eng.set_profiling(True)
+    val2, g2 = eng.evaluate(theta)
+    tm = eng.timings()
+    assert tm["kbuild_ms"] > 0 and tm["chol_ms"] > 0 and tm["grad_ms"] > 0
+    assert np.float64(val2).tobytes() == np.float64(val).tobytes() and g2.tobytes() == g.tobytes()
+    eng.set_profiling(False)
+    eng.factorize()
+    tm = eng.timings()
+    assert tm["kbuild_ms"] > 0 and tm["chol_ms"] > 0
+    eng.close()
 
 
 @pytest.mark.parametrize("case", CASES)
