@@ -621,8 +621,12 @@ __global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
   int tix, tj_lo, tj_hi;
   const int gs = a.gsplit > 1 ? a.gsplit : 1;  // (strip == 1 then: launch_cov)
   const int part = (int)(blockIdx.x % (unsigned)gs);
+  // The triangle is walked from its END: the strips that hold direct-loop tiles -- a ragged last tile row, every row's diagonal
+  // tile -- take ~30 us each whatever the matrix, and in ascending order the last of them STARTED when everything else was done.
+  long long b = (long long)(blockIdx.x / (unsigned)gs);
+  if (a.tri_grid) b = (long long)(gridDim.x / (unsigned)gs) - 1 - b;
   if (!cov_decode_block(a.ti, a.tj, a.strip, a.tri_grid, a.row_first, a.row_stride,
-                        a.mode == COV_TRAIN && a.lower_only, (long long)(blockIdx.x / (unsigned)gs), &tix, &tj_lo, &tj_hi))
+                        a.mode == COV_TRAIN && a.lower_only, b, &tix, &tj_lo, &tj_hi))
     return;
   int tj_gen = tj_lo;  // first tile of the strip that goes through the direct loop
 #ifndef GMB_KBUILD_DIRECT
