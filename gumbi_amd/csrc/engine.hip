@@ -648,8 +648,9 @@ int launch_cov(gmb_engine* e, const CovTileArgs& a_in) {
   a.stream_stores = tiles * TILE * TILE * 8.0 >= 1073741824.0 / (a.row_stride > 0 ? a.row_stride : 1);  // by the whole matrix
   // tiles per workgroup: enough strips left to fill the chip's ~800 workgroup slots several times over
   a.strip = e->cov_strip > 0 ? e->cov_strip : (tiles >= 32768.0 ? 4 : tiles >= 12288.0 ? 2 : 1);
-  // small grids: four workgroups per tile (N = 392: the build's one launch 29.6 -> 11.8 us; tools/gpu_timeline.sh)
-  a.gsplit = (a.strip == 1 && cov_grid_blocks(a.ti, a.tj, 1, a.tri_grid, a.row_first, a.row_stride) <= 128) ? 4 : 1;
+  // small grids (up to 1024 tiles, N <= 5.7k): four workgroups per tile (N = 392: the build's one launch 29.6 -> 11.8 us, N = 2560:
+  // 43 -> 30, N = 4000: 55 -> 39, N = 5200: 61 -> 50; from ~2000 tiles on the split costs more than the direct-loop tiles' tail)
+  a.gsplit = (a.strip == 1 && cov_grid_blocks(a.ti, a.tj, 1, a.tri_grid, a.row_first, a.row_stride) <= 1024) ? 4 : 1;
   switch (a.p.kind) {
     case GMB_EXPQUAD: return launch_cov_nc<0>(e, a, e->nc_pad);
     case GMB_MATERN52: return launch_cov_nc<1>(e, a, e->nc_pad);
@@ -1629,7 +1630,7 @@ int grad_reduce(gmb_engine* e, int shard, int nshards, const double* Z, int64_t 
     if (total <= 128) a.split = 0;
     // small launches: four workgroups per direct-loop tile (GradArgs::gsplit)
     const int ndirect = a.split ? a.general_tiles : grid;  // runs / list tiles of grad_tile_kernel
-    a.gsplit = ndirect <= 128 ? 4 : 1;
+    a.gsplit = ndirect <= 512 ? 4 : 1;
     const int nvec = a.split ? ndirect * a.gsplit + grid : ndirect * a.gsplit;  // partial vectors the pass leaves
     if (grid > 0) {
       if ((rc = ensure(e, &e->dgred, &e->cap_gred, (int64_t)nvec * a.part_stride))) return rc;
