@@ -32,7 +32,10 @@ launch of the persistent tile kernel: step, phases, the launch's roofline), ``st
 (the N = 100k problem of the multi-GPU runs on this one GPU), ``default_start`` and ``end_to_end`` (the user-level
 ``DataSet -> GP.fit() -> prepare_grid() -> predict_grid()`` wall time, host transfers included).
 
-Several GPUs (``--gpus N``, launched by torch.distributed.run, one rank per GPU): ONE GP -- BASELINE.json
+Several GPUs (``--gpus N``: under torch.distributed.run when the driver launches it, one rank per GPU; started WITHOUT a
+launcher -- no WORLD_SIZE in the environment -- bench.py re-runs itself as N ranks under torch.distributed.run on 127.0.0.1;
+fewer than N devices, or a launcher whose WORLD_SIZE differs from --gpus, is an error line + non-zero exit, never a silent
+one-GPU run): ONE GP -- BASELINE.json
 configs[4] = C5, N = 100k, d = 8, RBF-ARD -- factored block-cyclically over all ranks by the native driver
 (gumbi_amd/csrc/dist_driver.hpp; all-gathers on RCCL over xGMI).  Default: hyper-parameters fixed, a step = one
 MAP objective + gradient evaluation (factorise + row-partitioned gradient) + re-factorisation (``fit`` at fixed
@@ -939,6 +942,52 @@ def run_with_deadline(fn, seconds):
     return box["value"], True
 
 
+def fail_line(args, n_gpus, message, do_print=True):
+    """The contract's JSON line for a run that could not be made: value null, `error` says why; the caller exits non-zero."""
+    out = {"metric": "fit+predict achieved GFLOP/s (fp64 exact GP)", "value": None, "unit": "GFLOP/s", "n_gpus": int(n_gpus),
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": CONFIGS[args.config or "c5"]["label"]},
+           "error": {"error": str(message)[:400]}}
+    if do_print:
+        print(json.dumps(out, ensure_ascii=False), flush=True)
+    sys.stderr.write(f"[bench] {message}\n")
+    sys.stderr.flush()
+    return out
+
+
+def enough_devices(n_ranks):
+    """(ok, devices): one GPU per rank, except under the tests' hook that puts every rank on GPU 0 (gloo only)."""
+    from gumbi_amd import engine
+
+    have = engine.device_count()
+    if os.environ.get("GUMBI_BENCH_SINGLE_DEVICE") == "1":
+        return have >= 1 and os.environ.get("GUMBI_BENCH_BACKEND", "nccl") != "nccl", have
+    return have >= n_ranks, have
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` started WITHOUT a launcher (no WORLD_SIZE in the environment): re-run this same command line
+    as N ranks, one per GPU, under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``
+    -- exactly the form the driver uses for N > 1 -- and hand its exit code on.  Fewer than N GPUs on the node is an ERROR
+    (JSON line with ``error``, exit code 2), never a silent one-GPU run."""
+    import socket
+    import subprocess
+
+    ok, have = enough_devices(args.gpus)
+    if not ok:
+        fail_line(args, args.gpus, f"--gpus {args.gpus} needs {args.gpus} MI355X devices (one rank per GPU over RCCL); this node shows {have}")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    sys.stderr.write("[bench] --gpus %d without a launcher: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GUMBI_BENCH_SELF_LAUNCHED="1")
+    return subprocess.call(cmd, env=env, cwd=str(ROOT))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -957,15 +1006,27 @@ def main():
         cpu_fit_subprocess(args.cpu_fit)
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))  # `python bench.py --gpus N` by itself: N ranks under torch.distributed.run
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     config_name = args.config or ("c3" if world == 1 else "c5")
     cfg = CONFIGS[config_name]
+    if world != args.gpus:
+        # a launcher that started another number of ranks than --gpus names: never print a line whose n_gpus is not what was asked
+        fail_line(args, args.gpus, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", rank == 0)
+        sys.exit(2)
     if world > 1 and config_name != "c5":
-        raise SystemExit("several GPUs run the one-GP workload: --config c5")
+        fail_line(args, world, "several GPUs run the one-GP workload: --config c5", rank == 0)
+        sys.exit(2)
 
     dist = None
+    if world > 1:
+        ok, have = enough_devices(world)  # before anything touches a device that may not exist
+        if not ok:
+            fail_line(args, world, f"{world} ranks need {world} MI355X devices (one rank per GPU over RCCL); this node shows {have}", rank == 0)
+            sys.exit(2)
     import torch
 
     if os.environ.get("GUMBI_BENCH_SINGLE_DEVICE") == "1":
@@ -1065,6 +1126,10 @@ def main():
                 out["comm"] = res["comm"]
                 out["transport"], out["rccl_ranks"] = res["comm"]["transport"], res["comm"]["rccl_ranks"]
                 out["comm_ms_total"], out["comm_ms_exposed"] = res["comm"]["comm_ms_total"], res["comm"]["comm_ms_exposed"]
+                out["launcher"] = "bench.py itself (--gpus N without WORLD_SIZE)" if os.environ.get("GUMBI_BENCH_SELF_LAUNCHED") == "1" else "external (WORLD_SIZE set)"
+                if out["transport"] == "rccl" and out["rccl_ranks"] != world:
+                    # the library's communicator does not span the ranks that were launched: whatever was timed is not an N-GPU run
+                    out["error"] = {"error": f"RCCL communicator reports {out['rccl_ranks']} ranks, {world} were launched"}
             if "ceiling" in res:
                 cb, ca = res["ceiling"]["before_timed_region"], res["ceiling"]["after_timed_region"]
                 out["roofline"]["mfma_only_ceiling"] = {

@@ -211,3 +211,41 @@ def test_schedule_model_orders_are_topological_and_column_major_is_not_beaten():
         assert all(seen[(i, j)] == j for j in range(nct) for i in range(j, nct)) and len(seen) == nct * (nct + 1) // 2
         t, _ = S.simulate(nct, order)
         assert t > 0.97 * base
+
+
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+    import os
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_gpus_flag_without_enough_devices_is_an_error_line_not_a_one_gpu_run():
+    """``python bench.py --gpus N`` started without a launcher must produce an N-rank run or FAIL.  With
+    fewer than N devices on the node (here: none, or one on the GPU box) it prints the contract's line with value null and
+    ``error``, n_gpus = what was asked, and exits non-zero -- it never degrades to the one-GPU C3 line."""
+    import json
+
+    from gumbi_amd import engine
+
+    want = max(engine.device_count(), 1) + 1
+    out = _run_bench(["--gpus", str(want), "--steps", "1", "--warmup", "0"])
+    assert out.returncode == 2, (out.returncode, out.stderr[-500:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == want and d["value"] is None and d["scaling"] == "strong"
+    assert f"needs {want} MI355X devices" in d["error"]["error"] and "this node shows" in d["error"]["error"]
+    assert "ONE GP" in d["config"]["workload"]
+
+
+def test_gpus_flag_must_agree_with_the_launchers_world_size():
+    """A launcher that started another number of ranks than ``--gpus`` names is refused before any device is touched."""
+    import json
+
+    out = _run_bench(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert out.returncode == 2
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["value"] is None and "WORLD_SIZE=1" in d["error"]["error"] and "--gpus 4" in d["error"]["error"]

@@ -638,10 +638,12 @@ def test_driver_on_the_rccl_backend_with_one_rank(gpu):
     assert e_val < 1e-10 and e_g < 1e-8 and e_mu < 1e-8 and e_var < 1e-9
 
 
-@pytest.mark.parametrize("map_evals", [0, 3])
-def test_bench_contract_with_two_ranks_on_one_gpu(gpu, map_evals):
+@pytest.mark.parametrize("launcher,map_evals", [("torchrun", 0), ("self", 0), ("self", 3)])
+def test_bench_contract_with_two_ranks_on_one_gpu(gpu, launcher, map_evals):
     """bench.py as the driver launches it for N > 1 (``python -m torch.distributed.run --nproc-per-node N
-    bench.py --gpus N ...``), with both ranks on the test box's one GPU over gloo: rank 0 prints exactly ONE
+    bench.py --gpus N ...``) and, ``launcher == "self"``, as plain ``python bench.py --gpus 2`` with NO launcher around it
+    (bench.py then re-runs itself under torch.distributed.run), with both ranks on the test box's one
+    GPU over gloo: rank 0 prints exactly ONE
     JSON line with the contract's keys, n_gpus = 2, the workload is ONE GP partitioned over the ranks (fixed
     hyper-parameters, or a distributed ``find_MAP(maxeval=k)`` with ``--map-evals k``), and the line says what the
     collectives cost (``comm``) and what the same step does on ONE GPU (``strong_scaling_base_gflops``)."""
@@ -653,9 +655,10 @@ def test_bench_contract_with_two_ranks_on_one_gpu(gpu, map_evals):
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, GUMBI_BENCH_SINGLE_DEVICE="1", GUMBI_BENCH_BACKEND="gloo", GUMBI_BENCH_DIST_N="3000",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1"] + (["--map-evals", str(map_evals)] if map_evals else [])
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+            "127.0.0.1", "--master-port", str(_free_port())] if launcher == "torchrun" else [sys.executable]
+    cmd = head + [str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + (["--map-evals", str(map_evals)] if map_evals else [])
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -667,6 +670,7 @@ def test_bench_contract_with_two_ranks_on_one_gpu(gpu, map_evals):
                 "comm_ms_exposed", "strong_scaling_base_gflops", "speedup_over_one_gpu"):
         assert key in d, key
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert d["launcher"].startswith("bench.py itself" if launcher == "self" else "external")
     assert d["value"] > 0 and d["results_finite"] and "cpu_baseline" not in d
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert "ONE GP" in d["config"]["workload"] and "over 2 GPUs" in d["config"]["parallelism"]
@@ -764,3 +768,28 @@ def test_bench_default_config_is_the_largest_single_gpu_one():
     src = (root / "bench.py").read_text()
     assert 'args.config or ("c3" if world == 1 else "c5")' in src
     assert mod.CONFIGS["c3"]["label"].startswith("synthetic N=50k d=8 Matern-5/2")
+
+
+def test_bench_gpus_2_over_rccl_on_a_one_gpu_box_fails_loudly(gpu):
+    """``python bench.py --gpus 2`` on the production transport (nccl = RCCL, one rank per GPU) needs two devices: on a box
+    with fewer it exits non-zero with an error line naming the shortfall, whether bench.py launches the ranks itself or a
+    launcher already did -- it never prints a one-GPU line for a multi-GPU request."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    if gpu >= 2:
+        pytest.skip("this box has two devices: the request can be served")
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GUMBI_BENCH_SINGLE_DEVICE", "GUMBI_BENCH_BACKEND")}
+    for head in ([sys.executable],
+                 [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port())]):
+        out = subprocess.run(head + [str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0, out.stdout[-500:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, (out.stdout[-1000:], out.stderr[-1000:])
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["value"] is None and "need" in d["error"]["error"] and "this node shows 1" in d["error"]["error"]
