@@ -113,6 +113,7 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   e->coll_count = e->coll_hash = 0;
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_factorize (set-up)"))) return rc;
   e->factored = false;
+  e->factor_kind = gmb_engine::FK_CAPACITY;
   e->factor_consumed = false;
   e->have_alpha = false;
   e->notpd = -1;
@@ -331,6 +332,7 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
   }
   const int G = comm->world, rank = comm->rank;
   rc = require_ready(e, true);
+  if (!rc) rc = require_capacity_factor(e, "gmb_dist_nlml");
   if (!rc && !nlml) rc = fail(e, GMB_EINVAL, "nlml output pointer is null");
   if (!rc && (e->own_world != G || e->own_rank != rank)) rc = fail(e, GMB_EINVAL, "the resident rows were factored for another rank / world size");
   if (!rc && hipSetDevice(e->device) != hipSuccess) rc = fail(e, GMB_EHIP, "hipSetDevice(%d) failed", e->device);
@@ -526,6 +528,7 @@ int cap_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M
   if (rc) return rc;
   const int G = comm->world, rank = comm->rank;
   rc = require_ready(e, true);
+  if (!rc) rc = require_capacity_factor(e, "gmb_dist_predict");
   if (!rc && (e->own_world != G || e->own_rank != rank)) rc = fail(e, GMB_EINVAL, "the resident rows were factored for another rank / world size");
   if (!rc && (M < 0 || (M > 0 && (!Xs || !mean || !var)) || ldxs < e->D)) rc = fail(e, GMB_EINVAL, "bad Xs/M/ldxs/mean/var");
   if (!rc && hipSetDevice(e->device) != hipSuccess) rc = fail(e, GMB_EHIP, "hipSetDevice(%d) failed", e->device);
@@ -540,6 +543,9 @@ int cap_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M
   if (!rc) rc = cap_ensure(e, G, rank, cw);
   if (!rc) rc = cap_staging(e, G, cw);
   if (!rc) rc = ensure(e, &res, &cap_res, std::max<int64_t>(2 * width * (1 + G) + width * std::max(e->D, 1), 1));
+  // gmb_predict's own workspaces for the largest shard's M-tile, BEFORE the ranks agree to start: an allocation that fails
+  // inside a pass would take its rank out of gmb_predict ahead of the solve hook, i.e. ahead of the pass's all-gathers
+  if (!rc && width > 0) rc = predict_workspace(e, predict_tile_rows(e, width));
   e->coll_count = e->coll_hash = 0;
   rc = dist_agree(e, comm, rc, "gmb_dist_predict (set-up)");
   if (rc || M == 0) {
@@ -567,9 +573,16 @@ int cap_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M
         xs_dev = xs_stage;
         ld_dev = e->D;
       }
-      e->solve_hook = [&](double* V, int64_t ldv, int ntm) { return cap_solve(e, comm, V, ldv, ntm, bad); };
+      // exactly ONE visit of the hook per pass (mc <= the M-tile): a gmb_predict that leaves before it -- a failed copy or
+      // launch ahead of the solve -- is followed by the pass's gathers alone, so that this rank's peers are never left waiting
+      bool solved = false;
+      e->solve_hook = [&](double* V, int64_t ldv, int ntm) {
+        solved = true;
+        return cap_solve(e, comm, V, ldv, ntm, bad);
+      };
       if (!bad.rc) bad.note(e, gmb_predict(e, xs_dev, mc, ld_dev, with_noise, my_mean + m0, my_var + m0, GMB_DEVICE));
       e->solve_hook = nullptr;
+      if (!solved) cap_solve(e, comm, nullptr, TILE, 0, bad);
     } else {
       cap_solve(e, comm, nullptr, TILE, 0, bad);  // nothing of mine in this pass: the gathers only
     }

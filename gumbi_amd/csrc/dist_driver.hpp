@@ -299,6 +299,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   e->coll_count = e->coll_hash = 0;  // the issue log covers this call: its closing agreement compares the ranks' sequences
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_factorize (set-up)"))) return rc;
   e->factored = false;
+  e->factor_kind = gmb_engine::FK_REPLICATED;
   e->factor_consumed = false;
   e->have_alpha = false;
   e->notpd = -1;
@@ -505,6 +506,7 @@ int dist_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
   const int G = comm->world, rank = comm->rank;
   // ---- local checks and every allocation first, then the ranks agree ----
   rc = require_ready(e, true);
+  if (!rc) rc = require_full_factor(e, "gmb_dist_nlml (replicated mode)");
   if (!rc && !nlml) rc = fail(e, GMB_EINVAL, "nlml output pointer is null");
   if (!rc && e->factor_consumed) rc = fail(e, GMB_EINVAL, "the factor was already consumed by a gradient call; refactorize");
   if (!rc && hipSetDevice(e->device) != hipSuccess) rc = fail(e, GMB_EHIP, "hipSetDevice(%d) failed", e->device);
@@ -644,6 +646,7 @@ int dist_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t 
   if (rc) return rc;
   const int G = comm->world, rank = comm->rank;
   rc = require_ready(e, true);
+  if (!rc) rc = require_full_factor(e, "gmb_dist_predict (replicated mode)");
   if (!rc && (M < 0 || (M > 0 && (!Xs || !mean || !var)) || ldxs < e->D)) rc = fail(e, GMB_EINVAL, "bad Xs/M/ldxs/mean/var");
   if (!rc && hipSetDevice(e->device) != hipSuccess) rc = fail(e, GMB_EHIP, "hipSetDevice(%d) failed", e->device);
   auto bound = [&](int q) { return (int64_t)((double)M * q / G); };

@@ -109,6 +109,10 @@ struct gmb_engine {
   int32_t* dinfo = nullptr; // = dscal + SCAL_INFO_AT (and dgpart = dscal + SCAL_GACC_AT)
   double* dv = nullptr;
   bool factored = false;
+  // which path produced the resident factorisation (meaningful while `factored`): the single-engine and the replicated
+  // multi-GPU paths leave the COMPLETE factor in dA; the capacity driver leaves this rank's rows in dAown and nothing in dA
+  enum { FK_NONE = 0, FK_SINGLE = 1, FK_REPLICATED = 2, FK_CAPACITY = 3 };
+  int factor_kind = FK_NONE;
   bool factor_consumed = false;  // U = L^-T sits in the factor buffer's diagonal tiles (multi-GPU gradient; or a failed one)
   bool have_alpha = false;       // dalpha holds Sigma^-1 y of the current factorisation
   double* dDiagSave = nullptr;   // the factor's diagonal blocks while the gradient keeps U in their place
@@ -514,7 +518,7 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
     // half round of tail -- and a tile time is tile flops / intrinsic rate.  Intrinsic rates
     // measured on MI355X on large plain products (TF/s, r02 kernels with the interleaved staging):
     // 128x128 73, 64x64 63, 128x64 65, 128x32 60.  Measured launch by launch on the N = 10k fit
-    // (round 1, tools/gpu_variant_compare.py): always-128x128 61.7 ms, always-64x64 52.2 ms, best shape
+    // (round 1): always-128x128 61.7 ms, always-64x64 52.2 ms, best shape
     // per launch 51.0 ms.
     static const double rate[4] = {73.0, 63.0, 65.0, 60.0};
     static const int per128[4] = {1, 4, 2, 4};  // tiles per 128 x 128 block
@@ -1928,6 +1932,9 @@ int grad_chain_rule(gmb_engine* e, const std::vector<double>& h, double* grad) {
   return GMB_OK;
 }
 
+// -1 = by size (default), 0 = plain recursion, 2 = masked look-ahead streams, 3 = persistent tile kernel
+inline bool chol_scheme_valid(int s) { return s == -1 || s == 0 || s == 2 || s == 3; }
+
 int require_ready(gmb_engine* e, bool need_factor) {
   if (!e) return GMB_EINVAL;
   if (e->N <= 0) return fail(e, GMB_EINVAL, "gmb_set_data has not been called");
@@ -1935,6 +1942,23 @@ int require_ready(gmb_engine* e, bool need_factor) {
   if (!e->have_theta) return fail(e, GMB_EINVAL, "gmb_set_theta has not been called");
   if (need_factor && !e->factored)
     return fail(e, GMB_EINVAL, "no valid factorisation: call gmb_factorize first");
+  return GMB_OK;
+}
+
+// The calls that read the COMPLETE factor out of dA (single-engine gradient / prediction / factor windows, the replicated
+// multi-GPU passes) against a factorisation of the capacity driver, which leaves none there -- and the reverse: the capacity
+// passes against anything else than a capacity factorisation (their dAown would be an older theta's).
+int require_full_factor(gmb_engine* e, const char* what) {
+  if (e->factor_kind == gmb_engine::FK_CAPACITY || !e->dA || e->cap_A <= 0)
+    return fail(e, GMB_EINVAL, "%s needs the complete factor on this device, but the resident factorisation is a capacity-mode one "
+                               "(gmb_dist_set_mode(e, 1): no rank holds the factor) -- use the gmb_dist_* calls, or gmb_factorize first", what);
+  return GMB_OK;
+}
+
+int require_capacity_factor(gmb_engine* e, const char* what) {
+  if (e->factor_kind != gmb_engine::FK_CAPACITY || !e->dAown)
+    return fail(e, GMB_EINVAL, "%s in capacity mode needs a factorisation made by gmb_dist_factorize in capacity mode; the resident "
+                               "one was made by %s", what, e->factor_kind == gmb_engine::FK_SINGLE ? "gmb_factorize / gmb_evaluate" : "the replicated multi-GPU driver");
   return GMB_OK;
 }
 
@@ -1997,15 +2021,19 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   // Environment switches of the PRODUCT library: only the ones a test or a documented tools/ A-B uses.
   //   GMB_LEAF_NAIVE=1   the reference diagonal-block kernel (tests/test_gpu_parity.py::test_potrf_leaf_block)
   //   GMB_CHOL_SCHEME    0 = plain recursion, 2 = masked look-ahead, 3 = persistent tile kernel, for every size
-  //                      (tests/test_gpu_parity.py::test_cholesky_schedules_agree; tools/gpu_ab_env.py); default: by size
-  //   GMB_TRACE_FILE     per-launch event log while profiling (tools/gpu_trace_run.py, tools/gpu_bulk_trace.py)
+  //                      (tests/test_gpu_parity.py::test_cholesky_schedules_agree); default: by size
+  //   GMB_TRACE_FILE     per-launch event log while profiling (tools/gpu_timeline_run.py)
   //   GMB_GEMM_DMA=0     the 128 x 128 GEMM with register staging instead of the LDS-DMA ring (tools/gpu_ab_gemm_dma.py)
   // Everything else is compiled in only with -DGMB_TUNING (GUMBI_BUILD_TUNING=1 python -m gumbi_amd.build writes
   // gumbi_amd/lib/libgumbi_hip_tuning.so; tools/README.md).
   e->naive_leaf = flag("GMB_LEAF_NAIVE", false);
   e->gemm_dma = flag("GMB_GEMM_DMA", true);
   const char* cs = getenv("GMB_CHOL_SCHEME");
-  if (cs) e->chol_scheme = atoi(cs);
+  if (cs && cs[0]) {
+    const int v = atoi(cs);
+    if (chol_scheme_valid(v)) e->chol_scheme = v;
+    else fprintf(stderr, "[gumbi_hip] GMB_CHOL_SCHEME=%s ignored: valid schemes are -1 (by size), 0, 2, 3\n", cs);
+  }
   int part = 32;  // compute units the masked bulk stream leaves to the panel chain
 #ifdef GMB_TUNING
   e->small_tiles = flag("GMB_SMALL_TILES", true);
@@ -2286,6 +2314,7 @@ int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
   if (rc) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
   e->factored = false;
+  e->factor_kind = gmb_engine::FK_SINGLE;
   e->factor_consumed = false;
   e->have_alpha = false;
   e->notpd = -1;
@@ -2464,12 +2493,49 @@ int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, do
   return grad ? grad_chain_rule(e, h, grad) : GMB_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// M is tiled so that the solved cross-covariance (Mt x Np doubles) stays within ~8 GiB
+int64_t predict_tile_rows(const gmb_engine* e, int64_t M) {
+  int64_t mt_max = (int64_t)(8.0 * 1024 * 1024 * 1024 / 8.0 / (double)e->Np);
+  mt_max = std::max<int64_t>(TILE, std::min<int64_t>(mt_max / TILE * TILE, 32768));
+  return std::min<int64_t>(round_up(M, TILE), mt_max);
+}
+
+// Every allocation of gmb_predict for M-tiles of Mt rows.  The capacity driver calls it BEFORE its ranks agree to start a
+// prediction: a rank that ran out of memory here would otherwise leave gmb_predict before the solve hook, i.e. without
+// issuing the pass's all-gathers, with its peers blocked inside them.
+int predict_workspace(gmb_engine* e, int64_t Mt) {
+  int rc;
+  if (e->Mt_cap < Mt) {
+    e->Mt_cap = 0;  // (a failure half-way leaves no capacity claimed)
+    if ((rc = alloc(e, &e->dV, Mt * e->Np))) return rc;
+    if ((rc = alloc(e, &e->dXs, Mt * (int64_t)e->D))) return rc;
+    if ((rc = alloc(e, &e->txs, (int64_t)17 * Mt))) return rc;
+    if ((rc = alloc(e, &e->txl, (int64_t)MAX_LIN * Mt))) return rc;
+    if ((rc = alloc(e, &e->tcat, (int64_t)MAX_TABS * Mt))) return rc;
+    if ((rc = alloc(e, &e->dkss, Mt))) return rc;
+    if ((rc = alloc(e, &e->dmean, Mt))) return rc;
+    if ((rc = alloc(e, &e->dvar, Mt))) return rc;
+    e->Mt_cap = Mt;
+  }
+  const int nchunk = (int)((e->N + RED_CHUNK - 1) / RED_CHUNK);
+  return ensure(e, &e->dpart, &e->cap_part, (int64_t)2 * nchunk * e->Mt_cap);
+}
+
+}  // namespace
+
+extern "C" {
+
 int gmb_nlml(gmb_engine* e, double* nlml, double* grad) {
   int rc = require_ready(e, true);
   if (rc) return rc;
   if (!nlml) return fail(e, GMB_EINVAL, "nlml output pointer is null");
   *nlml = 0.5 * (double)e->N * std::log(2.0 * M_PI) + e->logdet + 0.5 * e->vnorm2;
   if (grad) {
+    if ((rc = require_full_factor(e, "gmb_nlml with a gradient"))) return rc;
     std::vector<double> h;
     if ((rc = grad_accumulate(e, h))) return rc;
     return grad_chain_rule(e, h, grad);
@@ -2484,6 +2550,8 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
   if (M < 0 || (M > 0 && (!Xs || !mean || !var)) || ldxs < e->D)
     return fail(e, GMB_EINVAL, "bad Xs/M/ldxs/mean/var");
   if (M == 0) return GMB_OK;
+  // (the capacity driver's passes come through here with their own triangular solve; everybody else reads the factor in dA)
+  if ((rc = e->solve_hook ? require_capacity_factor(e, "gmb_predict") : require_full_factor(e, "gmb_predict"))) return rc;
   if (e->factor_consumed)
     return fail(e, GMB_EINVAL, "the factor was consumed by a gradient call: call gmb_factorize again");
   HIP_TRY(e, hipSetDevice(e->device));
@@ -2491,23 +2559,9 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
   tm.predict_ms = tm.predict_gemm_ms = tm.predict_gemm_flops = 0.0;
   tm.predict_gemm_launches = 0;
 
-  // tile M so that the solved cross-covariance (Mt x Np doubles) stays within ~8 GiB
-  int64_t mt_max = (int64_t)(8.0 * 1024 * 1024 * 1024 / 8.0 / (double)e->Np);
-  mt_max = std::max<int64_t>(TILE, std::min<int64_t>(mt_max / TILE * TILE, 32768));
-  const int64_t Mt = std::min<int64_t>(round_up(M, TILE), mt_max);
-  if (e->Mt_cap < Mt) {
-    if ((rc = alloc(e, &e->dV, Mt * e->Np))) return rc;
-    if ((rc = alloc(e, &e->dXs, Mt * (int64_t)e->D))) return rc;
-    if ((rc = alloc(e, &e->txs, (int64_t)17 * Mt))) return rc;
-    if ((rc = alloc(e, &e->txl, (int64_t)MAX_LIN * Mt))) return rc;
-    if ((rc = alloc(e, &e->tcat, (int64_t)MAX_TABS * Mt))) return rc;
-    if ((rc = alloc(e, &e->dkss, Mt))) return rc;
-    if ((rc = alloc(e, &e->dmean, Mt))) return rc;
-    if ((rc = alloc(e, &e->dvar, Mt))) return rc;
-    e->Mt_cap = Mt;
-  }
+  const int64_t Mt = predict_tile_rows(e, M);
+  if ((rc = predict_workspace(e, Mt))) return rc;
   const int nchunk = (int)((e->N + RED_CHUNK - 1) / RED_CHUNK);
-  if ((rc = ensure(e, &e->dpart, &e->cap_part, (int64_t)2 * nchunk * e->Mt_cap))) return rc;
 
   const hipMemcpyKind in_kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   const hipMemcpyKind out_kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -2609,7 +2663,8 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
 int gmb_copy_factor(const gmb_engine* ce, int64_t r0, int64_t nr, int64_t c0, int64_t nc, double* out) {
   gmb_engine* e = const_cast<gmb_engine*>(ce);
   if (!e || !out) return GMB_EINVAL;
-  if (!e->dA || r0 < 0 || c0 < 0 || nr < 0 || nc < 0 || r0 + nr > e->Nr || c0 + nc > e->Np)
+  if (e->factored && require_full_factor(e, "gmb_copy_factor")) return GMB_EINVAL;
+  if (!e->dA || e->cap_A <= 0 || r0 < 0 || c0 < 0 || nr < 0 || nc < 0 || r0 + nr > e->Nr || c0 + nc > e->Np)
     return fail(e, GMB_EINVAL, "factor window out of range");
   if (nr == 0 || nc == 0) return GMB_OK;
   std::vector<double> tmp((size_t)nr * nc);  // column-major window
@@ -2848,6 +2903,7 @@ int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n) {
 
 int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme) {
   if (!e) return GMB_EINVAL;
+  if (!chol_scheme_valid(scheme)) return fail(e, GMB_EINVAL, "Cholesky scheme %d: valid are -1 (by size), 0, 2, 3", scheme);
   const int old = e->chol_scheme;
   e->chol_scheme = scheme;
   return old + 1;  // previous scheme + 1: "by size" (-1) comes back as 0, so no valid answer collides with a (negative) status
@@ -2965,8 +3021,23 @@ extern "C" {
 int gmb_dist_set_mode(gmb_engine* e, int32_t mode) {
   if (!e || mode < 0 || mode > 1) return GMB_EINVAL;
   const int old = e->dist_mode;
-  if (old != mode) e->factored = false;
+  if (old != mode) {
+    e->factored = false;
+    e->factor_kind = gmb_engine::FK_NONE;
+  }
   e->dist_mode = mode;
+  if (mode == 1) {
+    // the point of the mode is that no rank keeps an Nr x Np buffer: one left behind by an earlier single-engine or replicated
+    // factorisation goes now (its factorisation was just invalidated, or is of no use to the capacity passes)
+    if (e->dA && e->cap_A > 0) {
+      if (hipSetDevice(e->device) == hipSuccess) (void)hipStreamSynchronize(e->stream);
+      release(e, e->dA);
+      e->factored = false;
+      e->factor_kind = gmb_engine::FK_NONE;
+    }
+    e->dA = nullptr;
+    e->cap_A = 0;
+  }
   return old;
 }
 

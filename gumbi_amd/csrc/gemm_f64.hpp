@@ -329,7 +329,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, const int vbid)
     // non-MFMA work at the k-tile seams); left to itself the compiler hoists every fragment read, then waits
     // for the global loads right after issuing them (63 TF/s).  Measured on one box, 8192^3 / 16384^2 x 3072:
     // 69.1 / 68.5 TF/s before, 73.4 / 73.0 TF/s with this order; N = 30k factorisation 152.3 -> 146.7 ms,
-    // gradient 272.7 -> 263.5 ms (tools/gpu_ab_gemm.py; s_setprio around the MFMAs: -5 %; explicit fragment
+    // gradient 272.7 -> 263.5 ms (round-2 A/B; s_setprio around the MFMAs: -5 %; explicit fragment
     // prefetch: no change; loop rotated by one k4 group so that the last 16 MFMAs of a tile sit behind the
     // barrier and cover the next tile's first LDS reads: -1.5 %).
     constexpr int NMFMA = WTM * WTN * (KT / 4), NMEM = NA + NB;

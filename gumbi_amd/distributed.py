@@ -167,25 +167,68 @@ class TorchDistComm:
         pass
 
 
-def _handshake(comm, device_index: int) -> bool:
-    """One all-gather of four doubles per rank through ``comm`` (the ``gmb_comm`` the native driver will call), verified:
-    slot r of the result must hold rank r's values."""
+def _all_ranks_ok(ok: bool, group, dev) -> bool:
+    """MIN over the group's ranks of a local flag, through ``torch.distributed`` (not the communicator under test)."""
     import torch
+    import torch.distributed as dist
+
+    if dist.get_world_size(group) == 1:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
+def _handshake(comm, device_index: int, group=None, deadline_s: float | None = None) -> bool:
+    """One all-gather of four doubles per rank through ``comm`` (the ``gmb_comm`` the native driver will call), verified:
+    slot r of the result must hold rank r's values.  Collective over ``group``; every rank returns the same answer.
+
+    Everything that can fail LOCALLY (allocations, the handle) happens first and the ranks agree on it through
+    ``torch.distributed`` -- a rank that cannot even start must not leave its peers inside the RCCL call.  The all-gather
+    itself runs on a side stream and is awaited by polling an event against a deadline (``GUMBI_DIST_HANDSHAKE_S``, default
+    60 s): a communicator that delivers nothing is reported as failed instead of blocking the process for ever."""
+    import time
+
+    import torch
+    import torch.distributed as dist
 
     dev = torch.device("cuda", device_index)
+    agree_dev = dev if dist.get_backend(group) == "nccl" else "cpu"
+    deadline_s = float(os.environ.get("GUMBI_DIST_HANDSHAKE_S", "60")) if deadline_s is None else deadline_s
     n = 4
+    h = send = recv = side = done = None
     try:
         h = comm.handle.contents
         send = torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * (h.rank + 1)
         recv = torch.full((h.world * n,), -1.0, dtype=torch.float64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        done = torch.cuda.Event()
         torch.cuda.synchronize(dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        rc = h.all_gather(h.ctx, send.data_ptr(), recv.data_ptr(), n, stream)
-        torch.cuda.synchronize(dev)
-        want = (torch.arange(n, dtype=torch.float64)[None, :] + 1000.0 * (torch.arange(h.world, dtype=torch.float64)[:, None] + 1)).reshape(-1)
-        return rc == 0 and bool(torch.equal(recv.cpu(), want))
+        ready = True
     except Exception:  # noqa: BLE001 -- whatever went wrong, the caller falls back to torch.distributed's collectives
+        ready = False
+    if not _all_ranks_ok(ready, group, agree_dev):
         return False
+    delivered = False
+    try:
+        rc = h.all_gather(h.ctx, send.data_ptr(), recv.data_ptr(), n, side.cuda_stream)
+        done.record(side)
+        t_end = time.perf_counter() + deadline_s
+        while not done.query() and time.perf_counter() < t_end:
+            time.sleep(0.002)
+        if done.query():
+            want = (torch.arange(n, dtype=torch.float64)[None, :] + 1000.0 * (torch.arange(h.world, dtype=torch.float64)[:, None] + 1)).reshape(-1)
+            delivered = rc == 0 and bool(torch.equal(recv.cpu(), want))
+        else:
+            import sys
+
+            sys.stderr.write(f"[gumbi_amd] first all-gather through the library's RCCL communicator did not complete within {deadline_s:.0f} s "
+                             f"on rank {h.rank}\n")
+    except Exception:  # noqa: BLE001
+        delivered = False
+    if not delivered:
+        comm._handshake_buffers = (send, recv, side, done)  # a collective that may still be in flight keeps its buffers
+    return _all_ranks_ok(delivered, group, agree_dev)
 
 
 def make_comm(device_index: int, group=None, prefer: str | None = None):
@@ -217,12 +260,9 @@ def make_comm(device_index: int, group=None, prefer: str | None = None):
         ok = int(flag.item())
     if ok:
         # first contact: one small all-gather through the new communicator, checked on every rank, before the driver's panel
-        # loop depends on it (a communicator that delivers the wrong ranks' data -- or none -- is replaced, not trusted)
-        ok = 1 if _handshake(comm, device_index) else 0
-        if dist.get_world_size(group) > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            ok = int(flag.item())
+        # loop depends on it (a communicator that delivers the wrong ranks' data -- or none -- is replaced, not trusted);
+        # the ranks agree on the outcome inside _handshake
+        ok = 1 if _handshake(comm, device_index, group) else 0
         if not ok:
             import sys
 

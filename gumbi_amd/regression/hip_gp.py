@@ -65,26 +65,63 @@ class HipModel:
 
 
 _BLAS_CONTROLLER = None
+_BLAS_LIBS_SEEN = -1
 
 
 def _single_threaded_host_blas(engine):
     """Context for the optimiser's loop when the evaluations run on the GPU: scipy's L-BFGS-B factors its m x m (m <= 10)
     matrices with LAPACK, and a many-threaded OpenBLAS spends 0.1 - 20 ms per iteration waking its pool for them -- more than a
     whole MAP evaluation at Gumbi's usual sizes (N = 392: 0.27 ms).  One thread inside ``minimize`` only, and only for engines
-    whose arithmetic is not the host's BLAS (``host_blas_free``); the library scan is done once per process."""
-    import contextlib
+    whose arithmetic is not the host's BLAS (``host_blas_free``).
 
-    if not getattr(engine, "host_blas_free", False):
+    The limit is PROCESS-GLOBAL while the context is open (that is how threadpoolctl works): another thread doing host BLAS work
+    during ``find_MAP`` is throttled too.  ``GUMBI_HOST_BLAS_LIMIT=0`` switches it off.  The library scan is cached and redone
+    when the number of shared objects in the process changed -- a BLAS loaded after the first fit (torch's bundled copy, a
+    second numpy / scipy one) is then covered as well; counting the objects costs ~20 us, a scan ~2 ms."""
+    import contextlib
+    import os
+
+    if not getattr(engine, "host_blas_free", False) or os.environ.get("GUMBI_HOST_BLAS_LIMIT", "1") == "0":
         return contextlib.nullcontext()
-    global _BLAS_CONTROLLER
+    global _BLAS_CONTROLLER, _BLAS_LIBS_SEEN
     try:
-        if _BLAS_CONTROLLER is None:
+        n_libs = _loaded_shared_objects()
+        if _BLAS_CONTROLLER is None or n_libs != _BLAS_LIBS_SEEN:
             from threadpoolctl import ThreadpoolController
 
             _BLAS_CONTROLLER = ThreadpoolController()
+            _BLAS_LIBS_SEEN = n_libs
         return _BLAS_CONTROLLER.limit(limits=1, user_api="blas")
     except Exception:  # noqa: BLE001 -- no threadpoolctl, or a BLAS it cannot steer: the fit is merely slower
         return contextlib.nullcontext()
+
+
+def _loaded_shared_objects() -> int:
+    """How many shared objects the process has mapped (dl_iterate_phdr): changes when a library -- e.g. another BLAS -- is loaded."""
+    import ctypes
+
+    global _PHDR_COUNTER
+    try:
+        if _PHDR_COUNTER is None:
+            cb_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+            count = [0]
+
+            def _cb(_info, _size, _data):
+                count[0] += 1
+                return 0
+
+            libc = ctypes.CDLL(None)
+            libc.dl_iterate_phdr.argtypes = [cb_t, ctypes.c_void_p]
+            _PHDR_COUNTER = (libc, cb_t(_cb), count)
+        libc, cb, count = _PHDR_COUNTER
+        count[0] = 0
+        libc.dl_iterate_phdr(cb, None)
+        return count[0]
+    except Exception:  # noqa: BLE001 -- no dl_iterate_phdr: behave as before (one scan per process)
+        return 0
+
+
+_PHDR_COUNTER = None
 
 
 class HipGP(Regressor):

@@ -319,6 +319,81 @@ def test_capacity_mode_at_n_20k_keeps_each_rank_well_below_a_single_engine(pool,
     assert len({r[-1] for r in results}) == 1
 
 
+def _capacity_guard_task(rank, world, group, out):
+    """the single-engine entry points against a capacity-mode factorisation and the reverse mix."""
+    from gumbi_amd.distributed import DistributedEngine
+    from gumbi_amd.engine import Engine, KernelSpec
+    from oracle import gp_oracle as O
+
+    N, d = 1500, 3
+    X, y, ls = O.synthetic_table(N, d, seed=11)
+    theta = np.concatenate([ls, [1.0, 0.25]])
+    kspec = KernelSpec(D=d, idx_cont=list(range(d)), kind="ExpQuad")
+    Xs = np.random.default_rng(2).standard_normal((200, d))
+    res = {}
+    # (a) a full factor left behind by a single-engine factorisation goes when the mode is switched on
+    e1 = Engine(0)
+    e1.set_data(X, y)
+    e1.set_kernel(kspec)
+    e1.set_theta(theta)
+    e1.factorize()
+    before = e1.resident_bytes()
+    e1.set_dist_mode(Engine.DIST_CAPACITY)
+    res["released"] = before - e1.resident_bytes()
+    res["full_buffer"] = 8 * (((N + 1 + 127) // 128) * 128) * (((N + 127) // 128) * 128)
+    res["valid_after_switch"] = e1.factor_is_current()
+    e1.close()
+    eng = DistributedEngine(0, group, panel_blocks=2, capacity=True)
+    eng.set_data(X, y)
+    eng.set_kernel(kspec)
+    eng.set_theta(theta)
+    eng.factorize()
+    mu, var = eng.predict(Xs)
+
+    def refused(fn):
+        try:
+            fn()
+            return "no error"
+        except ValueError as err:
+            return str(err)
+
+    # (b) the calls that read the complete factor out of dA: refused, with a message that says why
+    res["predict"] = refused(lambda: eng.eng.predict(Xs))
+    res["grad"] = refused(lambda: eng.eng.nlml(grad=True))
+    res["copy_factor"] = refused(lambda: eng.eng.copy_factor())
+    res["value_only"] = eng.eng.nlml()  # (log-det and |v|^2 are replicated scalars: no factor needed)
+    mu_b, var_b = eng.predict(Xs)       # ... and the capacity factorisation is still intact
+    res["intact"] = bool(mu_b.tobytes() == mu.tobytes() and var_b.tobytes() == var.tobytes())
+    # (c) the reverse: a single-engine factorisation, then the capacity passes (their rows would be an older theta's)
+    eng.set_theta(theta * 1.05)
+    eng.eng.factorize()
+    res["cap_grad_after_single"] = refused(lambda: eng.nlml(grad=True))
+    res["cap_predict_after_single"] = refused(lambda: eng.predict(Xs))
+    mu_s, _ = eng.eng.predict(Xs)       # (the single engine's own prediction works: it made that factor)
+    eng.set_theta(theta)
+    eng.factorize()
+    mu_c, var_c = eng.predict(Xs)
+    res["back"] = bool(mu_c.tobytes() == mu.tobytes() and var_c.tobytes() == var.tobytes())
+    res["single_differs"] = bool(np.max(np.abs(mu_s - mu)) > 1e-6)
+    eng.close()
+    out.put((rank, res))
+
+
+def test_capacity_mode_and_single_engine_calls_do_not_mix_silently(pool):
+    """``cap_factorize`` leaves no factor in dA: gmb_predict / gmb_nlml(grad) / gmb_copy_factor on such an engine return
+    GMB_EINVAL instead of running on a null or stale buffer, gmb_dist_nlml / gmb_dist_predict in capacity mode refuse a
+    factorisation they did not make, and switching the mode on releases an Nr x Np buffer that is already there."""
+    for rank, r in pool.run(_capacity_guard_task, 2):
+        assert r["released"] >= r["full_buffer"] and not r["valid_after_switch"], r
+        for key in ("predict", "grad", "copy_factor"):
+            assert "capacity-mode" in r[key], (key, r[key])
+        assert np.isfinite(r["value_only"]) and r["intact"]
+        for key in ("cap_grad_after_single", "cap_predict_after_single"):
+            # (rank 0 reports its own refusal; a later rank may report rank 0's, which it learns of first at the agreement)
+            assert "needs a factorisation made by gmb_dist_factorize in capacity mode" in r[key] or (rank > 0 and "failed with status" in r[key]), (key, r[key])
+        assert r["back"] and r["single_differs"]
+
+
 def _notpd_task(rank, world, group, out):
     from gumbi_amd.distributed import DistributedEngine
     from gumbi_amd.engine import Engine, KernelSpec
