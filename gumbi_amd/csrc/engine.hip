@@ -559,13 +559,20 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   double flops = 0.0;
   const int nblocks = gemm_schedule(g, bm, bn, &flops);
   if (nblocks <= 0) return GMB_OK;
+  // Population 7 = the Cholesky's BULK trailing updates = the kind-7 launches that run the 128 x 128 kernel; they go through an
+  // entry point of their own (gemm_f64_dma_chol_update_kernel, the same body), so that a rocprofv3 kernel trace lists exactly
+  // the launches the live events of `roofline` time.  Kind-7 launches small enough for another tile shape count as in-panel
+  // products (kind 0), like the panels' own.
+  const bool bulk_update = ev_kind == 7 && variant == 0 && !in_place;
+  if (ev_kind == 7 && !bulk_update) ev_kind = 0;
   ev_begin(e, ev_kind, flops, g_in.mt, g_in.nt, g.k,
            g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (variant << 8));
   const dim3 grid(nblocks);
   const bool pfc = g.beta != 0.0 && g.k <= 1024 && !in_place;
   switch (variant) {
     case 0:
-      if (e->gemm_dma && !in_place) hipLaunchKernelGGL(gemm_f64_dma_kernel, grid, dim3(256), 0, e->cur, g);
+      if (e->gemm_dma && bulk_update) hipLaunchKernelGGL(gemm_f64_dma_chol_update_kernel, grid, dim3(256), 0, e->cur, g);
+      else if (e->gemm_dma && !in_place) hipLaunchKernelGGL(gemm_f64_dma_kernel, grid, dim3(256), 0, e->cur, g);
       else hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 4, 4, 2>), grid, dim3(256), 0, e->cur, g);
       break;
 #ifdef GMB_TUNING

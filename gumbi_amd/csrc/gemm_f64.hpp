@@ -529,6 +529,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_dma_kernel(GemmArgs g) {
   gemm_f64_dma_body<>(g, blockIdx.x);
 }
 
+// The same body under a second name: the Cholesky's bulk trailing updates (SYRK / GEMM on the factor's trailing columns), so
+// that profilers list that population -- the one the north star states its MFMA target on -- as a kernel of its own.
+__global__ __launch_bounds__(256, 2) void gemm_f64_dma_chol_update_kernel(GemmArgs g) {
+  gemm_f64_dma_body<>(g, blockIdx.x);
+}
+
 template <int WGM, int WGN, int WTM, int WTN, int OCC, bool PFC = false>
 __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f64_kernel(GemmArgs g) {
   gemm_f64_body<WGM, WGN, WTM, WTN, PFC>(g, blockIdx.x);

@@ -280,6 +280,22 @@ class IcmEngine:
                 return False
         return True
 
+    # -- measurement (bench.py --config c4) -----------------------------------------------------------------------
+    def set_profiling(self, on):
+        """Per-launch HIP events on every inner engine (resets their totals)."""
+        for eng in self._engs:
+            eng.set_profiling(on)
+
+    def timings(self):
+        """The inner engines' ``gmb_timings`` with the cumulative ``total_*`` counters summed over the P systems (the
+        per-call fields are engine 0's)."""
+        tms = [eng.timings() for eng in self._engs]
+        out = dict(tms[0])
+        for key in out:
+            if key.startswith("total_"):
+                out[key] = type(out[key])(sum(t[key] for t in tms))
+        return out
+
     def close(self):
         for eng in reversed(self._engs):  # siblings first: they borrow engine 0's streams
             eng.close()

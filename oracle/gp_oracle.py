@@ -429,7 +429,18 @@ def _kernel_grad_given_M(spec, theta, X, M, dist_mode="direct"):
     MF = M * Fm
     # lengthscales: d r2/d ls_k = -2 (x_k-x'_k)^2 / ls_k^3
     dk = p["eta"] ** 2 * _stationary_dr2(spec["kind"], r2)
-    if spec["ard"]:
+    if spec["ard"] and dist_mode == "gemm":
+        # The expanded form PyMC's graph differentiates (square_dist = |x|^2 + |x'|^2 - 2 x.x'; reverse mode sends the
+        # cotangent G = M * dk through the dot product): sum_ij G_ij (x_ik - x_jk)^2 = sum_i x_ik^2 (R_i + C_i) - 2 x_k^T G x_k
+        # with R, C the row and column sums of G -- one N x N x d product instead of d passes over N x N temporaries.
+        G = MF * dk
+        rc = G.sum(axis=1) + G.sum(axis=0)
+        GX = G @ Xc
+        for j in range(len(ic)):
+            xj = Xc[:, j]
+            g[k + j] = -2.0 / p["ls"][j] ** 3 * (float(np.dot(xj * xj, rc)) - 2.0 * float(np.dot(xj, GX[:, j])))
+        k += len(ic)
+    elif spec["ard"]:
         for j in range(len(ic)):
             dj = Xc[:, j][:, None] - Xc[:, j][None, :]
             g[k + j] = np.sum(MF * dk * (-2.0) * dj * dj / p["ls"][j] ** 3)

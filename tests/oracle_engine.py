@@ -53,3 +53,27 @@ class OracleEngine:
 
     def close(self):
         pass
+
+
+class HostBaselineEngine(OracleEngine):
+    """The stand-in ``bench.py --cpu-fit`` times as the host baseline: PyMC's own distance expansion (``dist_mode="gemm"``, the
+    form pm.gp.cov.Stationary.square_dist computes and differentiates) and ONE factorisation per objective evaluation
+    (``evaluate`` -- what a compiled PyTensor value-and-gradient function does), instead of the parity tests' direct
+    differences and their separate factorize / nlml calls."""
+
+    host_blas_free = False  # its arithmetic IS the host's BLAS: find_MAP must not throttle it to one thread
+
+    def evaluate(self, theta, grad=True):
+        self.set_theta(theta)
+        if not grad:
+            return O.nlml(self.spec, self.theta, self.X, self.y, dist_mode="gemm")
+        out = O.nlml_and_grad(self.spec, self.theta, self.X, self.y, dist_mode="gemm")
+        self._factored = True
+        return out
+
+    def factorize(self):
+        O.factorize(self.spec, self.theta, self.X, self.y, dist_mode="gemm")
+        self._factored = True
+
+    def predict(self, Xs, with_noise=True):
+        return O.predict(self.spec, self.theta, self.X, self.y, np.asarray(Xs, float), with_noise=with_noise, dist_mode="gemm")

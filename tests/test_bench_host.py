@@ -82,6 +82,26 @@ def test_configs_name_the_baseline_workloads():
     assert bench.CONFIGS["c3"]["N"] == 50_000 and bench.CONFIGS["c3"]["d"] == 8 and bench.CONFIGS["c3"]["kernel"] == "Matern52"
     assert bench.CONFIGS["c2"]["N"] == 10_000 and bench.CONFIGS["c2"]["d"] == 4
     assert bench.CONFIGS["c5"]["d"] == 8 and bench.CONFIGS["c5"]["kernel"] == "ExpQuad"
+    assert bench.CONFIGS["c4"]["N"] == 20_000 and bench.CONFIGS["c4"]["d"] == 4 and bench.CONFIGS["c4"]["P"] == 2
+
+
+def test_c4_table_is_the_survey_generator_and_its_flops_are_the_kronecker_forms():
+    """bench.py's C4 table = the generator tests/test_gpu_configs.py::icm_problem restates (same draws, same stacking), so the
+    bench times the problem the parity tests check; flops of a step = P systems of N^3 per evaluation."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_gpu_configs import icm_problem
+
+    bench = load_bench()
+    cfg = dict(bench.CONFIGS["c4"], N=300)
+    Xc, Y, ls, Xg, Fg = bench.c4_table(cfg)
+    X, y, _spec, _theta = icm_problem(300, 4)
+    assert np.array_equal(X[:300, :4], Xc) and np.array_equal(X[300:, :4], Xc) and np.array_equal(X[:, 4], np.repeat([0.0, 1.0], 300))
+    z = np.concatenate([(Y[p] - Y[p].mean()) / Y[p].std(ddof=1) for p in range(2)])
+    assert np.allclose(z, y, rtol=0, atol=1e-14)
+    assert Xg.shape == (10_000, 4) and Fg.shape == (2, 10_000) and np.all(np.isfinite(Fg))
+    assert bench.c4_step_flops(1000, 2, 500, 3, 1) == 2 * (3 * 1e9 + 1e9 / 3 + 1e6 * 500 + 4.0 * 1000 * 500)
+    r = bench.cpu_baseline_c4(dict(cfg, N=256, res=8), target_seconds=0.01)
+    assert r["kind"] == "port" and r["value"] > 0 and "256 rows x 2 outputs" in r["sample"]
 
 
 def test_truth_matches_the_table_and_fit_quality_sees_a_fit(monkeypatch):

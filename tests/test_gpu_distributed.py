@@ -791,7 +791,7 @@ def test_bench_contract_single_process(gpu):
         _POOL[0] = None
     root = Path(__file__).resolve().parent.parent
     # (the host's config-size sections -- minutes of CPU time: a whole C2 fit over the oracle, a 50k dpotrf -- are switched off here)
-    env = dict(os.environ, GUMBI_BENCH_DIST_N="2304", GUMBI_BENCH_CPU_SECONDS="2", GUMBI_BENCH_NO_CPU_CONFIG_SIZE="1")
+    env = dict(os.environ, GUMBI_BENCH_DIST_N="2304", GUMBI_BENCH_C4_N="1536", GUMBI_BENCH_CPU_SECONDS="2", GUMBI_BENCH_NO_CPU_CONFIG_SIZE="1")
     out = subprocess.run([sys.executable, str(root / "bench.py"), "--config", "c2", "--steps", "1", "--warmup", "0",
                           "--map-evals", "4"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -826,6 +826,49 @@ def test_bench_contract_single_process(gpu):
     assert ce["before_timed_region"]["seconds"] >= 1.0 and 1500 < ce["after_timed_region"]["shader_mhz"] < 2600
     assert r["achieved_le_ceiling"] is True
     assert d["default_start"]["fit_quality"]["n_eval"] >= 1 and d["bench_wall_s"] > 0
+    assert "restatement" in d["default_start"]["note"].lower() and "1e-3" in d["parity_pin"] and "1e-8" in d["parity_pin"]
+    assert d["roofline_frac_dominant_kernel"] == r["frac"] and abs(d["roofline_frac_whole_step"] - d["value"] / 1e3 / r["peak"]) < 1e-3
+    # BASELINE configs[3] as a side figure: the two-output GP through the Kronecker path, the stacked engine beside it
+    c4 = d["c4_single_gpu"]
+    assert "error" not in c4 and "skipped" not in c4, c4
+    assert c4["results_finite"] and c4["seconds_per_map_evaluation"] > 0 and "N=1536" in c4["workload"] and "CAPPED" in c4["step"]
+    assert "eval_tiles_kernel" in c4["roofline"]["kernel"] and 0 < c4["roofline"]["frac"] < 1
+    assert c4["phases"]["stacked_map_evaluation_ms"] > 0 and c4["phases"]["kronecker_map_evaluation_ms"] > 0
+
+
+def test_bench_config_c4_is_the_kronecker_fit(gpu):
+    """``python bench.py --config c4`` (BASELINE.json configs[3], shrunk by the test hook): the two-output coregionalised GP
+    declared through DataSet -> GP(outputs=[y0, y1]) -> build_model, fitted through the Kronecker engine HipGP chooses, predicted
+    on the grid of both outputs; roofline = the P N x N evaluation launches; cpu_baseline = the oracle's STACKED evaluation."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    if _POOL[0] is not None:
+        _POOL[0].close()
+        _POOL[0] = None
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GUMBI_BENCH_C4_N="1536", GUMBI_BENCH_CPU_SECONDS="2")
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--config", "c4", "--steps", "1", "--warmup", "1", "--map-evals", "12"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["results_finite"]
+    assert "Kronecker" in d["metric"] and d["config"]["outputs"] == 2 and d["config"]["N"] == 1536 and d["config"]["M"] == 20_000
+    n_eval = d["config"]["map_evals_per_step"][0]
+    assert 1 <= n_eval <= 20 and d["fit_quality"]["n_hyperparameters"] == 18
+    flops = 2 * (n_eval * 1536.0**3 + d["config"]["refactorizations_at_the_map_per_step"][0] * 1536.0**3 / 3 + 1536.0**2 * 20_000 + 4.0 * 1536 * 20_000)
+    assert abs(d["value"] - flops / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert "eval_tiles_kernel" in r["kernel"] and r["launches"] >= 2 and 0 < r["frac"] < 1
+    ph = d["phases"]
+    assert ph["stacked_map_evaluation_ms"] > 0 and ph["kronecker_map_evaluation_ms"] > 0 and ph["stacked_over_kronecker"]["map_evaluation"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and "stacked" in c["sample"] and c["value"] > 0
+    assert "c5_single_gpu" not in d and "1e-3" in d["parity_pin"]
 
 
 def test_bench_default_config_is_the_largest_single_gpu_one():

@@ -158,3 +158,20 @@ def test_additive_model_covariance_and_gradient(two_outputs, lin, hetero):
     Xs[:, 0] += 0.1
     mu, var = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
     assert np.all(np.isfinite(mu)) and np.all(var > 0)
+
+
+def test_host_posterior_blockwise_is_the_oracle():
+    """tests/host_reference.py (the full-size host check of tests/test_gpu_configs.py) against ``O.predict`` / ``O.nlml`` at a size where both run in a second."""
+    from host_reference import host_posterior_blockwise
+
+    def rel(a, b):
+        return np.max(np.abs(a - b)) / np.max(np.abs(b))
+
+    N, d = 1500, 8
+    X, y, ls = O.synthetic_table(N, d)
+    spec = O.make_spec(d, range(d), kind="Matern52")
+    theta = O.pack_theta(spec, ls, 1.0, 0.2)
+    Xs = O.synthetic_grid(d, res=6)
+    mu, var, nl = host_posterior_blockwise(spec, theta, X, y, Xs, block=200, threads=3)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, with_noise=True)
+    assert rel(mu, mu_r) < 1e-12 and np.max(np.abs(var - var_r)) < 1e-12 and np.isclose(nl, O.nlml(spec, theta, X, y), rtol=1e-13)
