@@ -865,7 +865,7 @@ PointSet train_set(const gmb_engine* e) { return PointSet{e->xs, e->xl, e->cat, 
 // the full factor buffer (Nr x Np, leading dimension Nr), allocated on first use
 int ensure_factor_buffer(gmb_engine* e) {
   if (e->dist_mode == 1 && e->dA && e->cap_A == 0) e->dA = nullptr;  // (a virtual base left behind by the capacity driver)
-  return ensure(e, &e->dA, &e->cap_A, e->Nr * e->Np);
+  return ensure(e, &e->dA, &e->cap_A, e->ld * e->Np);
 }
 
 // Covariance build: lower-triangular tiles of Sigma = K + noise + jitter, the y row, identity padding, written
@@ -2199,12 +2199,15 @@ int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t l
   e->Np = round_up(N, TILE);
   e->Nr = round_up(N + 1, TILE);
   e->ld = e->Nr;
+#ifdef GMB_TUNING
+  if (const char* lp = getenv("GMB_LD_PAD")) e->ld = e->Nr + atoi(lp);  // probe: leading dimension off the 1 KiB grid (tools/gpu_ld_pad.py)
+#endif
   int rc;
   if ((rc = alloc(e, &e->dX, N * (int64_t)D))) return rc;
   if ((rc = alloc(e, &e->dy, e->Np))) return rc;
   // (the factor buffer itself -- Nr x Np doubles -- is allocated by the first factorisation that needs it: in the multi-GPU
   // driver's capacity mode no rank ever holds it)
-  if (e->cap_A < e->Nr * e->Np && e->dA) {
+  if (e->cap_A < e->ld * e->Np && e->dA) {
     release(e, e->dA);
     e->dA = nullptr;
     e->cap_A = 0;
