@@ -27,7 +27,7 @@ launches alone -- the kernel the north star's MFMA target is stated on -- from p
 profiled evaluations after the timed region, plus the same figure over every GEMM launch, plus the register-only
 MFMA ceiling sampled for >= 1 s BEFORE and AFTER the timed region), ``kbuild`` (HBM GB/s of the covariance build),
 ``phases``, ``cpu_baseline`` (the oracle on a bounded sample on the host cores) and, while the time budget
-(GUMBI_BENCH_BUDGET_S, default 1500 s of process time) allows, ``c2_single_gpu`` (the N = 10k fit whose factorisation is ONE
+(GUMBI_BENCH_BUDGET_S, default 1600 s of process time) allows, ``c2_single_gpu`` (the N = 10k fit whose factorisation is ONE
 launch of the persistent tile kernel: step, phases, the launch's roofline), ``strong_scaling_base_gflops`` / ``c5_single_gpu``
 (the N = 100k problem of the multi-GPU runs on this one GPU), ``default_start`` and ``end_to_end`` (the user-level
 ``DataSet -> GP.fit() -> prepare_grid() -> predict_grid()`` wall time, host transfers included).
@@ -180,7 +180,7 @@ class Budget:
     say so in the JSON, when starting them would overrun it; the timed steps never are."""
 
     def __init__(self):
-        self.total = float(os.environ.get("GUMBI_BENCH_BUDGET_S", "1500"))
+        self.total = float(os.environ.get("GUMBI_BENCH_BUDGET_S", "1600"))
 
     def used(self):
         return time.perf_counter() - T_PROCESS_START
@@ -256,12 +256,16 @@ def cpu_baseline(cfg, target_seconds=20.0):
     Xs = O.synthetic_grid(d, cfg["res"])
     spec = O.make_spec(d, range(d), kind=cfg["kernel"])
 
+    split = {}
+
     def run(n):
         X, y, ls = O.synthetic_table(n, d)
         theta = O.pack_theta(spec, ls, 1.0, 0.2)
         t0 = time.perf_counter()
-        O.nlml_and_grad(spec, theta, X, y, dist_mode="gemm")
+        O.nlml_and_grad(spec, theta, X, y, dist_mode="gemm", inverse="potri")
+        t1 = time.perf_counter()
         O.predict(spec, theta, X, y, Xs, with_noise=True)
+        split["evaluation"], split["predict"] = t1 - t0, time.perf_counter() - t1
         return time.perf_counter() - t0
 
     # grow the sample (cost ~ N^3, but BLAS efficiency also grows with N, so re-scale from each
@@ -287,6 +291,7 @@ def cpu_baseline(cfg, target_seconds=20.0):
         "sample": f"1 MAP objective+gradient evaluation + predict(M={len(Xs)}) at N={Ns}, d={d}, {cfg['kernel']} "
                   f"(numpy/LAPACK oracle, {dt:.1f} s)",
         "seconds": round(dt, 2),
+        "evaluation_seconds": round(split["evaluation"], 2), "predict_seconds": round(split["predict"], 2),
     }
 
 
@@ -325,11 +330,13 @@ def cpu_config_size_sections(budget, gpu_c2=None):
     if budget.allows(est_eval):
         one = cpu_baseline(cfg, target_seconds=1e9)  # (target beyond reach: grows straight to the full N)
         out["c2_one_evaluation_plus_predict_seconds"] = one["seconds"]
+        out["c2_one_evaluation_seconds"] = one["evaluation_seconds"]
         out["c2_sample"] = one["sample"]
         n_eval = int(gpu_c2["n_eval"]) if gpu_c2 and gpu_c2.get("n_eval") else 29
-        est_fit = 1.1 * n_eval * one["seconds"] + 30.0
-        out["c2_seconds_estimate"] = round(n_eval * one["seconds"], 1)
-        out["c2_seconds_estimate_note"] = f"{n_eval} evaluations (the GPU fit's count) x the measured evaluation; NOT a measured fit"
+        # a fit = its evaluations + ONE prediction (+ the subprocess's start-up and table)
+        est_fit = 1.08 * (n_eval + 1) * one["evaluation_seconds"] + one["predict_seconds"] + 25.0
+        out["c2_seconds_estimate"] = round(n_eval * one["evaluation_seconds"] + one["predict_seconds"], 1)
+        out["c2_seconds_estimate_note"] = f"{n_eval} evaluations (the GPU fit's count) x the measured evaluation + one prediction; NOT a measured fit"
         if budget.allows(est_fit):
             try:
                 r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-fit", "c2"], cwd=str(ROOT), capture_output=True, text=True,

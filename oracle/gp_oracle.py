@@ -497,11 +497,13 @@ def _kernel_grad_given_M(spec, theta, X, M, dist_mode="direct"):
     return g
 
 
-def nlml_and_grad(spec, theta, X, y, dist_mode="direct"):
+def nlml_and_grad(spec, theta, X, y, dist_mode="direct", inverse="trsm"):
     """NLML and d NLML / d theta (natural scale), ``dNLML = 1/2 tr((Sigma^-1 - a a^T) dSigma)``.
 
     PyMC obtains the same derivative by reverse-mode autodiff through its Cholesky op
     (``pm.find_MAP``, call site ``pymc/GP.py:811``); it is restated analytically here.
+    ``inverse``: how Sigma^-1 is formed from L -- "trsm" (L^-1 by a triangular solve of the identity, then L^-T L^-1: the form
+    the parity tests pin) or "potri" (LAPACK dpotri on the factor: a third of the flops; what bench.py's host baseline times).
     """
     theta = np.asarray(theta, float)
     p = unpack_theta(spec, theta)
@@ -512,9 +514,19 @@ def nlml_and_grad(spec, theta, X, y, dist_mode="direct"):
     L = cholesky_lower(S)
     v = solve_lower(L, y)
     val = 0.5 * N * np.log(2.0 * np.pi) + np.sum(np.log(np.diag(L))) + 0.5 * float(v @ v)
-    Linv = solve_lower(L, np.eye(N))
-    Sinv = Linv.T @ Linv
-    alpha = Linv.T @ v
+    if inverse == "potri":
+        from scipy.linalg import lapack, solve_triangular
+
+        Sinv, info = lapack.dpotri(L, lower=1)
+        if info != 0:
+            raise np.linalg.LinAlgError(f"dpotri: info = {info}")
+        Sinv = np.tril(Sinv)  # (dpotri fills the lower triangle only)
+        Sinv = Sinv + np.tril(Sinv, -1).T
+        alpha = solve_triangular(L, v, lower=True, trans="T", check_finite=False)
+    else:
+        Linv = solve_lower(L, np.eye(N))
+        Sinv = Linv.T @ Linv
+        alpha = Linv.T @ v
     M = 0.5 * (Sinv - np.outer(alpha, alpha))  # dNLML/dSigma_ij
 
     g = np.zeros_like(theta)

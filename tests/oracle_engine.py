@@ -58,8 +58,8 @@ class OracleEngine:
 class HostBaselineEngine(OracleEngine):
     """The stand-in ``bench.py --cpu-fit`` times as the host baseline: PyMC's own distance expansion (``dist_mode="gemm"``, the
     form pm.gp.cov.Stationary.square_dist computes and differentiates) and ONE factorisation per objective evaluation
-    (``evaluate`` -- what a compiled PyTensor value-and-gradient function does), instead of the parity tests' direct
-    differences and their separate factorize / nlml calls."""
+    (``evaluate`` -- what a compiled PyTensor value-and-gradient function does; Sigma^-1 from the factor by LAPACK dpotri),
+    instead of the parity tests' direct differences and their separate factorize / nlml calls."""
 
     host_blas_free = False  # its arithmetic IS the host's BLAS: find_MAP must not throttle it to one thread
 
@@ -67,7 +67,7 @@ class HostBaselineEngine(OracleEngine):
         self.set_theta(theta)
         if not grad:
             return O.nlml(self.spec, self.theta, self.X, self.y, dist_mode="gemm")
-        out = O.nlml_and_grad(self.spec, self.theta, self.X, self.y, dist_mode="gemm")
+        out = O.nlml_and_grad(self.spec, self.theta, self.X, self.y, dist_mode="gemm", inverse="potri")
         self._factored = True
         return out
 

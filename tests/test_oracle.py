@@ -175,3 +175,17 @@ def test_host_posterior_blockwise_is_the_oracle():
     mu, var, nl = host_posterior_blockwise(spec, theta, X, y, Xs, block=200, threads=3)
     mu_r, var_r = O.predict(spec, theta, X, y, Xs, with_noise=True)
     assert rel(mu, mu_r) < 1e-12 and np.max(np.abs(var - var_r)) < 1e-12 and np.isclose(nl, O.nlml(spec, theta, X, y), rtol=1e-13)
+
+
+@pytest.mark.parametrize("kind", ["ExpQuad", "Matern52", "Matern12"])
+def test_host_baseline_variants_of_the_gradient_agree_with_the_pinned_form(kind):
+    """What bench.py's host baseline times (PyMC's GEMM distance expansion with its GEMM-form ARD gradient, Sigma^-1 by LAPACK
+    dpotri) against the form the parity tests pin (direct differences, L^-1 by a triangular solve)."""
+    N, d = 500, 5
+    X, y, ls = O.synthetic_table(N, d, seed=13)
+    spec = O.make_spec(d, range(d), kind=kind)
+    theta = O.pack_theta(spec, ls, 1.2, 0.25)
+    v0, g0 = O.nlml_and_grad(spec, theta, X, y, dist_mode="direct")
+    v1, g1 = O.nlml_and_grad(spec, theta, X, y, dist_mode="gemm", inverse="potri")
+    tol = 1e-11 if kind != "Matern12" else 1e-7  # (the kinked kernel sees the expansion's rounding near r = 0)
+    assert abs(v1 - v0) <= tol * abs(v0) and np.max(np.abs(g1 - g0)) <= tol * np.max(np.abs(g0))

@@ -48,12 +48,12 @@ def main(root, out):
         tf = mops * 512.0 / (d1[k] * 1e-9) / 1e12 if d1[k] else 0.0
         fetch_gb = 2.0 * p2.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0 / 1e9
         write_gb = p3.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0 / 1e9
-        rows.append([k, n1[k], round(d1[k] / 1e6, 3), round(util, 2), round(tf, 2),
+        rows.append([k, n1[k], round(d1[k] / 1e6, 3), round(d1[k] / 1e6 / max(n1[k], 1), 5), round(mops * 512.0 / max(n1[k], 1) / 1e9, 3), round(util, 2), round(tf, 2),
                      round(fetch_gb, 4), round(fetch_gb / (d2.get(k, 0) * 1e-9 + 1e-30) if d2.get(k) else 0, 1),
                      round(write_gb, 4), round(write_gb / (d3.get(k, 0) * 1e-9 + 1e-30) if d3.get(k) else 0, 1)])
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
-        w.writerow(["Kernel", "Launches", "TotalMs(pass1)", "MfmaUtil%", "MFMA_F64_TFLOPs", "FetchGB(x2 corrected)",
+        w.writerow(["Kernel", "Launches", "TotalMs(pass1)", "AvgMs(pass1)", "MFMA_GFlopPerLaunch", "MfmaUtil%", "MFMA_F64_TFLOPs", "FetchGB(x2 corrected)",
                     "FetchGB/s", "WriteGB(raw)", "WriteGB/s"])
         w.writerows(rows)
     for r in rows[:8]:
