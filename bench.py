@@ -27,7 +27,7 @@ launches alone -- the kernel the north star's MFMA target is stated on -- from p
 profiled evaluations after the timed region, plus the same figure over every GEMM launch, plus the register-only
 MFMA ceiling sampled for >= 1 s BEFORE and AFTER the timed region), ``kbuild`` (HBM GB/s of the covariance build),
 ``phases``, ``cpu_baseline`` (the oracle on a bounded sample on the host cores) and, while the time budget
-(GUMBI_BENCH_BUDGET_S, default 1600 s of process time) allows, ``c2_single_gpu`` (the N = 10k fit whose factorisation is ONE
+(GUMBI_BENCH_BUDGET_S, default 1550 s of process time) allows, ``c2_single_gpu`` (the N = 10k fit whose factorisation is ONE
 launch of the persistent tile kernel: step, phases, the launch's roofline), ``strong_scaling_base_gflops`` / ``c5_single_gpu``
 (the N = 100k problem of the multi-GPU runs on this one GPU), ``default_start`` and ``end_to_end`` (the user-level
 ``DataSet -> GP.fit() -> prepare_grid() -> predict_grid()`` wall time, host transfers included).
@@ -180,7 +180,7 @@ class Budget:
     say so in the JSON, when starting them would overrun it; the timed steps never are."""
 
     def __init__(self):
-        self.total = float(os.environ.get("GUMBI_BENCH_BUDGET_S", "1600"))
+        self.total = float(os.environ.get("GUMBI_BENCH_BUDGET_S", "1550"))
 
     def used(self):
         return time.perf_counter() - T_PROCESS_START

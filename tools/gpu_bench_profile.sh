@@ -12,7 +12,7 @@ cat gpurun_out/${TAG}_bench_${CFG}.json
 export TMPDIR=/tmp
 ROOT=$PWD
 cd /tmp
-GUMBI_BENCH_NO_DIST=1 GUMBI_BENCH_NO_E2E=1 GUMBI_BENCH_NO_CPU=1 GUMBI_BENCH_NO_C2=1 timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/${TAG}_prof -o ${TAG} -- python $ROOT/bench.py --config $CFG --steps 1 --warmup 0 > $ROOT/gpurun_out/${TAG}_prof_bench.log 2>&1
+GUMBI_BENCH_NO_DIST=1 GUMBI_BENCH_NO_E2E=1 GUMBI_BENCH_NO_CPU=1 GUMBI_BENCH_NO_C2=1 GUMBI_BENCH_NO_C4=1 GUMBI_BENCH_NO_DEFAULT_START=1 timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/${TAG}_prof -o ${TAG} -- python $ROOT/bench.py --config $CFG --steps 1 --warmup 0 > $ROOT/gpurun_out/${TAG}_prof_bench.log 2>&1
 cd $ROOT
 DB=$(find gpurun_out/${TAG}_prof -name "*_results.db" | head -1)
 python tools/rocprof_summary.py $DB gpurun_out/${TAG}_bench_${CFG}_kernel_stats.csv

@@ -12,7 +12,7 @@ mkdir -p $OUT $ROOT/gpurun_out
 cd /tmp
 # one step = a capped fit (8 evaluations: the counters are per launch, the launches of every evaluation are alike)
 CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 0 --map-evals 8"
-export GUMBI_BENCH_NO_DIST=1 GUMBI_BENCH_NO_CPU=1 GUMBI_BENCH_NO_E2E=1 GUMBI_BENCH_NO_DEFAULT_START=1 GUMBI_BENCH_NO_C2=1
+export GUMBI_BENCH_NO_DIST=1 GUMBI_BENCH_NO_CPU=1 GUMBI_BENCH_NO_E2E=1 GUMBI_BENCH_NO_DEFAULT_START=1 GUMBI_BENCH_NO_C2=1 GUMBI_BENCH_NO_C4=1
 timeout 1200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/p1 -o p1 -- $CMD > $OUT/p1.log 2>&1
 timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p2 -o p2 -- $CMD > $OUT/p2.log 2>&1
 timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/p3 -o p3 -- $CMD > $OUT/p3.log 2>&1
