@@ -103,39 +103,31 @@ class Regressor(ABC):
     # -- model specification -------------------------------------------------------------------------
     def specify_model(self, outputs=None, linear_dims=None, continuous_dims=None, continuous_levels=None,
                       continuous_coords=None, categorical_dims=None, categorical_levels=None, additive=False):
-        """Validate and normalise dims / levels / coords (reference :180-265)."""
+        """Validate and normalise dims / levels / coords (reference :180-265): same attributes, same errors."""
         self._structured_cache = None
-        outputs = outputs if outputs is not None else self.outputs
-        assert_is_subset(self.out_col, outputs, self.data.outputs)
-        self.outputs = outputs if isinstance(outputs, list) else [outputs]
+        chosen = self.outputs if outputs is None else outputs
+        assert_is_subset(self.out_col, chosen, self.data.outputs)
+        self.outputs = chosen if isinstance(chosen, list) else [chosen]
 
-        self.continuous_dims = self._parse_dimensions(continuous_dims)
-        self.linear_dims = self._parse_dimensions(linear_dims)
-        self.categorical_dims = self._parse_dimensions(categorical_dims)
-        if set(self.categorical_dims) & set(self.continuous_dims):
+        cont, lin, cat = (self._parse_dimensions(d) for d in (continuous_dims, linear_dims, categorical_dims))
+        if not set(cat).isdisjoint(cont):
             raise ValueError("Overlapping items in categorical_dims and continuous_dims")
+        cont_levels = self._parse_levels(cont, continuous_levels)
+        cat_levels = self._parse_levels(cat, categorical_levels)
+        cat = cat + [self.out_col]  # the output column is a categorical dimension too: always the last one
+        cat_levels[self.out_col] = self.outputs
 
-        self.continuous_levels = self._parse_levels(self.continuous_dims, continuous_levels)
-        self.categorical_levels = self._parse_levels(self.categorical_dims, categorical_levels)
+        # A dimension with one level does not vary: it SELECTS rows (get_filtered_data) instead of entering the model -- unless the
+        # table has a single observation, where everything has one level.  Decided once, in the order of `dims`.
+        by_dim = {**{d: cont_levels[d] for d in cont}, **{d: cat_levels[d] for d in cat}}
+        selects = self.data.wide.shape[0] > 1
+        self.filter_dims = {d: lv for d, lv in by_dim.items() if selects and len(lv) == 1}
+        keep = lambda names: [d for d in names if d not in self.filter_dims]  # noqa: E731
+        self.continuous_dims, self.categorical_dims, self.linear_dims = keep(cont), keep(cat), lin
+        self.continuous_levels = {d: lv for d, lv in cont_levels.items() if d not in self.filter_dims}   # (the dicts keep the
+        self.categorical_levels = {d: lv for d, lv in cat_levels.items() if d not in self.filter_dims}  # order they were given in)
 
-        # the output column is always the last categorical dim
-        self.categorical_dims = self.categorical_dims + [self.out_col]
-        self.categorical_levels[self.out_col] = self.outputs
-
-        # single-level dims only filter the data
-        self.filter_dims = {}
-        if self.data.wide.shape[0] > 1:
-            for dim in list(self.dims):
-                lv = self.levels[dim]
-                if len(lv) == 1:
-                    self.filter_dims[dim] = lv
-                    self.continuous_dims = [d for d in self.continuous_dims if d != dim]
-                    self.categorical_dims = [d for d in self.categorical_dims if d != dim]
-                    self.continuous_levels.pop(dim, None)
-                    self.categorical_levels.pop(dim, None)
-
-        self.continuous_coords = self._parse_coordinates(self.continuous_dims, self.continuous_levels,
-                                                         continuous_coords)
+        self.continuous_coords = self._parse_coordinates(self.continuous_dims, self.continuous_levels, continuous_coords)
         self.categorical_coords = self._parse_coordinates(self.categorical_dims, self.categorical_levels, None)
         assert_is_subset("continuous dimensions", self.linear_dims, self.continuous_dims)
         self.additive = additive
