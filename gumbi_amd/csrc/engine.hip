@@ -230,7 +230,10 @@ struct gmb_engine {
   int et_lag = -1;             // the INV tasks of column c - lag follow the CHOL tasks of column c in the task list (-1: by size)
   uint32_t* det_tasks = nullptr;  // task list on the device, and what it was built for
   int64_t cap_et_tasks = 0;
-  int et_key[4] = {-1, -1, -1, -1};
+  int et_key[5] = {-1, -1, -1, -1, -1};
+  int et_pairs = -1;           // Sigma^-1 tasks of two tiles (128 x 256; eval_tiles.hpp: et_zz2_task): -1 = by size, 0 = off, 1 = on
+  int et_pairs_min_blocks = 72;  // (measured, profiles/r05_eval_pairs_ab.txt: +19 % at 24 block columns, +8 % at 41, 0 at 50 - 64,
+                                 //  -0.7 % at 79, -1.0 ... -1.2 % at 128 - 157: a pair halves the number of tasks the tail is balanced with)
   int et_ntasks = 0;
   double* dUdiag = nullptr;    // diagonal tiles of U = L^-T
   int64_t cap_udiag = 0;
@@ -1058,15 +1061,18 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
   // N = 10k: 75 us median per task, 18.3 ms per evaluation; a quarter of the block columns behind: none, 16.3 ms;
   // tools/gpu_eval_lag.py)
   const int lag = e->et_lag >= 0 ? e->et_lag : std::max(2, std::min(24, nct / 4));
-  if (e->et_key[0] != nct || e->et_key[1] != nrt || e->et_key[2] != (int)with_chol || e->et_key[3] != lag) {
+  // (a traced launch keeps the list its stamps are decoded with)
+  const int pairs = (!e->ct_trace && (e->et_pairs > 0 || (e->et_pairs < 0 && nct >= e->et_pairs_min_blocks))) ? 1 : 0;
+  if (e->et_key[0] != nct || e->et_key[1] != nrt || e->et_key[2] != (int)with_chol || e->et_key[3] != lag || e->et_key[4] != pairs) {
     std::vector<uint32_t> list;
-    et_build_tasks(nct, nrt, with_chol, lag, list);
+    et_build_tasks(nct, nrt, with_chol, lag, list, pairs != 0);
     if ((rc = ensure(e, &e->det_tasks, &e->cap_et_tasks, (int64_t)list.size()))) return rc;
     HIP_TRY(e, hipMemcpy(e->det_tasks, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     e->et_key[0] = nct;
     e->et_key[1] = nrt;
     e->et_key[2] = (int)with_chol;
     e->et_key[3] = lag;
+    e->et_key[4] = pairs;
     e->et_ntasks = (int)list.size();
   }
   const int ntasks = e->et_ntasks;
@@ -2939,10 +2945,17 @@ int gmb_set_grad_scheme(gmb_engine* e, int32_t scheme, int32_t lag) {
   return old + 1;
 }
 
+int gmb_set_eval_pairs(gmb_engine* e, int32_t mode) {
+  if (!e || mode < -1 || mode > 1) return GMB_EINVAL;
+  const int old = e->et_pairs;
+  e->et_pairs = mode;
+  return old + 1;
+}
+
 int64_t gmb_debug_eval_tasks(int32_t nct, int32_t nrt, int32_t with_chol, int32_t lag, uint32_t* out, int64_t cap) {
-  if (nct < 1 || nrt < nct || nrt > 0x7fff || lag < 0) return GMB_EINVAL;
+  if (nct < 1 || nrt < nct || nrt > 0x3fff || lag < 0 || with_chol < 0 || with_chol > 3) return GMB_EINVAL;
   std::vector<uint32_t> list;
-  et_build_tasks(nct, nrt, with_chol != 0, lag, list);
+  et_build_tasks(nct, nrt, (with_chol & 1) != 0, lag, list, (with_chol & 2) != 0);
   if (out)
     for (int64_t i = 0; i < (int64_t)list.size() && i < cap; ++i) out[i] = list[(size_t)i];
   return (int64_t)list.size();

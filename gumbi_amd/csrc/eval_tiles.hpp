@@ -432,6 +432,159 @@ __device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOper
   return true;
 }
 
+// ---- two tiles per task: out0 | out1 (128 x 256) = sum_k N(k) [M0(k) | M1(k)]^T -------------------------------------------------
+// The n operand (the task's own, unshared row) is streamed ONCE for two output tiles: 0.75 x the operand bytes per flop of the
+// 128 x 128 form, and every wave owns 4 x 4 MFMA tiles (64 x 64) -- 8 LDS fragment reads per 16 MFMAs instead of 6 per 8.  Same
+// ring discipline as gemm_f64_dma_body: stages of EIGHT k-rows, three operand images per stage ([k][144] each: M0, M1, N), a ring of
+// four, one barrier per stage inside the MFMA stream, three stages of DMA in flight across it; every wave DMAs k-row `wave` of the
+// three operands.  Both tiles contract over the same k range [kb_lo, kb_hi) and wait for the flags of all three rows.
+template <bool NEG>
+__device__ __forceinline__ bool et_ksum_dma2(const CholTilesArgs& g, const EtOperand m0_in, const EtOperand m1_in, const EtOperand nop_in,
+                                             const uint32_t* m0flags, const uint32_t* m1flags, const uint32_t* nflags, const int kb_lo_in,
+                                             const int kb_hi_in, double* __restrict__ out0, double* __restrict__ out1, const int64_t ldo,
+                                             ct_lds_double* l3, int* s_i, const int k_last_in = TILE) {
+  constexpr int WGN = 2;                 // waves along n (rows); four along m: waves 0 .. 3 -> tile 0, 4 .. 7 -> tile 1
+  constexpr int WTM = 4, WTN = 4;        // MFMA tiles per wave
+  constexpr int KD = 8, NS = 4;
+  constexpr int PA = PITCH;
+  constexpr int STAGE = KD * 3 * PA;     // doubles
+  constexpr int KPB = TILE / KD;         // stages per k-block
+  static_assert(NS * STAGE <= ct_lds_doubles(8), "the DMA ring must fit the workgroup's LDS");
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void g_void;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;  // wm 0 .. 3: 64 columns of the 256; wn: 64 rows of the 128
+  const int r16 = lane & 15, kq = lane >> 4;
+  const EtOperand op[3] = {{et_uni_ptr(m0_in.base), et_uni64(m0_in.ld), et_uni_ptr(m0_in.diag), et_uni(m0_in.diag_kb)},
+                           {et_uni_ptr(m1_in.base), et_uni64(m1_in.ld), et_uni_ptr(m1_in.diag), et_uni(m1_in.diag_kb)},
+                           {et_uni_ptr(nop_in.base), et_uni64(nop_in.ld), et_uni_ptr(nop_in.diag), et_uni(nop_in.diag_kb)}};
+  const int kb_lo = et_uni(kb_lo_in), kb_hi = et_uni(kb_hi_in);
+
+  d4 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // Running source pointers, one per operand image: k-row `wave` of the next stage and the distance to the stage behind it.  They
+  // are set at the start of every SEGMENT (a run of stages whose operands are final and which does not leave a diagonal side
+  // tile), so that inside the loop a DMA is three loads and ONE uniform condition (past the end of the segment the pointers stay
+  // on its last stage: the ring keeps its count of outstanding loads, the garbage lands in stages nobody reads).
+  const double* rp[3];
+  int64_t rstep[3];
+  int issued = 0, seg_end = 0;
+  auto seg_init = [&](const int kt, const int kt1) {
+    const int kb = kt / KPB;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (kb == op[q].diag_kb) {
+        rp[q] = op[q].diag + ((int64_t)(kt - kb * KPB) * KD + wave) * TILE;
+        rstep[q] = (int64_t)KD * TILE;
+      } else {
+        rp[q] = op[q].base + ((int64_t)kt * KD + wave) * op[q].ld;
+        rstep[q] = (int64_t)KD * op[q].ld;
+      }
+    }
+    issued = kt;
+    seg_end = kt1;
+  };
+  const int lane2 = 2 * lane;
+  auto dma = [&](const int stage) {
+    ct_lds_double* S = l3 + stage * STAGE + wave * PA;
+    __builtin_amdgcn_global_load_lds((g_void*)(rp[0] + lane2), (lds_void*)S, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g_void*)(rp[1] + lane2), (lds_void*)(S + KD * PA), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g_void*)(rp[2] + lane2), (lds_void*)(S + 2 * KD * PA), 16, 0, 0);
+    if (issued + 1 < seg_end) {
+      rp[0] += rstep[0];
+      rp[1] += rstep[1];
+      rp[2] += rstep[2];
+      ++issued;
+    }
+  };
+  double fa[2][WTM], fb[2][WTN];
+  const int a_off = (wm >> 1) * KD * PA + (wm & 1) * (16 * WTM);  // image M0 or M1, 64-column half
+  auto frags = [&](const int kt, const int k4, const int buf) {
+    const ct_lds_double* S = l3 + (kt & (NS - 1)) * STAGE + (4 * k4 + kq) * PA + r16;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) fa[buf][i] = S[a_off + i * 16];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) fb[buf][j] = S[2 * KD * PA + wn * (16 * WTN) + j * 16];
+  };
+  auto mfmas = [&](const int buf) {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+  };
+  auto pin_step = [&]() {  // the next step's fragment reads go out behind the first MFMAs of this one
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, WTM * WTN - 8, 0);
+  };
+
+  const int kt_end = kb_hi * KPB - (KPB - (et_uni(k_last_in) + KD - 1) / KD);
+  int ktc = kb_lo * KPB;
+  while (ktc < kt_end) {
+    const int kb = ktc / KPB;
+    if (wave == 0) {
+      int r = et_wait_rows(g, m0flags, nflags, kb, kb_hi, kb + 1 >= kb_hi);
+      if (r >= 0) {
+        const int r2 = et_wait_rows(g, m1flags, nflags, kb, r, kb + 1 >= kb_hi);
+        r = r2 < 0 ? r2 : (r2 < r ? r2 : r);
+      }
+      if (r >= 0) r *= KPB;
+      s_i[1] = r;
+    }
+    __syncthreads();  // (no DMA in flight here)
+    const int kt1r = __builtin_amdgcn_readfirstlane(s_i[1]);
+    if (kt1r < 0) return false;
+    int kt1 = kt1r < kt_end ? kt1r : kt_end;
+    // (a k-block that sits in a diagonal side tile is a segment of its own: inside a segment the pointers step uniformly)
+    if ((kb == op[0].diag_kb || kb == op[1].diag_kb || kb == op[2].diag_kb) && kt1 > (kb + 1) * KPB) kt1 = (kb + 1) * KPB;
+    const int kt0 = ktc;
+    seg_init(kt0, kt1);
+    dma(kt0 & (NS - 1));
+    dma((kt0 + 1) & (NS - 1));
+    dma((kt0 + 2) & (NS - 1));
+    dma((kt0 + 3) & (NS - 1));
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    frags(kt0, 0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      frags(kt, 1, 1);
+      mfmas(0);
+      pin_step();
+      // this wave's reads of stage kt are back, its DMAs of stage kt + 1 have landed (kt + 2, kt + 3 stay in flight)
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      dma(kt & (NS - 1));
+      frags(kt + 1, 0, 0);  // (behind the last stage of a segment: garbage, never used)
+      mfmas(1);
+      pin_step();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ktc = kt1;
+  }
+
+  double* __restrict__ Cg = ((wm >> 1) ? out1 : out0) + wn * (16 * WTN) + r16;
+  const int64_t m0 = (wm & 1) * (16 * WTM) + kq;
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* row = Cg + (m0 + i * 16 + 4 * r) * ldo;
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) row[j * 16] = NEG ? -acc[i][j][r] : acc[i][j][r];
+    }
+  return true;
+}
+
 // the contraction of a task: LDS-DMA staging for eight-wave workgroups (ET_DMA), the register-staged loop otherwise
 #ifndef ET_DMA
 #define ET_DMA 1
@@ -638,6 +791,177 @@ __device__ __noinline__ bool et_zz_task(const CholTilesArgs g_in, ct_g_double* A
   return true;
 }
 
+// ---- the same two-tile contraction with NO LDS and NO barrier in the loop: operands straight from L1 / L2 into MFMA fragments ------
+// Both operands are k-major, so a lane's fragment values are already contiguous pairs in memory if the wave's sixteen-wide MFMA
+// tiles take the EVEN and the ODD columns (rows) of a 32-wide group: lane (r16, kq) loads the two doubles 2 r16, 2 r16 + 1 of k-row
+// 4 s + kq with one 16-byte load and feeds the first to tile 2a, the second to tile 2a + 1 -- four loads per sixteen MFMAs, each wave
+// on its own (nothing is shared through LDS, nothing waits for the other seven waves); loads are issued PF steps ahead.
+template <bool NEG>
+__device__ __forceinline__ bool et_ksum_reg2(const CholTilesArgs& g, const EtOperand m0_in, const EtOperand m1_in, const EtOperand nop_in,
+                                             const uint32_t* m0flags, const uint32_t* m1flags, const uint32_t* nflags, const int kb_lo_in,
+                                             const int kb_hi_in, double* __restrict__ out0, double* __restrict__ out1, const int64_t ldo,
+                                             int* s_i, const int k_last_in = TILE) {
+  constexpr int WGN = 2;
+  constexpr int PF = 4;                 // k4-steps of loads in flight per wave
+  constexpr int SPB = TILE / 4;         // k4-steps per k-block
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const EtOperand mop = (wm >> 1) ? EtOperand{et_uni_ptr(m1_in.base), et_uni64(m1_in.ld), et_uni_ptr(m1_in.diag), et_uni(m1_in.diag_kb)}
+                                  : EtOperand{et_uni_ptr(m0_in.base), et_uni64(m0_in.ld), et_uni_ptr(m0_in.diag), et_uni(m0_in.diag_kb)};
+  const EtOperand nop{et_uni_ptr(nop_in.base), et_uni64(nop_in.ld), et_uni_ptr(nop_in.diag), et_uni(nop_in.diag_kb)};
+  const int d0 = et_uni(m0_in.diag_kb), d1 = et_uni(m1_in.diag_kb);
+  const int kb_lo = et_uni(kb_lo_in), kb_hi = et_uni(kb_hi_in);
+  const int acol = (wm & 1) * 64 + 2 * r16, brow = wn * 64 + 2 * r16;  // this lane's pair inside the first 32-wide group
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  d2 fa[PF][2], fb[PF][2];
+  const double* pa = nullptr;
+  const double* pb = nullptr;
+  int64_t sa = 0, sb = 0;  // doubles between k4-steps
+  int left = 0;            // steps of the segment behind the one the pointers stand at
+  auto load = [&](const int slot) {
+    fa[slot][0] = *reinterpret_cast<const d2*>(pa);
+    fa[slot][1] = *reinterpret_cast<const d2*>(pa + 32);
+    fb[slot][0] = *reinterpret_cast<const d2*>(pb);
+    fb[slot][1] = *reinterpret_cast<const d2*>(pb + 32);
+    // (past the end of the segment the pointers stay on its last step: loads that run ahead never leave the operands)
+    const bool more = left > 0;
+    pa += more ? sa : 0;
+    pb += more ? sb : 0;
+    left -= more ? 1 : 0;
+  };
+  auto mfmas = [&](const int slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i >> 1][i & 1], fb[slot][j >> 1][j & 1], acc[i][j], 0, 0, 0);
+  };
+
+  const int st_end = kb_hi * SPB - (SPB - (et_uni(k_last_in) + 3) / 4);
+  int stc = kb_lo * SPB;
+  while (stc < st_end) {
+    const int kb = stc / SPB;
+    if (wave == 0) {
+      int r = et_wait_rows(g, m0flags, nflags, kb, kb_hi, kb + 1 >= kb_hi);
+      if (r >= 0) {
+        const int r2 = et_wait_rows(g, m1flags, nflags, kb, r, kb + 1 >= kb_hi);
+        r = r2 < 0 ? r2 : (r2 < r ? r2 : r);
+      }
+      if (r >= 0) r *= SPB;
+      s_i[1] = r;
+    }
+    __syncthreads();
+    const int st1r = __builtin_amdgcn_readfirstlane(s_i[1]);
+    if (st1r < 0) return false;
+    int st1 = st1r < st_end ? st1r : st_end;
+    if ((kb == d0 || kb == d1 || kb == nop.diag_kb) && st1 > (kb + 1) * SPB) st1 = (kb + 1) * SPB;
+    // this segment's running pointers (k-row 4 s + kq of the wave's operand images)
+    if (kb == mop.diag_kb) {
+      pa = mop.diag + ((int64_t)(stc - kb * SPB) * 4 + kq) * TILE + acol;
+      sa = 4 * TILE;
+    } else {
+      pa = mop.base + ((int64_t)stc * 4 + kq) * mop.ld + acol;
+      sa = 4 * mop.ld;
+    }
+    if (kb == nop.diag_kb) {
+      pb = nop.diag + ((int64_t)(stc - kb * SPB) * 4 + kq) * TILE + brow;
+      sb = 4 * TILE;
+    } else {
+      pb = nop.base + ((int64_t)stc * 4 + kq) * nop.ld + brow;
+      sb = 4 * nop.ld;
+    }
+    const int nst = st1 - stc;  // (a multiple of 4 except in the cut last k-block)
+    int done = 0;
+    left = nst - 1;
+    // prologue: PF steps on their way
+#pragma unroll
+    for (int q = 0; q < PF; ++q) load(q);
+    for (; done + PF <= nst; done += PF) {
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // the oldest step's four loads are back (3 x 4 stay in flight)
+        mfmas(q);
+        load(q);
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+    }
+    for (int q = 0; done < nst; ++done, ++q) {  // ragged tail (the cut last k-block): step by step
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (q == 0) mfmas(0);
+      else if (q == 1) mfmas(1);
+      else if (q == 2) mfmas(2);
+      else mfmas(3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stc = st1;
+  }
+
+  // D layout: n = lane & 15 -> row pair 2 r16 (+ j & 1), m = kq + 4 reg -> column 2 (kq + 4 reg) (+ i & 1) of the 32-wide groups
+  double* __restrict__ Cg = ((wm >> 1) ? out1 : out0) + wn * 64 + 2 * r16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t col = (wm & 1) * 64 + (i >> 1) * 32 + 2 * (kq + 4 * r) + (i & 1);
+      double* row = Cg + col * ldo;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        d2 v{acc[i][2 * jj][r], acc[i][2 * jj + 1][r]};
+        if (NEG) v = -v;
+        *reinterpret_cast<d2*>(row + 32 * jj) = v;
+      }
+    }
+  return true;
+}
+
+// ZZ pair task (I; J, J + 1), J + 1 <= I: the tiles (I, J) and (I, J + 1) of Sigma^-1 in one pass over block row I of U.
+constexpr uint32_t ET_PAIR = 0x4000u;  // flag in the J field of a ZZ task word
+template <int NW>
+__device__ __noinline__ bool et_zz2_task(const CholTilesArgs g_in, ct_g_double* A, ct_g_double* udiag, ct_g_double* Z, const int64_t ldz,
+                                         ct_g_u32* uflags, ct_g_u32* ctl, ct_g_u64* dbg, const int I, const int J, const int t, ct_lds_double* l3,
+                                         ct_lds_int* s3) {
+  const CholTilesArgs g = ct_rebuild(g_in, A, nullptr, nullptr, nullptr, nullptr, nullptr, ctl, dbg);
+  const uint32_t* uf = (const uint32_t*)uflags;
+  const double* ud = (const double*)udiag;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const EtOperand m0{g.A + (int64_t)J * TILE, g.ld, ud + (int64_t)J * TILE * TILE, J};
+  const EtOperand m1{g.A + (int64_t)(J + 1) * TILE, g.ld, ud + (int64_t)(J + 1) * TILE * TILE, J + 1};
+  const EtOperand nop{g.A + (int64_t)I * TILE, g.ld, ud + (int64_t)I * TILE * TILE, I};
+  double* out0 = (double*)Z + (int64_t)I * TILE + (int64_t)J * TILE * ldz;
+  const int k_last = (int)(g.N - (int64_t)(g.nct - 1) * TILE);
+  if constexpr (NW == 8) {
+#ifdef ET_PAIR_REG
+    if (!et_ksum_reg2<false>(g, m0, m1, nop, uf + (int64_t)J * g.nct, uf + (int64_t)(J + 1) * g.nct, uf + (int64_t)I * g.nct, I, g.nct, out0,
+                             out0 + (int64_t)TILE * ldz, ldz, (int*)s3, k_last))
+      return false;
+#else
+    if (!et_ksum_dma2<false>(g, m0, m1, nop, uf + (int64_t)J * g.nct, uf + (int64_t)(J + 1) * g.nct, uf + (int64_t)I * g.nct, I, g.nct, out0,
+                             out0 + (int64_t)TILE * ldz, ldz, l3, (int*)s3, k_last))
+      return false;
+#endif
+  }
+  if (g.dbg && wave == 0) {
+    const unsigned long long now = wall_clock64();
+    g.dbg[4 * (int64_t)t + 1] = now;
+    g.dbg[4 * (int64_t)t + 2] = now;
+    g.dbg[4 * (int64_t)t + 3] = now;
+  }
+  return true;
+}
+
 // The persistent loop: tickets index the host-built task list.
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void eval_tiles_kernel(CholTilesArgs g, EvalTilesArgs x) {
@@ -671,6 +995,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_tiles_kernel(CholTilesArgs g,
       ok = et_inv_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)g.dinv16, (ct_g_double*)x.udiag, (ct_g_double*)x.apart, (ct_g_u32*)g.flags,
                            (ct_g_u32*)x.uflags, (ct_g_u32*)x.rowdone, (ct_g_u32*)g.ctl, (ct_g_u64*)g.dbg, I, J, t, x.yb, (ct_lds_double*)lds,
                            (ct_lds_int*)s_i);
+    } else if (kind == ET_ZZ && (J & (int)ET_PAIR)) {
+      ok = et_zz2_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)x.udiag, (ct_g_double*)x.Z, x.ldz, (ct_g_u32*)x.uflags, (ct_g_u32*)g.ctl,
+                           (ct_g_u64*)g.dbg, I, J & ~(int)ET_PAIR, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
     } else if (kind == ET_ZZ) {
       ok = et_zz_task<NW>(g, (ct_g_double*)g.A, (ct_g_double*)x.udiag, (ct_g_double*)x.Z, x.ldz, (ct_g_u32*)x.uflags, (ct_g_u32*)g.ctl,
                           (ct_g_u64*)g.dbg, I, J, t, (ct_lds_double*)lds, (ct_lds_int*)s_i);
@@ -796,7 +1123,7 @@ __global__ __launch_bounds__(1024) void grad_finish_kernel(GradFinishArgs a) {
 // Host side: the task list.  `with_chol`: the factorisation's tile tasks are part of the launch (column c's tasks, then the
 // INV tasks of column c - lag); otherwise the factor is final and only INV / ZZ / FIN tasks are listed.  INV column c: r = 0 .. c
 // (longest contraction first); ZZ: block rows I ascending (longest first), J = 0 .. I inside; FIN (r), r = 0 .. nct-1, last.
-inline void et_build_tasks(int nct, int nrt, bool with_chol, int lag, std::vector<uint32_t>& out) {
+inline void et_build_tasks(int nct, int nrt, bool with_chol, int lag, std::vector<uint32_t>& out, bool zz_pairs = false) {
   out.clear();
   auto inv_col = [&](int c) {
     for (int r = 0; r <= c; ++r) out.push_back(et_pack(ET_INV, r, c));
@@ -813,7 +1140,14 @@ inline void et_build_tasks(int nct, int nrt, bool with_chol, int lag, std::vecto
   }
   for (int c = next_inv; c < nct; ++c) inv_col(c);
   for (int I = 0; I < nct; ++I)
-    for (int J = 0; J <= I; ++J) out.push_back(et_pack(ET_ZZ, I, J));
+    for (int J = 0; J <= I; ++J) {
+      if (zz_pairs && J + 1 <= I) {  // (I; J, J + 1): one pass over block row I for two tiles
+        out.push_back(et_pack(ET_ZZ, I, J | (int)ET_PAIR));
+        ++J;
+      } else {
+        out.push_back(et_pack(ET_ZZ, I, J));
+      }
+    }
   for (int r = 0; r < nct; ++r) out.push_back(et_pack(ET_FIN, r, 0));
 }
 

@@ -253,6 +253,7 @@ _SIGNATURES = {
     "gmb_chol_task_trace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "gmb_set_chol_scheme": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_debug_assume_factored": (C.c_int, [C.c_void_p]),
+    "gmb_set_eval_pairs": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_set_grad_scheme": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "gmb_dist_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_resident_bytes": (C.c_int64, [C.c_void_p, C.c_int32]),
@@ -301,7 +302,7 @@ def _preload_hip_runtime():
 #: version 6 the communication fields of ``gmb_timings`` and ``gmb_rccl_comm_ranks``; version 7 ``gmb_evaluate``, the tile
 #: Cholesky's doors ``gmb_set_chol_scheme`` / ``gmb_chol_task_trace`` / ``gmb_debug_chol_*``; version 8 the persistent evaluation
 #: launch: ``gmb_set_grad_scheme``, ``gmb_debug_eval_tasks``, ``total_eval_tile_*`` in ``gmb_timings``; version 9 the timing
-#: tools' door ``gmb_debug_assume_factored`` and the guards between single-engine and capacity-mode factorisations)
+#: tools' door ``gmb_debug_assume_factored``, the guards between single-engine and capacity-mode factorisations, ``gmb_set_eval_pairs``)
 ABI_VERSION = 9
 
 
@@ -575,6 +576,13 @@ class Engine:
     #: how the ranks of ``dist_*`` hold the factor (``set_dist_mode``): every rank all of it / owned block rows + panel buffers
     DIST_REPLICATED, DIST_CAPACITY = 0, 1
 
+    def set_eval_pairs(self, mode: int) -> int:
+        """Sigma^-1 tile tasks in pairs (128 x 256): -1 by size, 0 never, 1 always (same bits either way); returns the previous mode."""
+        prev = int(self._lib.gmb_set_eval_pairs(self._h, int(mode)))
+        if prev < 0:
+            self._check(prev, "gmb_set_eval_pairs")
+        return prev - 1
+
     def debug_assume_factored(self):
         """Timing tools only: the last factorisation counts as valid whatever it produced (``gmb_debug_assume_factored``)."""
         self._check(self._lib.gmb_debug_assume_factored(self._h), "gmb_debug_assume_factored")
@@ -652,15 +660,17 @@ def chol_task(t: int, nct: int, nrt: int):
     return i.value, j.value
 
 
-def eval_task_list(nct: int, nrt: int, with_chol: bool = True, lag: int = 1) -> list:
+def eval_task_list(nct: int, nrt: int, with_chol: bool = True, lag: int = 1, pairs: bool = False) -> list:
     """[(kind, I, J), ...] of the persistent evaluation launch in ticket order (host-only; kind 0 = Cholesky tile,
-    1 = tile of U = L^-T, 2 = tile of Sigma^-1, 3 = alpha (and v) of block row I)."""
+    1 = tile of U = L^-T, 2 = tile of Sigma^-1, 3 = alpha (and v) of block row I).  ``pairs``: the Sigma^-1 tasks as the launch
+    lists them for large matrices -- ``(2, I, J + 0x4000)`` stands for the two tiles (I, J) and (I, J + 1)."""
     lib = load_library()
-    n = lib.gmb_debug_eval_tasks(int(nct), int(nrt), int(bool(with_chol)), int(lag), None, 0)
+    mode = int(bool(with_chol)) | (2 if pairs else 0)
+    n = lib.gmb_debug_eval_tasks(int(nct), int(nrt), mode, int(lag), None, 0)
     if n < 0:
         raise ValueError("gmb_debug_eval_tasks: bad arguments")
     buf = (C.c_uint32 * n)()
-    lib.gmb_debug_eval_tasks(int(nct), int(nrt), int(bool(with_chol)), int(lag), buf, n)
+    lib.gmb_debug_eval_tasks(int(nct), int(nrt), mode, int(lag), buf, n)
     return [(w >> 30, (w >> 15) & 0x7FFF, w & 0x7FFF) for w in buf]
 
 

@@ -321,6 +321,12 @@ int gmb_set_grad_scheme(gmb_engine* e, int32_t scheme, int32_t lag);
  * Sigma^-1; `with_chol` = the factorisation's tasks are part of the launch, `lag` = how many block columns the inverse
  * follows the factorisation by.  Writes at most `cap` words, returns the number of tasks. */
 int64_t gmb_debug_eval_tasks(int32_t nct, int32_t nrt, int32_t with_chol, int32_t lag, uint32_t* out, int64_t cap);
+/* (ABI 9) `with_chol` bit 1 of gmb_debug_eval_tasks: the Sigma^-1 tasks in PAIRS -- a task word whose J field carries 0x4000 stands
+ * for the two tiles (I, J) and (I, J + 1), J + 1 <= I, computed in one pass over block row I of U (128 x 256: the task's own
+ * operand row is streamed once for two tiles).  gmb_set_eval_pairs: -1 = by size (default: matrices of at least 72 block
+ * columns), 0 = never, 1 = always; same results to the bit either way; returns the previous mode plus one, or a negative
+ * gmb_status. */
+int gmb_set_eval_pairs(gmb_engine* e, int32_t mode);
 /* The covariance build alone: what gmb_factorize factors -- the lower-triangle 128 x 128 tiles of
  * Sigma = K + noise + jitter (pymc/GP.py:580), row N = y, identity padding -- written column-major into `out`
  * (device memory; ceil((N+1)/128)*128 rows x ceil(N/128)*128 columns, leading dimension ldo >= the row count).

@@ -222,3 +222,35 @@ def test_evaluation_task_list_is_a_topological_order_of_its_dependency_graph():
                     deps = [(INV, i, q) for q in range(i, nct)]
                 assert all(pos[dep] < t for dep in deps), (nct, nrt, lag, with_chol, tasks[t])
 
+
+
+def test_paired_sigma_inverse_tasks_cover_every_tile_once_and_keep_the_order_topological():
+    """The evaluation launch's list for large matrices (gmb_set_eval_pairs; csrc/eval_tiles.hpp: et_zz2_task): a Sigma^-1 task word
+    with 0x4000 in its J field computes the tiles (I, J) and (I, J + 1) in one pass over block row I of U.  Every tile of the lower
+    block triangle exactly once, pairs only below the diagonal's left neighbour (J + 1 <= I), everything else as in the plain
+    list and in the same order, and every Sigma^-1 task behind all the tiles of U it reads."""
+    from gumbi_amd import engine
+
+    CHOL, INV, ZZ, FIN = 0, 1, 2, 3
+    PAIR = 0x4000
+    for nct, nrt, lag in [(1, 1, 0), (2, 3, 1), (7, 7, 2), (72, 73, 18), (157, 157, 24)]:
+        for with_chol in (True, False):
+            plain = engine.eval_task_list(nct, nrt, with_chol, lag)
+            paired = engine.eval_task_list(nct, nrt, with_chol, lag, pairs=True)
+            assert [t for t in paired if t[0] != ZZ] == [t for t in plain if t[0] != ZZ]
+            tiles = []
+            for k, i, j in paired:
+                if k != ZZ:
+                    continue
+                if j & PAIR:
+                    j &= ~PAIR
+                    assert j + 1 <= i < nct
+                    tiles += [(i, j), (i, j + 1)]
+                else:
+                    assert j <= i < nct
+                    tiles.append((i, j))
+            assert tiles == [(i, j) for k, i, j in plain if k == ZZ]  # the same tiles in the same order, two at a time
+            n_pairs = sum(1 for k, _, j in paired if k == ZZ and j & PAIR)
+            assert n_pairs == sum((i + 1) // 2 for i in range(nct))
+            first_zz = min(t for t, (k, _, _) in enumerate(paired) if k == ZZ)
+            assert all(k != INV for k, _, _ in paired[first_zz:])  # Sigma^-1 only reads U: every INV task has a smaller ticket

@@ -752,6 +752,33 @@ def test_evaluation_schedules_agree_with_each_other_and_the_oracle(gpu, N, kind)
     eng.close()
 
 
+@pytest.mark.parametrize("N,kind", [(300, "ExpQuad"), (2689, "Matern52"), (5200, "ExpQuad"), (9300, "Matern32")])
+def test_paired_sigma_inverse_tasks_change_no_bit(gpu, N, kind):
+    """gmb_set_eval_pairs: Sigma^-1 as 128 x 256 tasks (two tiles per pass over the task's own block row of U; by default for
+    matrices of >= 72 block columns) against the 128 x 128 form -- every output element is the same sum in the same k order in
+    one accumulator, so NLML, gradient and alpha carry the same bits; in the fused launch and behind a final factor; ragged sizes
+    (the cut last k-block), pairs that end on a diagonal tile (I = J + 1)."""
+    d = 3
+    X, y, ls = O.synthetic_table(N, d, seed=43)
+    spec = O.make_spec(d, range(d), kind=kind)
+    theta = O.pack_theta(spec, ls, 1.05, 0.3)
+    eng = make_engine(spec, theta, X, y)
+    got = {}
+    for mode in (0, 1, 0, 1):
+        assert eng.set_eval_pairs(mode) in (-1, 0, 1)
+        val, g = eng.evaluate(theta)
+        alpha = eng.copy_alpha()
+        eng.factorize()
+        val2, g2 = eng.nlml(grad=True)
+        rec = (np.float64(val).tobytes(), g.tobytes(), alpha.tobytes(), np.float64(val2).tobytes(), g2.tobytes())
+        assert got.setdefault(mode, rec) == rec
+    assert got[0] == got[1]
+    if N <= 5200:
+        val_r, grad_r = O.nlml_and_grad(spec, theta, X, y)
+        assert abs(np.frombuffer(got[1][0])[0] - val_r) < 1e-10 * abs(val_r) and rel(np.frombuffer(got[1][1]), grad_r) < 1e-8
+    eng.close()
+
+
 def test_fused_evaluation_is_bit_reproducible_and_survives_a_lost_tile(gpu):
     """Whatever order the workgroups draw the tickets of the fused launch in, NLML / gradient / alpha come out with the same
     bits (every tile written once, contractions in k order); with the first diagonal tile withheld the launch gives up after
