@@ -56,12 +56,21 @@ inline void dist_owned(int rank, int G, int lo, int hi, int* first, int* count) 
 }
 inline int dist_max_owned(int G, int lo, int hi) { return hi > lo ? (hi - lo + G - 1) / G : 0; }
 
-int dist_default_panel(int nct) { return std::max(8, ((nct / 16 + 4) / 8) * 8); }
+// Panel width in block columns when the caller leaves it open: a sixteenth of the matrix for up to four ranks; with more ranks a
+// rank's share of the trailing update shrinks while the panel's chain (gather the square, factor it, solve, gather the panel)
+// does not, so the panels get narrower -- one-rank emulation with a 300 GB/s transport model at N = 100k
+// (profiles/r05_replicated_emulate.txt): G = 8: 694 / 699 / 708 / 737 / 782 ms for 16 / 24 / 32 / 48 / 64 block columns (the bulk stream
+// waits 71 ms for the chain at 24, 147 ms at 48); G = 4: flat from 32 to 48; G = 2: 2508 / 2468 / 2446 ms for 32 / 48 / 64.
+int dist_default_panel(int nct, int G) {
+  const int base = nct / 16 + 4;
+  const int w = G <= 4 ? base : G < 8 ? base * 3 / 4 : base / 2;  // (two ranks would take 64 -- 0.9 % -- at the price of wider panel buffers)
+  return std::max(8, (w / 8) * 8);
+}
 
 std::vector<gmb_dist_step> dist_build_plan(int64_t N, int rank, int G, int w) {
   std::vector<gmb_dist_step> plan;
   const int nct = (int)((N + TILE - 1) / TILE), nrt = (int)((N + 1 + TILE - 1) / TILE);
-  if (w <= 0) w = dist_default_panel(nct);
+  if (w <= 0) w = dist_default_panel(nct, G);
   auto push = [&](int op, int c0, int c1, int lo, int hi, int stream) {
     gmb_dist_step s{};
     s.op = op;
