@@ -1044,7 +1044,7 @@ def comm_block(tm, eng, transport, clock):
     }
 
 
-def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock, map_evals=0):
+def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock, map_evals=0, capacity=False):
     import torch
 
     from gumbi_amd import engine as E
@@ -1083,7 +1083,7 @@ def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock, map_eval
         else:
             from gumbi_amd.distributed import DistributedEngine
 
-            eng = DistributedEngine(local_rank)
+            eng = DistributedEngine(local_rank, capacity=capacity)  # capacity: no rank holds the factor (csrc/dist_capacity.hpp)
             transport = eng.comm.kind
         eng.set_data(X, y)
         eng.set_kernel(spec)
@@ -1227,6 +1227,9 @@ def main():
     ap.add_argument("--map-evals", type=int, default=0,
                     help="one GPU: cap on L-BFGS objective evaluations per fit (0 = run to convergence, cap 200); c5 / several "
                          "GPUs: 0 = fixed hyper-parameters, k > 0 = a (distributed) find_MAP(maxeval=k) per step")
+    ap.add_argument("--capacity", action="store_true",
+                    help="several GPUs, fixed hyper-parameters: the multi-GPU driver's CAPACITY mode (a rank keeps its own block rows + panel "
+                         "buffers; L is streamed again for the gradient and the prediction) instead of the replicated factor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-fit", default=None, choices=["c1", "c2"],
                     help="internal (cpu_baseline): the config's whole step on the HOST -- HipGP's host code over the numpy/LAPACK oracle")
@@ -1282,7 +1285,7 @@ def main():
     if config_name == "c5":
         def section():
             torch.cuda.set_device(local_rank)  # the current device is per-thread state
-            return one_gp_workload(cfg, world, local_rank, dist, args.steps, args.warmup, clock, args.map_evals)
+            return one_gp_workload(cfg, world, local_rank, dist, args.steps, args.warmup, clock, args.map_evals, args.capacity and world > 1)
 
         res, healthy = run_with_deadline(section, float(os.environ.get("GUMBI_BENCH_DEADLINE", "1500")))
     elif config_name == "c4":
@@ -1364,6 +1367,9 @@ def main():
                                          "ONE MAP objective + gradient evaluation + fit at fixed theta (re-factorisation) + grid prediction")
                 out["config"]["not_like_for_like_with"] = ("the one-GPU default line (config c3: a MAP fit to convergence at N = 50k); the one-GPU "
                                                            "point of THIS curve is strong_scaling_base_gflops / `python bench.py --config c5`")
+            if world > 1:
+                out["config"]["factor_storage"] = ("capacity mode: own block rows + panel buffers per rank (gmb_dist_set_mode 1)" if args.capacity and not args.map_evals
+                                                   else "replicated: every rank ends with the complete factor")
             if res.get("comm") is not None:
                 out["comm"] = res["comm"]
                 out["transport"], out["rccl_ranks"] = res["comm"]["transport"], res["comm"]["rccl_ranks"]

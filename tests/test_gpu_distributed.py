@@ -715,7 +715,7 @@ def test_driver_on_the_rccl_backend_with_one_rank(gpu):
     assert e_val < 1e-10 and e_g < 1e-8 and e_mu < 1e-8 and e_var < 1e-9
 
 
-@pytest.mark.parametrize("launcher,map_evals", [("torchrun", 0), ("self", 0), ("self", 3)])
+@pytest.mark.parametrize("launcher,map_evals", [("torchrun", 0), ("self", 0), ("self", 3), ("self-capacity", 0)])
 def test_bench_contract_with_two_ranks_on_one_gpu(gpu, launcher, map_evals):
     """bench.py as the driver launches it for N > 1 (``python -m torch.distributed.run --nproc-per-node N
     bench.py --gpus N ...``) and, ``launcher == "self"``, as plain ``python bench.py --gpus 2`` with NO launcher around it
@@ -735,7 +735,9 @@ def test_bench_contract_with_two_ranks_on_one_gpu(gpu, launcher, map_evals):
     env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
             "127.0.0.1", "--master-port", str(_free_port())] if launcher == "torchrun" else [sys.executable]
-    cmd = head + [str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + (["--map-evals", str(map_evals)] if map_evals else [])
+    capacity = launcher.endswith("capacity")  # (--capacity: the same step with no rank holding the factor)
+    cmd = (head + [str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + (["--map-evals", str(map_evals)] if map_evals else [])
+           + (["--capacity"] if capacity else []))
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -747,7 +749,8 @@ def test_bench_contract_with_two_ranks_on_one_gpu(gpu, launcher, map_evals):
                 "comm_ms_exposed", "strong_scaling_base_gflops", "speedup_over_one_gpu"):
         assert key in d, key
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
-    assert d["launcher"].startswith("bench.py itself" if launcher == "self" else "external")
+    assert d["launcher"].startswith("bench.py itself" if launcher.startswith("self") else "external")
+    assert d["config"]["factor_storage"].startswith("capacity mode" if capacity else "replicated")
     assert d["value"] > 0 and d["results_finite"] and "cpu_baseline" not in d
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert "ONE GP" in d["config"]["workload"] and "over 2 GPUs" in d["config"]["parallelism"]
