@@ -1,4 +1,4 @@
-"""Interleaved A/B of two builds of libgumbi_hip.so on the fused evaluation: ms per gmb_evaluate and result bits, one process per
+"""Interleaved A/B of two builds of libgumbi_hip.so: ms per gmb_evaluate, gmb_factorize, gmb_predict (10^4 points) and result bits, one process per
 build and round.   python tools/gpu_ab_libs.py LIB_A LIB_B      (AB_SIZES, AB_ROUNDS)"""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +16,15 @@ for N in [int(v) for v in os.environ.get("AB_SIZES", "2000,5200,10000,20000").sp
     val, g = e.evaluate(theta); best = 1e9
     for _ in range(8):
         t0 = time.perf_counter(); e.evaluate(theta); best = min(best, (time.perf_counter() - t0) * 1e3)
-    print("lib", os.path.basename(os.environ.get("GUMBI_HIP_LIB", "in-tree")), "N", N, "ms %%.3f" %% best, "TF/s on N^3 %%.1f" %% (float(N)**3 / best / 1e9),
-          "bits", hashlib.sha1(g.tobytes() + e.copy_alpha().tobytes()).hexdigest()[:12], flush=True)
+    alpha = e.copy_alpha()
+    Xs = O.synthetic_grid(d, 100)
+    bf = bp = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter(); e.factorize(); bf = min(bf, (time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter(); mu, var = e.predict(Xs); bp = min(bp, (time.perf_counter() - t0) * 1e3)
+    print("lib", os.path.basename(os.environ.get("GUMBI_HIP_LIB", "in-tree")), "N", N, "evaluate ms %%.3f" %% best, "(%%.1f TF/s on N^3)" %% (float(N)**3 / best / 1e9),
+          "factorize ms %%.3f" %% bf, "predict(10^4) ms %%.3f" %% bp,
+          "bits", hashlib.sha1(g.tobytes() + alpha.tobytes() + e.copy_v().tobytes() + mu.tobytes() + var.tobytes()).hexdigest()[:12], flush=True)
     e.close()
 ''' % root
 libs = sys.argv[1:3]
