@@ -27,7 +27,7 @@ launches alone -- the kernel the north star's MFMA target is stated on -- from p
 profiled evaluations after the timed region, plus the same figure over every GEMM launch, plus the register-only
 MFMA ceiling sampled for >= 1 s BEFORE and AFTER the timed region), ``kbuild`` (HBM GB/s of the covariance build),
 ``phases``, ``cpu_baseline`` (the oracle on a bounded sample on the host cores) and, while the time budget
-(GUMBI_BENCH_BUDGET_S, default 1550 s of process time) allows, ``c2_single_gpu`` (the N = 10k fit whose factorisation is ONE
+(GUMBI_BENCH_BUDGET_S, default 1400 s of process time: a quarter of the driver's 1800 s stays free) allows, ``c2_single_gpu`` (the N = 10k fit whose factorisation is ONE
 launch of the persistent tile kernel: step, phases, the launch's roofline), ``strong_scaling_base_gflops`` / ``c5_single_gpu``
 (the N = 100k problem of the multi-GPU runs on this one GPU), ``default_start`` and ``end_to_end`` (the user-level
 ``DataSet -> GP.fit() -> prepare_grid() -> predict_grid()`` wall time, host transfers included).
@@ -65,6 +65,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s me
 LS_LOWER_Z = 0.5     # ls_bounds of the headline fit: length scales >= half a standard deviation of the input
 WARMUP_EVALS = 3     # evaluation budget of an (untimed) warm-up step
 PROFILE_EVALS = 4    # evaluations of the profiled pass behind `roofline` (per-launch HIP events)
+C2_HOST_CAPPED_EVALS = 4  # evaluation cap of the HOST's C2 fit when the time budget is too short for the whole fit (cpu_baseline)
 T_PROCESS_START = time.perf_counter()
 
 CONFIGS = {
@@ -180,7 +181,7 @@ class Budget:
     say so in the JSON, when starting them would overrun it; the timed steps never are."""
 
     def __init__(self):
-        self.total = float(os.environ.get("GUMBI_BENCH_BUDGET_S", "1550"))
+        self.total = float(os.environ.get("GUMBI_BENCH_BUDGET_S", "1400"))
 
     def used(self):
         return time.perf_counter() - T_PROCESS_START
@@ -316,13 +317,22 @@ def cpu_config_size_sections(budget, gpu_c2=None):
 
     c2  -- the oracle behind the SAME host code (HipGP.find_MAP / predict with tests/oracle_engine.OracleEngine standing in
            for the HIP engine: same priors, same L-BFGS-B, same declaration): one objective + gradient evaluation and one
-           grid prediction at N = 10k always (~12 s); the whole fit to convergence + prediction in a SUBPROCESS when ~6
-           minutes are left (the evaluation count is then the optimiser's own), otherwise evaluations x seconds as an
-           estimate, labelled as one;
+           grid prediction at N = 10k always (~12 s); the whole fit to convergence + prediction in a SUBPROCESS when the ~3.5
+           minutes it takes are left (the evaluation count is then the optimiser's own); with less time a fit CAPPED at
+           C2_HOST_CAPPED_EVALS evaluations is measured instead and the whole fit is that per-evaluation time x the GPU fit's
+           evaluation count + one prediction, labelled as an extrapolation (VERDICT r05 item 3);
     c3  -- LAPACK dpotrf alone on a 50,000 x 50,000 SPD matrix (20 GB; the factorisation of ONE of the fit's ~30
            evaluations);
     c5  -- N = 100k: never run, the N^3 extrapolation of the c3 figure, labelled as one."""
     import subprocess
+
+    def host_fit(maxeval, est):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-fit", "c2"], cwd=str(ROOT), capture_output=True, text=True,
+                           timeout=est * 1.5 + 60.0, env=dict(os.environ, GUMBI_BENCH_NO_CPU="1", GUMBI_BENCH_CPU_FIT_MAXEVAL=str(maxeval)))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"error": (r.stderr or r.stdout)[-300:]}
 
     out = {}
     cfg = CONFIGS["c2"]
@@ -335,30 +345,35 @@ def cpu_config_size_sections(budget, gpu_c2=None):
         n_eval = int(gpu_c2["n_eval"]) if gpu_c2 and gpu_c2.get("n_eval") else 29
         # a fit = its evaluations + ONE prediction (+ the subprocess's start-up and table)
         est_fit = 1.08 * (n_eval + 1) * one["evaluation_seconds"] + one["predict_seconds"] + 25.0
+        est_capped = 1.08 * (C2_HOST_CAPPED_EVALS + 2) * one["evaluation_seconds"] + one["predict_seconds"] + 25.0
         out["c2_seconds_estimate"] = round(n_eval * one["evaluation_seconds"] + one["predict_seconds"], 1)
         out["c2_seconds_estimate_note"] = f"{n_eval} evaluations (the GPU fit's count) x the measured evaluation + one prediction; NOT a measured fit"
-        if budget.allows(est_fit):
-            try:
-                r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-fit", "c2"], cwd=str(ROOT), capture_output=True, text=True,
-                                   timeout=est_fit * 1.5 + 60.0, env=dict(os.environ, GUMBI_BENCH_NO_CPU="1"))
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                if r.returncode == 0 and line:
-                    fit = json.loads(line[-1])
-                    out["c2_seconds"] = fit["fit_predict_seconds"]
-                    out["c2_fit"] = fit
-                else:
-                    out["c2_seconds"] = None
-                    out["c2_fit"] = {"error": (r.stderr or r.stdout)[-300:]}
-            except Exception as err:  # noqa: BLE001
-                out["c2_seconds"] = None
-                out["c2_fit"] = {"error": f"{type(err).__name__}: {err}"[:300]}
-        else:
-            out["c2_seconds"] = None
-            out["c2_fit"] = budget.skipped(est_fit)
+        out["c2_seconds"] = None
+        try:
+            if budget.allows(est_fit):
+                fit = host_fit(200, est_fit)
+                out["c2_fit"] = fit
+                out["c2_seconds"] = fit.get("fit_predict_seconds")
+            elif budget.allows(est_capped):
+                fit = host_fit(C2_HOST_CAPPED_EVALS, est_capped)
+                out["c2_fit_capped"] = fit
+                out["c2_fit"] = budget.skipped(est_fit)
+                if fit.get("n_eval"):
+                    per_eval = fit["fit_seconds"] / fit["n_eval"]  # (declaration and priors included: what the fit pays per evaluation)
+                    out["c2_seconds_extrapolated"] = round(per_eval * n_eval + fit["predict_seconds"], 1)
+                    out["c2_seconds_extrapolated_note"] = (
+                        f"EXTRAPOLATION, not a measured fit: a host fit capped at {fit['n_eval']} evaluations measured {fit['fit_seconds']} s "
+                        f"= {per_eval:.2f} s per evaluation, x the GPU fit's {n_eval} evaluations + the measured prediction "
+                        f"({fit['predict_seconds']} s); the time budget did not allow the ~{est_fit:.0f} s of the whole host fit "
+                        "(profiles/r05_bench_c3_driver_like.json holds a measured one: 173 s)")
+            else:
+                out["c2_fit"] = budget.skipped(est_capped)
+        except Exception as err:  # noqa: BLE001
+            out["c2_fit"] = {"error": f"{type(err).__name__}: {err}"[:300]}
     else:
         out["c2_seconds"] = None
         out["c2_fit"] = budget.skipped(est_eval)
-    est_c3 = 90.0  # (measured: 44 - 45 s for the factorisation + ~15 s to fill 20 GB)
+    est_c3 = 75.0  # (measured: 43 - 45 s for the factorisation + ~15 s to fill 20 GB)
     if budget.allows(est_c3):
         try:
             out.update(cpu_dpotrf_seconds(CONFIGS["c3"]["N"]))
@@ -419,7 +434,7 @@ def cpu_fit_subprocess(config_name):
     t0 = time.perf_counter()
     ds, cols = make_dataset(cfg)
     gp = gmb.GP(ds, outputs=["y"], device=0)
-    gp.fit(continuous_dims=cols, continuous_kernel=cfg["kernel"], ls_bounds=ls_bounds_for(ds, cols, LS_LOWER_Z), MAP_kwargs={"maxeval": 200})
+    gp.fit(continuous_dims=cols, continuous_kernel=cfg["kernel"], ls_bounds=ls_bounds_for(ds, cols, LS_LOWER_Z), MAP_kwargs={"maxeval": int(os.environ.get("GUMBI_BENCH_CPU_FIT_MAXEVAL", "200"))})
     t_fit = time.perf_counter() - t0
     t1 = time.perf_counter()
     if cfg["d"] > 2:
@@ -489,6 +504,14 @@ def roofline_block(tm, config):
         "reproduce_from_profiles": "profiles/*_bench_c3_kernel_stats.csv: AverageNs of gemm_f64_dma_chol_update_kernel; "
                                    "profiles/*_pmc_bench_c3_summary.csv: its MFMA_F64_TFLOPs (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 / duration) "
                                    "and flops per launch; frac = TFLOP/s / 78.6",
+        #  the population behind achieved / frac CHANGED between rounds 4 and 5: r04 = every trailing-update launch of
+        # the Cholesky, whatever tile shape it ran (1950 launches of ~107 GF per profiled pass at C3: 0.914); r05 on = only the
+        # updates large enough for the 128 x 128 kernel (215 launches of ~944 GF: 0.923).  The figures of the two rounds are NOT
+        # like-for-like; `all_trailing_updates` below is the r04 population, measured in this run, and the trend metric across
+        # rounds is roofline_frac_whole_step (top level) / all_gemm_launches
+        "population": "bulk trailing updates that run the 128 x 128 LDS-DMA kernel (ev kind 7); smaller updates (other tile shapes, "
+                      "in-place) are counted under in_panel_products",
+        "population_changed_since": "r04 (r04 = all_trailing_updates below; r04's 0.914 and r05's 0.923 are different populations)",
         "achieved": round(chol_tf, 3),
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
@@ -515,6 +538,13 @@ def roofline_block(tm, config):
             "achieved_over_wall_time": round(tm["total_gemm_flops"] / max(tm.get("total_gemm_wall_ms", 0.0), 1e-9) / 1e9, 3),
         },
     }
+    if tm.get("total_chol_update_all_launches", 0) > 0:
+        # every launch the Cholesky's schedules issue AS a trailing update (the population of `roofline` up to round 4)
+        a_tf = tm["total_chol_update_all_flops"] / max(tm["total_chol_update_all_ms"], 1e-9) / 1e9
+        out["all_trailing_updates"] = {"achieved": round(a_tf, 3), "frac": round(a_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                                       "launches": int(tm["total_chol_update_all_launches"]),
+                                       "avg_launch_ms": round(tm["total_chol_update_all_ms"] / tm["total_chol_update_all_launches"], 5),
+                                       "flops_per_launch": round(tm["total_chol_update_all_flops"] / tm["total_chol_update_all_launches"], 1)}
     if tm.get("masked_gemm_flops", 0.0) > 0.0:
         # trailing updates of the masked look-ahead schedule run on masked_cus of the chip's compute units BY
         # DESIGN (the rest serves the concurrent panel chain): their share and rate are reported separately
@@ -593,8 +623,8 @@ def roofline_block(tm, config):
         # predict: other launch sizes than the ones `achieved` is quoted on), so the bytes are scaled by flops
         bytes_per_flop = pt["bytes_per_launch"] / pt["flops_per_launch"]
         out["traffic"] = round(bytes_per_flop * tm["total_chol_gemm_flops"] / n_chol, 1)
-        out["traffic_unit"] = ("HBM-side bytes per bulk-update launch: (2*FETCH_SIZE + WRITE_SIZE) per flop of the 128x128 "
-                               "gemm_f64_kernel instantiation over one bench step (rocprofv3 PMC passes), times this launch's flops")
+        out["traffic_unit"] = ("HBM-side bytes per bulk-update launch: (2*FETCH_SIZE + WRITE_SIZE) per flop of "
+                               "gemm_f64_dma_chol_update_kernel over one bench step (rocprofv3 PMC passes), times this launch's flops")
         out["traffic_flop_per_byte"] = round(1.0 / bytes_per_flop, 2)
         out["traffic_source"] = pt["source"]
         out["traffic_is_stale"] = pt["stale"]  # the counters were taken on other kernel sources than the ones running now
@@ -711,12 +741,21 @@ def map_fit_workload(cfg, config_name, local_rank, steps, warmup, map_evals, clo
     eng.factorize()
     phases["predict_ms"] = wall_ms(lambda: eng.predict_device(xs_dev.data_ptr(), M, cfg["d"], mean_dev.data_ptr(),
                                                                 var_dev.data_ptr(), True))
+    # the prediction as the timed step runs it: behind the fit's last evaluation, whose inverse factor is still resident -- one GEMM
+    # with a triangular operand instead of the solve for matrices on the tile path (csrc/predict_form.hpp);
+    # the first call also transposes the inverse once (what the step pays), the best of two more is the product alone
+    eng.evaluate(theta_fit)
+    predict = lambda: eng.predict_device(xs_dev.data_ptr(), M, cfg["d"], mean_dev.data_ptr(), var_dev.data_ptr(), True)  # noqa: E731
+    phases["predict_after_fit_first_call_ms"] = wall_ms(predict, reps=1)
+    phases["predict_after_fit_ms"] = wall_ms(predict)
+    phases["predict_after_fit_form"] = "gemm against the resident inverse factor" if eng.timings().get("predict_gemm_form") else "triangular solve"
     phases["ls_limits_ms"] = wall_ms(lambda: gp._prepare_lengthscales(gp.model.X, ARD=True))
     N = cfg["N"]
     phases["rates_tflops"] = {
         "factorize": round(N**3 / 3.0 / phases["factorize_ms"] / 1e9, 2),
         "map_evaluation": round(float(N) ** 3 / phases["factorize_plus_gradient_ms"] / 1e9, 2),
         "predict": round(float(N) ** 2 * M / phases["predict_ms"] / 1e9, 2),
+        "predict_after_fit": round(float(N) ** 2 * M / phases["predict_after_fit_ms"] / 1e9, 2),
     }
     phases["at_theta"] = "the MAP of the timed fits"
     phases["profiled_last_evaluation_ms"] = {k: round(tm[k], 3) for k in
@@ -746,7 +785,8 @@ def c2_side_section(local_rank, clock):
         "ms_per_step": round(1e3 * elapsed, 3), "fit_predict_seconds": round(elapsed, 4), "map_evals": res["n_evals"],
         "value": round(res["flops"] / elapsed / 1e9, 2),
         "unit": "GFLOP/s", "fit_quality": {k: res["quality"][k] for k in ("corr", "sigma_rel_err", "converged", "n_eval") if k in res["quality"]},
-        "phases": {k: ph[k] for k in ("factorize_ms", "factorize_plus_gradient_ms", "predict_ms", "rates_tflops", "tile_cholesky") if k in ph},
+        "phases": {k: ph[k] for k in ("factorize_ms", "factorize_plus_gradient_ms", "predict_ms", "predict_after_fit_ms", "predict_after_fit_first_call_ms",
+                                      "predict_after_fit_form", "rates_tflops", "tile_cholesky") if k in ph},
         "factorisation_roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "frac", "achieved_on_unpadded_N3", "frac_on_unpadded_N3", "launches", "avg_launch_ms", "traffic", "traffic_source", "traffic_is_stale") if k in r},
     }
 
@@ -948,7 +988,7 @@ def c4_workload(cfg, local_rank, steps, warmup, map_evals, clock, stacked_beside
                 ceiling={"before_timed_region": ceiling_before, "after_timed_region": ceiling_after})
 
 
-def cpu_baseline_c4(cfg, target_seconds=20.0):
+def cpu_baseline_c4(cfg, gpu_res=None, target_seconds=20.0):
     """The oracle's STACKED evaluation (what the reference's PyMC model computes: one PN x PN covariance, Cholesky, gradient) +
     prediction on a bounded sample of the C4 workload: n rows per output chosen so that it takes about ``target_seconds``."""
     from oracle import gp_oracle as O
@@ -965,7 +1005,7 @@ def cpu_baseline_c4(cfg, target_seconds=20.0):
         y = np.concatenate([(Y[p] - Y[p].mean()) / Y[p].std(ddof=1) for p in range(P)])
         theta = O.pack_theta(spec, ls, 1.0, 0.2, W_out=C4_W, kappa_out=C4_KAPPA, W_noise=np.array([[1.0, 0.0], [1.5, 0.0]]), kappa_noise=[1e-3, 1e-3])
         t0 = time.perf_counter()
-        O.nlml_and_grad(spec, theta, X, y, dist_mode="gemm")
+        O.nlml_and_grad(spec, theta, X, y, dist_mode="gemm", inverse="potri")  # (dpotri, like the C3 baseline)
         O.predict(spec, theta, X, y, Xs, with_noise=True)
         return time.perf_counter() - t0
 
@@ -977,14 +1017,28 @@ def cpu_baseline_c4(cfg, target_seconds=20.0):
             break
         n = min(cfg["N"], max(n + 64, int(n * (target_seconds / max(dt, 1e-3)) ** (1.0 / 3.0)) // 64 * 64))
         dt = run(n)
-    flops = float(P * n) ** 3 + float(P * n) ** 2 * len(Xs)  # the stacked system's own algorithmic flops
+    # ONE flop basis for host and GPU: the problem's algorithmic flops in the Kronecker form the GPU line counts
+    # (P N^3 per evaluation, P N^2 M_rows per prediction); what the host actually executes -- the stacked (PN)^3 system, like the
+    # reference's PyMC model -- is P^2 times that and is reported beside it, not as `value`
+    flops = c4_step_flops(n, P, len(Xs), 1, 0)
+    stacked = float(P * n) ** 3 + float(P * n) ** 2 * len(Xs)
     cores, blas = host_blas()
-    return {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": int(cores), "blas": blas, "kind": "port",
-            "sample": f"1 stacked MAP objective+gradient evaluation + predict(M={len(Xs)}) at N={n} rows x {P} outputs ({P * n} x {P * n} "
-                      f"covariance), d={d}, {cfg['kernel']} x Coregion + output noise (numpy/LAPACK oracle, {dt:.1f} s)",
-            "seconds": round(dt, 2),
-            "note": "flops counted on the stacked (PN)^3 system the oracle -- like the reference's PyMC model -- actually factors; the GPU "
-                    "line counts the Kronecker form's P N^3"}
+    out = {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": int(cores), "blas": blas, "kind": "port",
+           "sample": f"1 stacked MAP objective+gradient evaluation + predict(M={len(Xs)}) at N={n} rows x {P} outputs ({P * n} x {P * n} "
+                     f"covariance), d={d}, {cfg['kernel']} x Coregion + output noise (numpy/LAPACK oracle, {dt:.1f} s)",
+           "seconds": round(dt, 2),
+           "executed_stacked_system_gflops": round(stacked / dt / 1e9, 2),
+           "note": "value counts the SAME algorithmic flops as the GPU line (Kronecker form: P N^3 per evaluation + P N^2 M per prediction) "
+                   "over the host's seconds, so value ratios are wall-time ratios at equal size; the host executes the stacked (PN)^3 "
+                   "system (executed_stacked_system_gflops)"}
+    if gpu_res is not None and gpu_res.get("phases", {}).get("kronecker_map_evaluation_ms"):
+        ph = gpu_res["phases"]
+        gpu_s = (ph["kronecker_map_evaluation_ms"] + ph["kronecker_predict_ms"]) / 1e3
+        out["gpu_seconds_same_step_at_full_size"] = round(gpu_s, 4)
+        out["host_seconds_extrapolated_to_full_size"] = round(dt * (cfg["N"] / n) ** 3, 1)
+        out["wall_time_ratio_note"] = ("host: the sample's seconds x (N / n)^3 (an extrapolation, labelled); GPU: one Kronecker evaluation + one "
+                                       "prediction at the full N, measured in this run")
+    return out
 
 
 def c4_side_section(local_rank, clock):
@@ -1113,6 +1167,8 @@ def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock, map_eval
         one_step(record=True)
     clock.sync()
     elapsed = time.perf_counter() - t0
+    # (what the TIMED fit found -- before the profiled pass below runs a two-evaluation fit of its own on the same object)
+    quality_timed = fit_quality(gp, last["mu"], cfg) if map_evals > 0 else None
     eng.set_profiling(True)
     if map_evals > 0:
         gp.find_MAP(maxeval=min(map_evals, 2))
@@ -1129,7 +1185,7 @@ def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock, map_eval
         flops = sum(step_flops(N, M, n, r) for n, r in counts)
         phases = {"find_map_s": round(per[0], 4), "predict_s": round(per[1], 4), "map_evals_per_step": [c[0] for c in counts],
                   "refactorizations_at_the_map_per_step": [c[1] for c in counts],
-                  "fit_quality_after_k_evals": fit_quality(gp, last["mu"], cfg), "nlml": float(last["nl"])}
+                  "fit_quality_after_k_evals": quality_timed, "nlml": float(last["nl"])}
     else:
         per = clock.max_over_ranks([part["map_eval"] / steps, part["fit_fixed_theta"] / steps, part["predict"] / steps])
         flops = steps * step_flops(N, M, 1)
@@ -1145,7 +1201,8 @@ def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock, map_eval
     eng.close()
     if gp is not None:
         gp.engine = None
-    return dict(elapsed=elapsed, M=M, tm=tm, phases=phases, finite=finite, transport=transport, flops=flops, comm=comm)
+    return dict(elapsed=elapsed, M=M, tm=tm, phases=phases, finite=finite, transport=transport, flops=flops, comm=comm,
+                last=dict(nlml=float(last["nl"]), mean=np.asarray(last["mu"], dtype=float).copy(), var=np.asarray(last["var"], dtype=float).copy()))
 
 
 def run_with_deadline(fn, seconds):
@@ -1215,6 +1272,53 @@ def self_launch(args):
     sys.stderr.flush()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GUMBI_BENCH_SELF_LAUNCHED="1")
     return subprocess.call(cmd, env=env, cwd=str(ROOT))
+
+
+def c5_fit_predict_block(c5_side):
+    """fit+predict at the north star's size (N = 100k) on ONE GPU for the default line: an estimate from THIS run's measured
+    evaluation (n_eval of the recorded fit x map_eval_s + prediction), labelled, beside the builder-run record of a whole
+    find_MAP to convergence (profiles/*_bench_c5_map.json, `python bench.py --config c5 --map-evals 200 --steps 1 --warmup 0`)."""
+    import glob
+
+    out = {}
+    rec = None
+    files = sorted(glob.glob(os.path.join(str(ROOT), "profiles", "*_bench_c5_map.json")))
+    if files:
+        try:
+            with open(files[-1]) as fh:
+                rec = json.load(fh)
+            rec = rec.get("parsed", rec)
+            q = (rec.get("phases") or {}).get("fit_quality_after_k_evals") or {}
+            out["measured_record"] = {"source": os.path.relpath(files[-1], str(ROOT)), "fit_predict_seconds": rec.get("fit_predict_seconds"),
+                                      "n_eval": q.get("n_eval"), "converged": q.get("converged"), "corr": q.get("corr"),
+                                      "what": "find_MAP to convergence (ls_bounds as in the C3 headline) + 10^4-point grid prediction, one step, "
+                                              "one MI355X; a builder-run record, not this run"}
+        except Exception as err:  # noqa: BLE001
+            out["measured_record"] = {"error": f"{type(err).__name__}: {err}"[:200]}
+    ph = (c5_side or {}).get("phases") or {}
+    n_eval = (out.get("measured_record") or {}).get("n_eval")
+    if ph.get("map_eval_s") and n_eval:
+        out["c5_fit_predict_seconds_estimate"] = round(n_eval * ph["map_eval_s"] + ph.get("predict_s", 0.0), 1)
+        out["estimate_note"] = (f"ESTIMATE ~ n_eval x map_eval_s + predict_s: {n_eval} evaluations (the recorded fit's count) x {ph['map_eval_s']} s "
+                                f"(one evaluation at N = 100k, measured in this run) + {ph.get('predict_s')} s")
+    return out
+
+
+def match_against_one_gpu(dist_last, one_last, map_evals):
+    """The first multi-GPU line must validate itself: NLML, grid mean and variance of the N-rank step
+    against the same step on one GPU (rank 0 runs it after the timed region)."""
+    if not dist_last or not one_last:
+        return {"results_match_one_gpu": None, "results_match_note": "no one-GPU run to compare with"}
+    tol_nl, tol_mu, tol_var = (1e-10, 1e-8, 1e-9) if map_evals <= 0 else (1e-6, 1e-5, 1e-6)
+    nl_rel = abs(dist_last["nlml"] - one_last["nlml"]) / max(abs(one_last["nlml"]), 1e-300)
+    scale = max(float(np.max(np.abs(one_last["mean"]))), 1e-300)
+    mu_rel = float(np.max(np.abs(dist_last["mean"] - one_last["mean"]))) / scale
+    var_abs = float(np.max(np.abs(dist_last["var"] - one_last["var"])))
+    ok = bool(np.isfinite(nl_rel) and nl_rel <= tol_nl and mu_rel <= tol_mu and var_abs <= tol_var)
+    return {"nlml_rel_diff_vs_one_gpu": float(nl_rel), "mean_max_rel_diff_vs_one_gpu": mu_rel, "var_max_abs_diff_vs_one_gpu": var_abs,
+            "results_match_one_gpu": ok,
+            "results_match_note": f"NLML rel {nl_rel:.2e} (<= {tol_nl:g}), grid mean max rel {mu_rel:.2e} (<= {tol_mu:g}), variance max abs "
+                                  f"{var_abs:.2e} (<= {tol_var:g})" + ("; two L-BFGS-B trajectories: looser tolerances" if map_evals > 0 else "")}
 
 
 def main():
@@ -1293,9 +1397,12 @@ def main():
     else:
         res = map_fit_workload(cfg, config_name, local_rank, args.steps, args.warmup, args.map_evals, clock)
 
+    base_last = {}
+
     def c5_on_one_gpu(steps, warmup):
         torch.cuda.set_device(local_rank)
         r = one_gp_workload(CONFIGS["c5"], 1, local_rank, None, steps, warmup, Clock(None, dev), args.map_evals if config_name == "c5" else 0)
+        base_last.update(r["last"])
         return {"workload": CONFIGS["c5"]["label"], "note": "the multi-GPU runs' problem on ONE GPU: their strong-scaling base "
                                                            "(python bench.py --config c5)",
                 "value": round(r["flops"] / r["elapsed"] / 1e9, 2), "unit": "GFLOP/s", "steps": steps, "warmup": warmup,
@@ -1392,17 +1499,27 @@ def main():
                 out["roofline"]["mfma_only_microbench_tflops"] = round(max(cb["tflops_mean"], ca["tflops_mean"]), 2)
                 out["roofline"]["achieved_le_ceiling"] = bool(out["roofline"]["achieved"] <= out["roofline"]["mfma_only_microbench_tflops"])
 
-    # side sections of the one-GPU run (outside the timed steps), most important first, while the time budget lasts
+    # side sections of the one-GPU run (outside the timed steps), most important first, while the time budget lasts;
+    # `section_seconds` says what each one took
+    sections = {}
+
+    def timed_section(name, fn):
+        t_ = time.perf_counter()
+        try:
+            return fn()
+        finally:
+            sections[name] = round(time.perf_counter() - t_, 1)
+
     if world == 1 and out is not None and "error" not in out and config_name != "c5":
         if not args.no_cpu_baseline and os.environ.get("GUMBI_BENCH_NO_CPU") != "1":
-            out["cpu_baseline"] = cpu_baseline_c4(cfg) if config_name == "c4" else cpu_baseline(cfg)
+            out["cpu_baseline"] = timed_section("cpu_baseline", lambda: cpu_baseline_c4(cfg, res) if config_name == "c4" else cpu_baseline(cfg))
         if config_name == "c3" and os.environ.get("GUMBI_BENCH_NO_C2") != "1":
             # the size class Gumbi users live in (BASELINE.json configs[1], N = 10k): a converging fit + prediction, with the
             # phases of one evaluation -- its factorisation is ONE launch of the persistent tile kernel (csrc/chol_tiles.hpp)
-            est = 40.0
+            est = 20.0
             if budget.allows(est):
                 try:
-                    out["c2_single_gpu"] = c2_side_section(local_rank, clock)
+                    out["c2_single_gpu"] = timed_section("c2_single_gpu", lambda: c2_side_section(local_rank, clock))
                 except Exception as err:
                     out["c2_single_gpu"] = {"error": f"{type(err).__name__}: {err}"[:300]}
             else:
@@ -1412,24 +1529,36 @@ def main():
             est = 35.0
             if budget.allows(est):
                 try:
-                    out["c4_single_gpu"] = c4_side_section(local_rank, clock)
+                    out["c4_single_gpu"] = timed_section("c4_single_gpu", lambda: c4_side_section(local_rank, clock))
                 except Exception as err:
                     out["c4_single_gpu"] = {"error": f"{type(err).__name__}: {err}"[:300]}
             else:
                 out["c4_single_gpu"] = budget.skipped(est)
         if os.environ.get("GUMBI_BENCH_NO_DIST") != "1" and config_name != "c4":
-            est = 75.0
+            # (no warm-up step: the C3 run before it has just run the very same kernels for minutes -- VERDICT r05 item 3)
+            est = 45.0
             if budget.allows(est):
-                out["c5_single_gpu"], _ = run_with_deadline(lambda: c5_on_one_gpu(1, 1), 600.0)
+                out["c5_single_gpu"], _ = timed_section("c5_single_gpu", lambda: run_with_deadline(lambda: c5_on_one_gpu(1, 0), 600.0))
                 out["strong_scaling_base_gflops"] = out["c5_single_gpu"].get("value")
+                out["c5_fit_predict"] = c5_fit_predict_block(out["c5_single_gpu"])
             else:
                 out["c5_single_gpu"] = budget.skipped(est)
                 out["strong_scaling_base_gflops"] = None
+        if os.environ.get("GUMBI_BENCH_NO_E2E") != "1" and config_name != "c4":
+            # the user-level call sequence, declaration and host transfers inside the clock (ahead of the host's sections)
+            est = 1.1 * out["fit_predict_seconds"] + 8.0
+            if budget.allows(est):
+                try:
+                    out["end_to_end"] = timed_section("end_to_end", lambda: end_to_end_fit(cfg, local_rank, args.map_evals))
+                except Exception as err:
+                    out["end_to_end"] = {"error": f"{type(err).__name__}: {err}"[:300]}
+            else:
+                out["end_to_end"] = budget.skipped(est)
         if "cpu_baseline" in out and os.environ.get("GUMBI_BENCH_NO_CPU_CONFIG_SIZE") != "1" and config_name != "c4":
-            # the host at the configs' own sizes (minutes of host time; ahead of default_start / end_to_end since round 5: VERDICT r04 item 7), beside fit_predict_seconds
+            # the host at the configs' own sizes (minutes of host time), beside fit_predict_seconds
             gpu_c2 = out.get("fit_quality") if config_name == "c2" else (out.get("c2_single_gpu") or {}).get("fit_quality")
             try:
-                out["cpu_baseline"].update(cpu_config_size_sections(budget, gpu_c2))
+                out["cpu_baseline"].update(timed_section("cpu_config_size", lambda: cpu_config_size_sections(budget, gpu_c2)))
             except Exception as err:  # noqa: BLE001
                 out["cpu_baseline"]["config_size_error"] = f"{type(err).__name__}: {err}"[:300]
             gpu_c2_s = out.get("fit_predict_seconds") if config_name == "c2" else (out.get("c2_single_gpu") or {}).get("fit_predict_seconds")
@@ -1440,29 +1569,35 @@ def main():
             est = 10.0 + 12.0 * out["seconds_per_map_evaluation"]
             if budget.allows(est):
                 try:
-                    out["default_start"] = default_start_fit(cfg, local_rank)
+                    out["default_start"] = timed_section("default_start", lambda: default_start_fit(cfg, local_rank))
                 except Exception as err:
                     out["default_start"] = {"error": f"{type(err).__name__}: {err}"[:300]}
             else:
                 out["default_start"] = budget.skipped(est)
-        if os.environ.get("GUMBI_BENCH_NO_E2E") != "1" and config_name != "c4":
-            est = 1.15 * out["fit_predict_seconds"] + 10.0
-            if budget.allows(est):
-                try:
-                    out["end_to_end"] = end_to_end_fit(cfg, local_rank, args.map_evals)
-                except Exception as err:
-                    out["end_to_end"] = {"error": f"{type(err).__name__}: {err}"[:300]}
-            else:
-                out["end_to_end"] = budget.skipped(est)
-    # several GPUs: the same step on ONE GPU of this node, by rank 0 (the other ranks wait at the final barrier)
+    # several GPUs: the same step on ONE GPU of this node, by rank 0 (the other ranks wait at the final barrier) -- the curve's
+    # one-GPU point AND the check of this line: the N-rank run must have computed what one GPU computes
     if world > 1 and out is not None and "error" not in out and healthy and os.environ.get("GUMBI_BENCH_NO_BASE") != "1":
         base, _ = run_with_deadline(lambda: c5_on_one_gpu(1, 1), 500.0)
         out["strong_scaling_base"] = base
         out["strong_scaling_base_gflops"] = base.get("value")
         if base.get("value"):
             out["speedup_over_one_gpu"] = round(out["value"] / base["value"], 3)
+        if rank == 0:
+            out.update(match_against_one_gpu(res.get("last"), base_last, args.map_evals))
+            if out.get("results_match_one_gpu") is False:
+                out["error"] = {"error": "the N-rank run and the one-GPU run of the same step disagree: " + out["results_match_note"]}
     elif world == 1 and out is not None and "error" not in out and config_name == "c5":
         out["strong_scaling_base_gflops"] = out["value"]  # this IS the one-GPU point
+    if out is not None and "error" not in out:
+        # ONE key under which every line of `--gpus 1 / 2 / 4 / 8` carries its point of the SAME curve (C5, the one-GP workload):
+        # the default one-GPU line's headline is C3 (a different problem), its C5 point is the side figure
+        c5_step = ("find_MAP(maxeval=%d) + grid prediction" % args.map_evals if (config_name == "c5" and args.map_evals > 0) else
+                   "one MAP objective + gradient evaluation + fit at fixed theta + grid prediction")
+        gf = out["value"] if config_name == "c5" else out.get("strong_scaling_base_gflops")
+        out["scale_point"] = {"config": "c5", "n_gpus": world, "gflops": gf, "workload": CONFIGS["c5"]["label"], "step": c5_step,
+                              "note": None if gf is not None else "the C5 side figure was skipped (time budget / GUMBI_BENCH_NO_DIST)"}
+    if sections:
+        out["section_seconds"] = sections
     if out is not None:
         out["bench_wall_s"] = round(budget.used(), 1)
     if rank == 0 and out is not None:

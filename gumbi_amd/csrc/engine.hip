@@ -37,6 +37,7 @@
 #include "trsm_strip.hpp"
 #include "chol_tiles.hpp"
 #include "eval_tiles.hpp"
+#include "predict_form.hpp"
 
 using namespace gmb;
 
@@ -123,6 +124,13 @@ struct gmb_engine {
   // predict workspace
   int64_t Mt_cap = 0;
   double* dV = nullptr;
+  // GEMM-form prediction (predict_form.hpp): behind a gradient on the tile path U = L^-T of the resident factor sits in the
+  // factor buffer's upper triangle + dUdiag (`u_valid`); the first prediction transposes it into dW's lower triangle
+  // (`linv_valid`; Sigma^-1 is dead by then) and every prediction until the next factorisation is one GEMM into dV2
+  bool u_valid = false, linv_valid = false;
+  int predict_form = -1;   // -1 = GEMM form whenever U is there; 0 = always the triangular solve; 1 = as -1 (explicit)
+  double* dV2 = nullptr;   // Np x Mt: the solved cross-covariance with the TRAINING index fastest
+  int64_t Mt2_cap = 0;
   double* dXs = nullptr;
   double* txs = nullptr;
   double* txl = nullptr;
@@ -458,6 +466,11 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
         e->tm.chol_gemm_ms += t;
         e->tm.chol_gemm_flops += p.flops;
         e->tm.chol_gemm_launches += 1;
+        if (p.flags & (1 << 16)) {
+          e->tm.total_chol_update_all_ms += t;
+          e->tm.total_chol_update_all_flops += p.flops;
+          e->tm.total_chol_update_all_launches += 1;
+        }
         if (p.kind == 7) {
           e->tm.total_chol_gemm_ms += t;
           e->tm.total_chol_gemm_flops += p.flops;
@@ -567,9 +580,10 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   // the launches the live events of `roofline` time.  Kind-7 launches small enough for another tile shape count as in-panel
   // products (kind 0), like the panels' own.
   const bool bulk_update = ev_kind == 7 && variant == 0 && !in_place;
+  const int was_update = ev_kind == 7 ? (1 << 16) : 0;  // issued AS a trailing update, whatever tile shape it runs (total_chol_update_all_*)
   if (ev_kind == 7 && !bulk_update) ev_kind = 0;
   ev_begin(e, ev_kind, flops, g_in.mt, g_in.nt, g.k,
-           g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (variant << 8));
+           g.tri | (g.klo_n << 3) | (g.khi_n << 4) | (g.klo_m << 5) | (variant << 8) | was_update);
   const dim3 grid(nblocks);
   const bool pfc = g.beta != 0.0 && g.k <= 1024 && !in_place;
   switch (variant) {
@@ -1061,8 +1075,12 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
   // N = 10k: 75 us median per task, 18.3 ms per evaluation; a quarter of the block columns behind: none, 16.3 ms;
   // tools/gpu_eval_lag.py)
   const int lag = e->et_lag >= 0 ? e->et_lag : std::max(2, std::min(24, nct / 4));
-  // (a traced launch keeps the list its stamps are decoded with)
-  const int pairs = (!e->ct_trace && (e->et_pairs > 0 || (e->et_pairs < 0 && nct >= e->et_pairs_min_blocks))) ? 1 : 0;
+  int nw = 8;
+#ifdef GMB_TUNING
+  if (const char* cw = getenv("GMB_ET_WAVES")) nw = atoi(cw) == 4 ? 4 : 8;
+#endif
+  // (a traced launch keeps the list its stamps are decoded with; the pair task exists for eight-wave workgroups only -- ADVICE r05)
+  const int pairs = (nw == 8 && !e->ct_trace && (e->et_pairs > 0 || (e->et_pairs < 0 && nct >= e->et_pairs_min_blocks))) ? 1 : 0;
   if (e->et_key[0] != nct || e->et_key[1] != nrt || e->et_key[2] != (int)with_chol || e->et_key[3] != lag || e->et_key[4] != pairs) {
     std::vector<uint32_t> list;
     et_build_tasks(nct, nrt, with_chol, lag, list, pairs != 0);
@@ -1080,6 +1098,7 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
   const int64_t words = eval_tiles_words(nct, nrt);
   if ((rc = ensure(e, &e->dct, &e->cap_ct, words + 2))) return rc;
   if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
+  e->u_valid = e->linv_valid = false;  // (U is rewritten, Sigma^-1 takes dW: set again once the launch is known to have succeeded)
   if ((rc = ensure(e, &e->dUdiag, &e->cap_udiag, (int64_t)nct * TILE * TILE))) return rc;
   if ((rc = ensure(e, &e->dApart, &e->cap_apart, (int64_t)nct * nct * TILE + nct))) return rc;  // (+ the partials of |v|^2)
   if ((rc = grad_workspace(e))) return rc;
@@ -1136,10 +1155,6 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
     for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (double)(nrt - j);
   for (int c = 0; c < nct; ++c) flops += 2.0 * TILE * TILE * TILE * 0.5 * (double)c * (double)(c + 1);              // INV column c
   for (int I = 0; I < nct; ++I) flops += 2.0 * TILE * TILE * TILE * (double)(nct - I) * (double)(I + 1);             // ZZ block row I
-  int nw = 8;
-#ifdef GMB_TUNING
-  if (const char* cw = getenv("GMB_ET_WAVES")) nw = atoi(cw) == 4 ? 4 : 8;
-#endif
   const int grid = (int)std::min<long long>(ntasks, nw == 8 ? e->wg_slots / 2 : e->wg_slots);
   ev_begin(e, 9, flops, nct, nrt, (int)e->Np, with_chol ? 1 : 0);
   if (nw == 8) hipLaunchKernelGGL(eval_tiles_kernel<8>, dim3(grid), dim3(512), 0, e->cur, a, x);
@@ -1805,13 +1820,16 @@ int grad_accumulate(gmb_engine* e, std::vector<double>& h) {
       for (size_t t = 0; t < e->terms.size(); ++t)
         std::copy(e->hl->gacc + t * GACC_REGION, e->hl->gacc + (t + 1) * GACC_REGION, h.begin() + t * GACC_REGION);
       e->have_alpha = true;
+      e->u_valid = true;  // (gmb_evaluate takes both back if factorize_finish reports a failure)
       return GMB_OK;  // (abort word, failure index: factorize_finish, which gmb_evaluate calls next)
     }
     if (ab != 0) return fail(e, GMB_EHIP, "tile inverse: a workgroup waited longer than its time-out for a tile (launch abandoned)");
     e->have_alpha = true;
+    e->u_valid = true;
     return GMB_OK;
   }
   if ((rc = ensure(e, &e->dDiagSave, &e->cap_diag, (int64_t)nt * TILE * TILE))) return rc;
+  e->u_valid = e->linv_valid = false;
   PhaseTimer tg(e);
   // the diagonal blocks of L are put back at the end: U takes their place in between
   hipLaunchKernelGGL(diag_blocks_copy_kernel, dim3(nt), dim3(256), 0, e->stream, e->dA, e->ld, e->dDiagSave, 1);
@@ -2150,7 +2168,7 @@ void gmb_destroy(gmb_engine* e) {
   void* ptrs[] = {e->dct, e->dct_trace, e->dstat, e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
                   e->dnoise, e->dscal, e->dv, e->dV, e->dXs, e->txs, e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgred, e->dgbig, e->det_tasks, e->dUdiag, e->dApart,
-                  e->dAown, e->dPanel};
+                  e->dAown, e->dPanel, e->dV2};
   if (e->cap_A == 0) ptrs[11] = nullptr;  // (e->dA may be a virtual base of the capacity driver: nothing of ours to free)
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2195,10 +2213,13 @@ int gmb_set_data(gmb_engine* e, const double* X, int64_t N, int32_t D, int64_t l
   HIP_TRY(e, hipSetDevice(e->device));
   // not ready until every allocation below has succeeded; workspaces sized for the previous N / D are dropped
   e->factored = false;
+  e->factor_kind = gmb_engine::FK_NONE;  // (no factorisation of THIS data has been attempted: gmb_debug_assume_factored must refuse)
   e->have_theta = false;
   e->N = 0;
   e->cap_pts = 0;
   e->Mt_cap = 0;
+  e->Mt2_cap = 0;
+  e->u_valid = e->linv_valid = false;
   e->cap_part = 0;
   e->plan_N = -1;
   e->D = D;
@@ -2237,6 +2258,7 @@ int gmb_set_y(gmb_engine* e, const double* y, int32_t memspace) {
   HIP_TRY(e, hipSetDevice(e->device));
   const hipMemcpyKind kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   e->factored = false;  // the y row of the factor (v = L^-1 y) belongs to the old observations
+  e->factor_kind = gmb_engine::FK_NONE;
   HIP_TRY(e, hipMemcpyAsync(e->dy, y, e->N * sizeof(double), kind, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));  // the caller may reuse its buffer
   return GMB_OK;
@@ -2250,6 +2272,7 @@ int gmb_set_kernel(gmb_engine* e, const gmb_kernel_spec* spec) {
   e->have_spec = true;
   e->have_theta = false;
   e->factored = false;
+  e->factor_kind = gmb_engine::FK_NONE;
   e->nc_pad = pick_nc(spec->n_cont);
   e->cap_pts = 0;
   return GMB_OK;
@@ -2334,6 +2357,7 @@ int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
   e->factor_kind = gmb_engine::FK_SINGLE;
   e->factor_consumed = false;
   e->have_alpha = false;
+  e->u_valid = e->linv_valid = false;
   e->notpd = -1;
   if ((rc = ensure_factor_buffer(e))) return rc;
   gmb_timings& tm = e->tm;
@@ -2500,6 +2524,7 @@ int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, do
   if ((rc = factorize_finish(e))) {
     // the gradient ran on garbage: nothing of it may outlive this call (gmb_copy_alpha checks have_alpha only)
     e->have_alpha = false;
+    e->u_valid = e->linv_valid = false;
     e->factor_consumed = false;
     e->et_fused = false;
     if (factorize_retry_after_abort(e, rc) != GMB_OK) return rc;
@@ -2579,6 +2604,16 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
   const int64_t Mt = predict_tile_rows(e, M);
   if ((rc = predict_workspace(e, Mt))) return rc;
   const int nchunk = (int)((e->N + RED_CHUNK - 1) / RED_CHUNK);
+  // the GEMM form needs the inverse factor the tile path's gradient leaves behind, and a second Mt x Np buffer
+  const bool use_gemm_form = !e->solve_hook && e->predict_form != 0 && e->u_valid && e->factor_kind == gmb_engine::FK_SINGLE &&
+                             e->dW && e->dUdiag && e->cap_W >= e->Np * e->Np;
+  if (use_gemm_form && e->Mt2_cap < Mt) {
+    e->Mt2_cap = 0;
+    if ((rc = alloc(e, &e->dV2, Mt * e->Np))) return rc;
+    e->Mt2_cap = Mt;
+  }
+  bool gemm_form = false;
+  tm.predict_gemm_form = use_gemm_form ? 1 : 0;
 
   const hipMemcpyKind in_kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   const hipMemcpyKind out_kind = memspace == GMB_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -2646,8 +2681,39 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
       const bool tiles = !e->naive_leaf && ntm <= 96 && (e->chol_scheme == 3 || (e->chol_scheme < 0 && by_size));
       e->cur = e->stream;
       e->tt_used = false;
+      gemm_form = false;
       if (e->solve_hook) {
         if ((rc = e->solve_hook(e->dV, mpad, (int)(mpad / TILE)))) return rc;
+      } else if (use_gemm_form) {
+        // U = L^-T of this factor is resident (the fit's last evaluation left it): V^T = L^-1 K(X, X*) as ONE product with a
+        // triangular operand (predict_form.hpp) instead of a solve
+        if (!e->linv_valid) {
+          LinvArgs la{};
+          la.U = e->dA;
+          la.ldu = e->ld;
+          la.udiag = e->dUdiag;
+          la.W = e->dW;
+          la.ldw = e->Np;
+          la.nct = nblocks;
+          hipLaunchKernelGGL(linv_from_u_kernel, dim3((unsigned)((long long)nblocks * (nblocks + 1) / 2)), dim3(256), 0, e->stream, la);
+          HIP_TRY(e, hipGetLastError());
+          e->linv_valid = true;
+        }
+        GemmArgs g{};
+        g.C = e->dV2;
+        g.ldc = e->Np;
+        g.A = e->dV;
+        g.lda = mpad;
+        g.B = e->dW;
+        g.ldb = e->Np;
+        g.mt = ntm;
+        g.nt = nblocks;
+        g.k = (int)e->Np;
+        g.alpha = 1.0;
+        g.beta = 0.0;
+        g.khi_n = 1;
+        if ((rc = launch_gemm(e, g, 3))) return rc;
+        gemm_form = true;
       } else if ((rc = tiles ? trsm_tiles(e, e->dV, mpad, (int)(mpad / TILE), 3)
                              : trsm_cols(e, e->dV, mpad, (int)(mpad / TILE), 0, nblocks, 3, 6)))
         return rc;
@@ -2658,7 +2724,10 @@ int gmb_predict(gmb_engine* e, const double* Xs, int64_t M, int64_t ldxs, int32_
         if (ab != 0) return fail(e, GMB_EHIP, "tile triangular solve: a workgroup waited longer than its time-out for a tile (launch abandoned)");
       }
     }
-    {
+    if (gemm_form) {
+      hipLaunchKernelGGL(predict_rows_kernel, dim3((unsigned)mc), dim3(256), 0, e->stream, e->dV2, e->Np, e->dv, e->N, e->dkss, e->dmean, e->dvar);
+      HIP_TRY(e, hipGetLastError());
+    } else {
       double* pmu = e->dpart;
       double* ps = e->dpart + (int64_t)nchunk * mpad;
       hipLaunchKernelGGL(predict_partial_kernel, dim3((unsigned)(mpad / 256 + (mpad % 256 ? 1 : 0)), nchunk),
@@ -2920,6 +2989,10 @@ int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n) {
 
 int gmb_debug_assume_factored(gmb_engine* e) {
   if (!e) return GMB_EINVAL;
+  // a door for the timing tools (tools/gpu_dist_emulate.py), never for a caller of the product: it takes an explicit opt-in
+  // in the environment
+  const char* door = getenv("GUMBI_HIP_DEBUG_DOORS");
+  if (!door || door[0] != '1') return fail(e, GMB_EINVAL, "gmb_debug_assume_factored needs GUMBI_HIP_DEBUG_DOORS=1 in the environment");
   if (e->factor_kind == gmb_engine::FK_NONE || !e->have_theta) return fail(e, GMB_EINVAL, "no factorisation has been attempted at this theta");
   e->factored = true;
   e->factor_consumed = false;
@@ -2942,6 +3015,13 @@ int gmb_set_grad_scheme(gmb_engine* e, int32_t scheme, int32_t lag) {
   const int old = e->grad_scheme;
   e->grad_scheme = scheme;
   if (lag >= 0) e->et_lag = lag;
+  return old + 1;
+}
+
+int gmb_set_predict_form(gmb_engine* e, int32_t form) {
+  if (!e || form < -1 || form > 1) return GMB_EINVAL;
+  const int old = e->predict_form;
+  e->predict_form = form;
   return old + 1;
 }
 

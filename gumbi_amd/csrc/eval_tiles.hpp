@@ -942,6 +942,13 @@ __device__ __noinline__ bool et_zz2_task(const CholTilesArgs g_in, ct_g_double* 
   const EtOperand nop{g.A + (int64_t)I * TILE, g.ld, ud + (int64_t)I * TILE * TILE, I};
   double* out0 = (double*)Z + (int64_t)I * TILE + (int64_t)J * TILE * ldz;
   const int k_last = (int)(g.N - (int64_t)(g.nct - 1) * TILE);
+  static_assert(NW == 8 || NW == 4, "");
+  if constexpr (NW != 8) {
+    // no pair contraction for four-wave workgroups (the host never lists pair tasks for them): give the launch up loudly
+    // rather than leave two tiles of Sigma^-1 unwritten
+    if (wave == 0) __hip_atomic_store(g.ctl + 1, 1u, CT_RLX_AGENT);
+    return false;
+  }
   if constexpr (NW == 8) {
 #ifdef ET_PAIR_REG
     if (!et_ksum_reg2<false>(g, m0, m1, nop, uf + (int64_t)J * g.nct, uf + (int64_t)(J + 1) * g.nct, uf + (int64_t)I * g.nct, I, g.nct, out0,

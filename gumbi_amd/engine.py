@@ -101,6 +101,12 @@ class Timings(C.Structure):
         ("total_eval_tile_ms", C.c_double),
         ("total_eval_tile_flops", C.c_double),
         ("total_eval_tile_launches", C.c_int64),
+        # ABI 10: every launch issued AS a Cholesky trailing update (the population of ``total_chol_gemm_*`` up to round 4), and
+        # which form the last prediction took
+        ("total_chol_update_all_ms", C.c_double),
+        ("total_chol_update_all_flops", C.c_double),
+        ("total_chol_update_all_launches", C.c_int64),
+        ("predict_gemm_form", C.c_int64),
     ]
 
     def as_dict(self):
@@ -254,6 +260,7 @@ _SIGNATURES = {
     "gmb_set_chol_scheme": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_debug_assume_factored": (C.c_int, [C.c_void_p]),
     "gmb_set_eval_pairs": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gmb_set_predict_form": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_set_grad_scheme": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "gmb_dist_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_resident_bytes": (C.c_int64, [C.c_void_p, C.c_int32]),
@@ -302,8 +309,10 @@ def _preload_hip_runtime():
 #: version 6 the communication fields of ``gmb_timings`` and ``gmb_rccl_comm_ranks``; version 7 ``gmb_evaluate``, the tile
 #: Cholesky's doors ``gmb_set_chol_scheme`` / ``gmb_chol_task_trace`` / ``gmb_debug_chol_*``; version 8 the persistent evaluation
 #: launch: ``gmb_set_grad_scheme``, ``gmb_debug_eval_tasks``, ``total_eval_tile_*`` in ``gmb_timings``; version 9 the timing
-#: tools' door ``gmb_debug_assume_factored``, the guards between single-engine and capacity-mode factorisations, ``gmb_set_eval_pairs``)
-ABI_VERSION = 9
+#: tools' door ``gmb_debug_assume_factored``, the guards between single-engine and capacity-mode factorisations, ``gmb_set_eval_pairs``;
+#: version 10 ``gmb_set_predict_form`` (GEMM-form prediction behind a fit), ``total_chol_update_all_*`` / ``predict_gemm_form`` in
+#: ``gmb_timings``, ``gmb_debug_assume_factored`` behind GUMBI_HIP_DEBUG_DOORS=1)
+ABI_VERSION = 10
 
 
 def load_library():
@@ -581,6 +590,14 @@ class Engine:
         prev = int(self._lib.gmb_set_eval_pairs(self._h, int(mode)))
         if prev < 0:
             self._check(prev, "gmb_set_eval_pairs")
+        return prev - 1
+
+    def set_predict_form(self, form: int) -> int:
+        """How ``predict`` forms K(X*, X) L^-T: -1 / 1 = one GEMM against the inverse factor whenever the fit's last gradient
+        evaluation left it resident (tile path), 0 = always the triangular solve; returns the previous mode."""
+        prev = int(self._lib.gmb_set_predict_form(self._h, int(form)))
+        if prev < 0:
+            self._check(prev, "gmb_set_predict_form")
         return prev - 1
 
     def debug_assume_factored(self):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GMB_ABI_VERSION 9
+#define GMB_ABI_VERSION 10
 #define GMB_MAX_DIMS 16   /* continuous dims per kernel */
 #define GMB_MAX_LIN 8     /* linear dims per kernel (subset of the continuous dims) */
 #define GMB_MAX_COREG 4   /* categorical (coregion) dims besides the output column */
@@ -164,6 +164,15 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
   double total_eval_tile_ms;
   double total_eval_tile_flops;
   int64_t total_eval_tile_launches;
+  /* (ABI 10) every launch the Cholesky's schedules issue AS a trailing update, whatever tile shape it runs -- the population
+     `total_chol_gemm_*` covered up to round 4; since round 5 total_chol_gemm_* holds only the updates large enough for the
+     128 x 128 kernel (gemm_f64_dma_chol_update_kernel).  Cumulative like total_gemm_*. */
+  double total_chol_update_all_ms;
+  double total_chol_update_all_flops;
+  int64_t total_chol_update_all_launches;
+  /* (ABI 10) 1 when the last gmb_predict formed A^T = K(X*, X) L^-T as one GEMM against the inverse factor the fit's last
+     gradient evaluation left behind (csrc/predict_form.hpp), 0 when it solved against L (gmb_set_predict_form) */
+  int64_t predict_gemm_form;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;
@@ -327,6 +336,12 @@ int64_t gmb_debug_eval_tasks(int32_t nct, int32_t nrt, int32_t with_chol, int32_
  * columns), 0 = never, 1 = always; same results to the bit either way; returns the previous mode plus one, or a negative
  * gmb_status. */
 int gmb_set_eval_pairs(gmb_engine* e, int32_t mode);
+/* How gmb_predict forms A^T = K(X*, X) L^-T (pm.gp.Marginal.predict's `solve_lower`, pymc/GP.py:845-847).  Behind a gradient
+ * evaluation on the tile path (N <= ~28k: gmb_evaluate, or gmb_nlml with a gradient) the engine still holds U = L^-T of the
+ * resident factor; the prediction is then ONE product with a triangular operand (the GEMM that runs at 0.93 of the f64 matrix
+ * peak) instead of a triangular solve (0.73 at N = 10k).  -1 = that whenever U is there (default), 0 = always solve, 1 = as -1.
+ * Results agree with the solve to ~cond(L) eps (tests: <= 1e-10 relative on the golden cases).  Returns the previous mode + 1. */
+int gmb_set_predict_form(gmb_engine* e, int32_t form);
 /* The covariance build alone: what gmb_factorize factors -- the lower-triangle 128 x 128 tiles of
  * Sigma = K + noise + jitter (pymc/GP.py:580), row N = y, identity padding -- written column-major into `out`
  * (device memory; ceil((N+1)/128)*128 rows x ceil(N/128)*128 columns, leading dimension ldo >= the row count).

@@ -269,3 +269,49 @@ def test_gpus_flag_must_agree_with_the_launchers_world_size():
     assert out.returncode == 2
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["value"] is None and "WORLD_SIZE=1" in d["error"]["error"] and "--gpus 4" in d["error"]["error"]
+
+
+def test_multi_gpu_line_validates_itself_against_the_one_gpu_run():
+    """match_against_one_gpu: NLML / grid mean / variance of the N-rank step against the one-GPU step; a
+    mismatch is reported as one, with the figures."""
+    bench = load_bench()
+    rng = np.random.default_rng(0)
+    one = {"nlml": 56701.96, "mean": rng.standard_normal(100), "var": rng.random(100) + 0.1}
+    same = {"nlml": one["nlml"] * (1 + 2e-14), "mean": one["mean"] + 1e-13, "var": one["var"] + 1e-14}
+    r = bench.match_against_one_gpu(same, one, 0)
+    assert r["results_match_one_gpu"] is True and r["nlml_rel_diff_vs_one_gpu"] < 1e-13 and r["mean_max_rel_diff_vs_one_gpu"] < 1e-12
+    off = dict(same, nlml=one["nlml"] * (1 + 1e-8))
+    r = bench.match_against_one_gpu(off, one, 0)
+    assert r["results_match_one_gpu"] is False and "NLML rel" in r["results_match_note"]
+    assert bench.match_against_one_gpu(off, one, 5)["results_match_one_gpu"] is True  # two optimiser trajectories: looser
+    r = bench.match_against_one_gpu(dict(same, mean=one["mean"] + 1e-3), one, 0)
+    assert r["results_match_one_gpu"] is False
+    assert bench.match_against_one_gpu(None, one, 0)["results_match_one_gpu"] is None
+    assert bench.match_against_one_gpu(dict(same, nlml=float("nan")), one, 0)["results_match_one_gpu"] is False
+
+
+def test_c5_fit_predict_block_labels_its_estimate(tmp_path, monkeypatch):
+    """The default line's figure for fit+predict at the north star's size: an ESTIMATE from this run's evaluation time and
+    the recorded fit's evaluation count, beside the builder-run record itself."""
+    import json
+
+    bench = load_bench()
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "r98_bench_c5_map.json").write_text(json.dumps(
+        {"fit_predict_seconds": 430.0, "phases": {"fit_quality_after_k_evals": {"n_eval": 30, "converged": True, "corr": 0.999}}}))
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    b = bench.c5_fit_predict_block({"phases": {"map_eval_s": 14.0, "predict_s": 1.4}})
+    assert b["measured_record"]["fit_predict_seconds"] == 430.0 and b["measured_record"]["n_eval"] == 30
+    assert abs(b["c5_fit_predict_seconds_estimate"] - (30 * 14.0 + 1.4)) < 0.06 and "ESTIMATE" in b["estimate_note"]
+    (tmp_path / "profiles" / "r98_bench_c5_map.json").unlink()
+    assert bench.c5_fit_predict_block({"phases": {"map_eval_s": 14.0}}) == {}
+
+
+def test_c4_host_baseline_counts_the_gpu_lines_flops():
+    """host and GPU on ONE flop basis (the Kronecker form's), the stacked system's executed flops beside it."""
+    bench = load_bench()
+    cfg = dict(bench.CONFIGS["c4"], N=256, res=8)
+    r = bench.cpu_baseline_c4(cfg, target_seconds=0.01)
+    n = int(r["sample"].split("at N=")[1].split(" ")[0])
+    assert abs(r["value"] - bench.c4_step_flops(n, 2, 2 * 64, 1, 0) / r["seconds"] / 1e9) / r["value"] < 0.02
+    assert r["executed_stacked_system_gflops"] > 2.0 * r["value"] and "SAME algorithmic flops" in r["note"]

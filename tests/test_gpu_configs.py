@@ -93,6 +93,15 @@ def test_c2_full_size_direct_parity_and_dense_grid(gpu):
     mu_s, var_s = eng.predict(Xs[sub], with_noise=True)
     assert rel(mu_s, mu[sub]) < 1e-12 and np.max(np.abs(var_s - var[sub])) < 1e-12
     assert np.isclose(eng.nlml(), O.nlml(spec, theta, X, y), rtol=1e-10)
+    # the prediction behind a FIT: the last evaluation left the inverse factor resident, K(X*, X) L^-T is one GEMM
+    # (csrc/predict_form.hpp) -- same oracle, same tolerances, and 1e-10 from the solve form
+    eng.evaluate(theta)
+    mu_g, var_g = eng.predict(Xs[:20_000], with_noise=True)
+    assert eng.timings()["predict_gemm_form"] == 1
+    sub2 = sub[sub < 20_000] if np.any(sub < 20_000) else np.arange(8)
+    assert rel(mu_g, mu[:20_000]) < 1e-10 and np.max(np.abs(var_g - var[:20_000])) < 1e-11
+    mu_r2, var_r2 = O.predict(spec, theta, X, y, Xs[sub2], with_noise=True)
+    assert rel(mu_g[sub2], mu_r2) < 1e-8 and np.max(np.abs(var_g[sub2] - var_r2)) < 1e-9
     eng.close()
 
 

@@ -765,6 +765,11 @@ def test_bench_contract_with_two_ranks_on_one_gpu(gpu, launcher, map_evals):
     base = d["strong_scaling_base"]
     assert "error" not in base and base["results_finite"] and base["value"] == d["strong_scaling_base_gflops"] > 0
     assert abs(d["speedup_over_one_gpu"] - d["value"] / base["value"]) < 2e-3
+    # the line validates itself against that one-GPU run and carries its point of the C5 curve under one name
+    assert d["results_match_one_gpu"] is True, d["results_match_note"]
+    assert 0 <= d["nlml_rel_diff_vs_one_gpu"] <= (1e-6 if map_evals else 1e-10)
+    assert d["mean_max_rel_diff_vs_one_gpu"] <= (1e-5 if map_evals else 1e-8) and d["var_max_abs_diff_vs_one_gpu"] <= (1e-6 if map_evals else 1e-9)
+    assert d["scale_point"]["config"] == "c5" and d["scale_point"]["n_gpus"] == 2 and d["scale_point"]["gflops"] == d["value"]
     ph = d["phases"]
     N, M = 3000, 10_000
     if map_evals:
@@ -822,6 +827,8 @@ def test_bench_contract_single_process(gpu):
     assert "error" not in side, side
     assert side["results_finite"] and side["value"] > 0 and "N=2304" in side["workload"]
     assert d["strong_scaling_base_gflops"] == side["value"]
+    assert d["scale_point"] == dict(d["scale_point"], config="c5", n_gpus=1, gflops=side["value"]) and side["warmup"] == 0
+    assert set(d["section_seconds"]) >= {"cpu_baseline", "c4_single_gpu", "c5_single_gpu", "end_to_end", "default_start"}
     # what the timed fit found (capped at 4 evaluations here, so no quality bar -- only that it is reported)
     q = d["fit_quality"]
     assert set(q) >= {"corr", "rmse", "sigma_hat", "sigma_true", "nlml_final", "n_eval", "converged"} and q["n_eval"] == d["config"]["map_evals_per_step"][0]

@@ -309,6 +309,67 @@ def test_predict_matches_goldens(gpu, case):
     assert rel(mu, mu_d) < 1e-10 and np.max(np.abs(var - var_d)) < 1e-11
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_predict_gemm_form_matches_goldens(gpu, case):
+    """Behind a gradient evaluation the engine holds U = L^-T of the resident factor and forms K(X*, X) L^-T as ONE product with
+    a triangular operand instead of a solve (csrc/predict_form.hpp): same goldens, same tolerances, and the
+    solve form on the same engine beside it."""
+    spec = golden_spec(case)
+    X, y, Xs, theta = (GOLD[f"{case}/{k}"] for k in ("X", "y", "Xs", "theta"))
+    eng = make_engine(spec, theta, X, y)
+    eng.evaluate(theta)  # objective + gradient: the factor AND its inverse stay resident
+    mu, var = eng.predict(Xs, with_noise=True)
+    assert eng.timings()["predict_gemm_form"] == 1
+    assert rel(mu, GOLD[f"{case}/mu"]) < 1e-8 and np.max(np.abs(var - GOLD[f"{case}/var"])) < 1e-9
+    mu_d, var_d = O.predict(spec, theta, X, y, Xs, with_noise=True, dist_mode="direct")
+    assert rel(mu, mu_d) < 1e-10 and np.max(np.abs(var - var_d)) < 1e-11
+    mu2, var2 = eng.predict(Xs, with_noise=True)  # (the transposed inverse is reused: same bits)
+    assert np.array_equal(mu2, mu) and np.array_equal(var2, var)
+    assert eng.set_predict_form(0) == -1
+    mu_s, var_s = eng.predict(Xs, with_noise=True)
+    assert eng.timings()["predict_gemm_form"] == 0
+    assert rel(mu, mu_s) < 1e-11 and np.max(np.abs(var - var_s)) < 1e-12
+    eng.set_predict_form(-1)
+    # a factorisation without a gradient has no inverse: back to the solve, silently
+    eng.factorize()
+    mu_f, var_f = eng.predict(Xs, with_noise=True)
+    assert eng.timings()["predict_gemm_form"] == 0 and np.array_equal(mu_f, mu_s) and np.array_equal(var_f, var_s)
+    eng.close()
+
+
+@pytest.mark.parametrize("N,M", [(129, 1), (1000, 127), (2321, 129), (5000, 1000)])
+def test_predict_gemm_form_ragged_sizes(gpu, N, M):
+    """Ragged last blocks on both sides (the inverse's padding rows and columns are zero, the cross-covariance's padding too),
+    through gmb_evaluate and through gmb_factorize + gmb_nlml(grad)."""
+    d = 3
+    X, y, ls = O.synthetic_table(N, d, seed=N)
+    spec = O.make_spec(d, range(d), kind="Matern52")
+    theta = O.pack_theta(spec, ls, 1.3, 0.25)
+    Xs = np.random.default_rng(M).standard_normal((M, d))
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+    eng = make_engine(spec, theta, X, y)
+    eng.evaluate(theta)
+    mu, var = eng.predict(Xs)
+    assert eng.timings()["predict_gemm_form"] == 1
+    assert rel(mu, mu_r) < 1e-10 and np.max(np.abs(var - var_r)) < 1e-11
+    eng.factorize()
+    eng.nlml(grad=True)
+    by_tiles = -(-N // 128) >= 6  # (below six block columns the separate gradient call takes the launch tree: no U by rows)
+    mu2, var2 = eng.predict(Xs)
+    assert eng.timings()["predict_gemm_form"] == (1 if by_tiles else 0)
+    assert rel(mu2, mu_r) < 1e-10 and np.max(np.abs(var2 - var_r)) < 1e-11
+    # new hyper-parameters: nothing of the old inverse may be used
+    theta2 = O.pack_theta(spec, ls * 1.5, 0.9, 0.3)
+    eng.set_theta(theta2)
+    with pytest.raises(ValueError):
+        eng.predict(Xs)
+    eng.evaluate(theta2)
+    mu3, var3 = eng.predict(Xs)
+    mu_r3, var_r3 = O.predict(spec, theta2, X, y, Xs, dist_mode="direct")
+    assert rel(mu3, mu_r3) < 1e-10 and np.max(np.abs(var3 - var_r3)) < 1e-11
+    eng.close()
+
+
 def test_predict_edge_cases(gpu):
     X, y, ls = O.synthetic_table(200, 3, seed=5)
     spec = O.make_spec(3, range(3))

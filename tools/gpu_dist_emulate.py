@@ -13,6 +13,8 @@ DE_CAPACITY=1: the capacity mode (gmb_dist_set_mode(e, 1)): factorisation, then 
 """
 import ctypes as C
 import os
+
+os.environ.setdefault("GUMBI_HIP_DEBUG_DOORS", "1")  # gmb_debug_assume_factored is a tools-only door
 import sys
 import time
 from pathlib import Path
