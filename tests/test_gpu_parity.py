@@ -333,7 +333,8 @@ def test_predict_gemm_form_matches_goldens(gpu, case):
     # a factorisation without a gradient has no inverse: back to the solve, silently
     eng.factorize()
     mu_f, var_f = eng.predict(Xs, with_noise=True)
-    assert eng.timings()["predict_gemm_form"] == 0 and np.array_equal(mu_f, mu_s) and np.array_equal(var_f, var_s)
+    # (another schedule factored the matrix -- gmb_factorize, not the fused launch: equal to rounding, not to the bit)
+    assert eng.timings()["predict_gemm_form"] == 0 and rel(mu_f, mu_s) < 1e-12 and np.max(np.abs(var_f - var_s)) < 1e-12
     eng.close()
 
 
