@@ -81,6 +81,10 @@ struct CholTilesArgs {
   double* V;
   int64_t ldv;
   int32_t ntm;
+  // A launch on a PANEL of a larger matrix (engine.hip: chol_tiles_panel -- the bottom of the large matrices' recursion): A,
+  // dinv16 and N are the panel's own (origin = its diagonal's first element); row_base = the global index of that element,
+  // for the failure index only.
+  int64_t row_base;
 };
 
 __host__ __device__ inline int64_t ct_col_start(int J, int nrt) { return (int64_t)J * nrt - (int64_t)J * (J - 1) / 2; }
@@ -100,6 +104,14 @@ __host__ __device__ inline void ct_decode(int t, int nct, int nrt, int& I, int& 
 }
 
 #define CT_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// a pointer every lane holds the same value of, moved to scalar registers (address arithmetic and the LDS-DMA's base stay
+// on the scalar unit)
+__device__ __forceinline__ const double* et_uni_ptr_c(const double* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const double*)(((uint64_t)hi << 32) | lo);
+}
 
 // wave-uniform: true when the wait must be abandoned (somebody raised the abort word, or this wave has waited
 // longer than the time-out and raises it itself)
@@ -191,9 +203,23 @@ __device__ __forceinline__ int ct_wait_two(const CholTilesArgs& g, const uint32_
 // packed LDS layout (potrf_leaf_core<.., PRE = true>) instead of global memory.
 // TRSM: the "n" operand and the tile itself live in V (row tile I of the right-hand sides) instead of the factor buffer, and
 // only the flags of row I matter (the factor is final).
-template <int NW, bool TRSM = false>
+// eight-wave tasks stage the diagonal block of their strip solve through LDS (ct_strip_solve_lds); 0 = the global-operand form (A/B)
+#ifndef CT_STRIP_LDS
+#define CT_STRIP_LDS 1
+#endif
+// the ragged last block's tasks contract their real sixteen-wide groups only (ct_ksum<.., RAG>); 0 = whole tiles (A/B)
+#ifndef CT_RAGGED
+#define CT_RAGGED 1
+#endif
+
+// RAG (the ragged last block): only the first nrow16 sixteen-row groups of the tile (the last block ROW of
+// the bordered matrix: N + 1 - 128 I real rows) or the first ncol16 sixteen-column groups (the last block COLUMN of the solve:
+// N - 128 J real columns) are contracted -- the others would multiply the padding's zeros.  Every computed element is the same
+// sum in the same order as in the full form (same bits); the waves are dealt so that the live groups sit on all four SIMDs
+// (a row cut keeps the waves 0 .. 3 busy: wave -> (column quarter, row half) = (wave % 4, wave / 4) instead of (wave / 2, wave % 2)).
+template <int NW, bool TRSM = false, bool RAG = false>
 __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, const int J, double* __restrict__ lds,
-                                        int* s_i, const bool to_lds) {
+                                        int* s_i, const bool to_lds, const int nrow16 = 8, const int ncol16 = 8) {
   constexpr int WGN = 2, WGM = NW / WGN;           // waves along n (rows) and m (columns)
   constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);  // MFMA tiles per wave
   constexpr int KT = ct_kt(NW);            // (shadows gmb::KT of the launch-based GEMM)
@@ -202,7 +228,10 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
+  const bool rowcut = RAG && nrow16 < 8;
+  const int wm = rowcut ? wave % WGM : wave / WGN, wn = rowcut ? wave / WGM : wave % WGN;
+  // live MFMA tiles of this wave (RAG): i < ni along the columns, j < nj along the rows
+  const int ni = RAG ? max(0, min(WTM, ncol16 - wm * WTM)) : WTM, nj = RAG ? max(0, min(WTN, nrow16 - wn * WTN)) : WTN;
   const int r16 = lane & 15, kq = lane >> 4;
   const int s_row = tid / LA, s_col = 2 * (tid % LA);
   const double* __restrict__ Ag = g.A + (int64_t)J * TILE + s_col;  // "m" operand: rows of block row J = columns of the tile
@@ -264,7 +293,13 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WTN; ++j) {
+          if constexpr (RAG) {
+            if (i < ni && j < nj) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);  // (wave-uniform)
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          }
+        }
     }
   };
 
@@ -323,16 +358,18 @@ __device__ __forceinline__ bool ct_ksum(const CholTilesArgs& g, const int I, con
       gload(kt + 1);
       compute(st);
       lstore(st ^ 1);
+      if constexpr (!RAG) {  // (the ragged form's MFMAs sit behind scalar branches: nothing to pin)
 #pragma unroll
-      for (int q = 0; q < NMEM; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * SLOT * NMEM, 0);
+        for (int q = 0; q < NMEM; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * SLOT * NMEM, 0);
 #pragma unroll
-      for (int q = 0; q < NMEM; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+        for (int q = 0; q < NMEM; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, SLOT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+        }
       }
       __syncthreads();
       st ^= 1;
@@ -448,7 +485,7 @@ __device__ __noinline__ bool ct_diag_task(const CholTilesArgs g_in, ct_g_double*
   a.dinv16 = g.dinv16 + (int64_t)J * 8 * 256;
   a.logdet = g.logdet;
   a.info = g.info;
-  a.row0 = (int64_t)J * TILE;
+  a.row0 = g.row_base + (int64_t)J * TILE;
   a.dbg = nullptr;
   a.prog = NW == 8 ? g.prog + J : nullptr;  // (the strip solve below it follows the leaf column by column)
   if (pre) potrf_leaf_core<NW, true, true>(a, lds);
@@ -526,6 +563,80 @@ __device__ __forceinline__ void ct_strip_solve_pipelined(const CholTilesArgs& g,
     for (int q = 0; q < 4; ++q) __hip_atomic_store(&Bp[(int64_t)(16 * s + kq + 4 * q) * ta.ldb], X[s][q], CT_RLX_AGENT);
 }
 
+// The strip solve of an eight-wave task with its operands staged through LDS.  trsm_strip_solve_store_pf reads L(J, J) and
+// the sub-block inverses straight from global memory, every wave for itself, one step ahead: eight dependent L2 round trips
+// per slab, 17 - 19 us per task of which the 144 MFMAs are 3 (profiles/r05_eval_pairs_ab.txt; 2.7 % of a C2 evaluation).  Here
+// the workgroup pulls the block in ONCE by LDS-DMA -- columns 0 .. 111 of the factored diagonal block as a [column][row]
+// image with the contraction's pitch (the last sixteen columns hold only the diagonal sub-block, which the solve replaces by
+// its inverse), the eight 16 x 16 sub-block inverses behind it: 145,408 B, inside the contraction's ring, which is dead by
+// then -- one round trip, then every operand is a ds_read.  Same operands, same MFMAs in the same order as the global form:
+// the same bits.  Every thread of the workgroup calls it (two barriers inside); r0 = 16 * wave.
+template <bool WT>
+__device__ __forceinline__ void ct_strip_solve_lds(const TrsmArgs& g, const int64_t r0, strip_d4 (&X)[8], ct_lds_double* l3) {
+  typedef strip_d4 d4;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void g_void;
+  constexpr int PA = PITCH;
+  constexpr int NCOL = TILE - 16;      // columns of L(J, J) the solve reads
+  constexpr int DINV_AT = NCOL * PA;   // the sub-block inverses behind the image
+  static_assert(DINV_AT + 8 * 256 <= ct_lds_doubles(8), "the staged diagonal block must fit the contraction's ring");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const double* Lg = et_uni_ptr_c(g.L);
+  const double* Dg = et_uni_ptr_c(g.dinv16);
+  const int64_t ldl = g.ldl;
+#pragma unroll
+  for (int q = 0; q < NCOL / 8; ++q) {
+    const int j = wave + 8 * q;
+    __builtin_amdgcn_global_load_lds((g_void*)(Lg + (int64_t)j * ldl + 2 * lane), (lds_void*)(l3 + j * PA), 16, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = wave + 8 * q;
+    __builtin_amdgcn_global_load_lds((g_void*)(Dg + c * 128 + 2 * lane), (lds_void*)(l3 + DINV_AT + c * 128), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  double* Bp = g.B + r0 + r16;
+  double ops[2][32];
+  auto load_step = [&](const int s, double (&o)[32]) {
+    const ct_lds_double* Lrow = l3 + 16 * s + r16;
+#pragma unroll
+    for (int t = 0; t < s; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) o[4 * t + kk] = Lrow[(16 * t + 4 * kk + kq) * PA];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) o[28 + kk] = l3[DINV_AT + s * 256 + (4 * kk + kq) * 16 + r16];
+  };
+  const int smax = (g.nvalid + 15) / 16;  // (identity-padding sub-blocks of a ragged last block: see trsm_strip_solve_store_pf)
+  load_step(0, ops[0]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s >= smax) break;
+    if (s < 7) load_step(s + 1, ops[(s + 1) & 1]);
+    const double(&o)[32] = ops[s & 1];
+    const bool live = 16 * s + r16 < g.nvalid;
+    d4 y = X[s];
+#pragma unroll
+    for (int t = 0; t < s; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) y = __builtin_amdgcn_mfma_f64_16x16x4f64(live ? -o[4 * t + kk] : 0.0, X[t][kk], y, 0, 0, 0);
+    d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(o[28 + kk], y[kk], x, 0, 0, 0);
+    X[s] = x;
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (WT) __hip_atomic_store(&Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb], X[s][q], CT_RLX_AGENT);
+      else Bp[(int64_t)(16 * s + kq + 4 * q) * g.ldb] = X[s][q];
+    }
+  __syncthreads();  // the image is the next contraction's ring: nobody may still be reading it when that starts
+}
+
 // Off-diagonal tile (I, J): contraction, strip solve against L(J, J), publication.  The slab's own data is requested
 // BEFORE the wait for the diagonal block (it does not depend on it); the solved slab is stored write-through.
 template <int NW>
@@ -535,7 +646,15 @@ __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_doub
   const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, logdet, info, flags, half, ctl, dbg, nullptr, prog);
   int* s_i = (int*)s3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (J > 0 && !ct_ksum<NW>(g, I, J, (double*)l3, s_i, false)) return false;
+  // the last block row of the bordered matrix holds N + 1 - 128 I real rows (the y row is its last): contract those only
+  const int64_t rv = g.N + 1 - (int64_t)I * TILE;
+  const int nrow16 = rv >= TILE ? 8 : (int)((rv + 15) / 16);
+  if (J > 0) {
+    bool ok;
+    if (NW == 8 && CT_RAGGED && nrow16 < 8) ok = ct_ksum<NW, false, true>(g, I, J, (double*)l3, s_i, false, nrow16, 8);
+    else ok = ct_ksum<NW>(g, I, J, (double*)l3, s_i, false);
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) return false;
+  }
   if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
   TrsmArgs ta;
   ta.B = g.A + (int64_t)I * TILE + (int64_t)J * TILE * g.ld;
@@ -568,8 +687,12 @@ __device__ __noinline__ bool ct_offdiag_task(const CholTilesArgs g_in, ct_g_doub
     if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
     if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
     if (near_chain) __builtin_amdgcn_s_setprio(3);
-    trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
-    if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+    if constexpr (NW == 8 && CT_STRIP_LDS) {
+      ct_strip_solve_lds<true>(ta, 16 * wave, X0, l3);
+    } else {
+      trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+      if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+    }
   }
   __builtin_amdgcn_s_setprio(0);
   ct_publish(g, I, J, t, wave);
@@ -584,7 +707,15 @@ __device__ __noinline__ bool ct_trsm_task(const CholTilesArgs g_in, ct_g_double*
                                           ct_lds_int* s3) {
   const CholTilesArgs g = ct_rebuild(g_in, A, dinv16, nullptr, nullptr, flags, nullptr, ctl, dbg, V);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (c > 0 && !ct_ksum<NW, true>(g, r, c, (double*)l3, (int*)s3, false)) return false;
+  // the last block column holds N - 128 c real columns (behind them identity padding, whose results nobody reads): contract those only
+  const int64_t cv = g.N - (int64_t)c * TILE;
+  const int ncol16 = cv >= TILE ? 8 : (int)((cv + 15) / 16);
+  if (c > 0) {
+    bool ok;
+    if (NW == 8 && CT_RAGGED && ncol16 < 8) ok = ct_ksum<NW, true, true>(g, r, c, (double*)l3, (int*)s3, false, 8, ncol16);
+    else ok = ct_ksum<NW, true>(g, r, c, (double*)l3, (int*)s3, false);
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) return false;
+  }
   if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
   TrsmArgs ta;
   ta.B = g.V + (int64_t)r * TILE + (int64_t)c * TILE * g.ldv;
@@ -600,8 +731,12 @@ __device__ __noinline__ bool ct_trsm_task(const CholTilesArgs g_in, ct_g_double*
   strip_d4 X0[8], X1[8];
   trsm_strip_load(ta, 16 * wave, X0);
   if constexpr (NW == 4) trsm_strip_load(ta, 16 * (wave + 4), X1);
-  trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
-  if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  if constexpr (NW == 8 && CT_STRIP_LDS) {
+    ct_strip_solve_lds<true>(ta, 16 * wave, X0, l3);
+  } else {
+    trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+    if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave == 0) {

@@ -203,6 +203,7 @@ struct gmb_engine {
   int64_t cap_ct_trace = 0;
   bool ct_trace = false;
   bool ct_used = false;      // the last factorisation ran on the tile kernel (its abort word has to be read back)
+  bool ct_panels = false;    // ... as panel launches at the bottom of the recursion (chol_tiles_panel)
   bool ct_traced = false;    // ... and left task stamps in dct_trace
   bool tt_used = false;      // the current prediction ran its triangular solve on the tile kernel (same abort word)
   int ct_ntasks = 0;
@@ -249,6 +250,12 @@ struct gmb_engine {
   int64_t cap_apart = 0;
   bool et_fused = false;       // the factorisation in flight carries INV / ZZ tasks: Sigma^-1 (dW) and the alpha parts come with it
   int et_min_blocks = 1;       // smallest matrix (in 128-blocks) whose MAP evaluation runs as the fused launch by default
+  // the bottom of the plain recursion (matrices beyond tiles_max_blocks): panels of <= panel_tiles_w block columns, with every
+  // row below them, are factored by ONE launch of the tile kernel instead of leaf / strip / small-product launches
+  // (chol_tiles_panel).  `panel_tiles_on` is raised by factorize_enqueue around the single-engine recursion
+  // only: the multi-GPU driver's chains run beside a bulk stream whose workgroups a persistent launch would not fit beside.
+  int panel_tiles_w = 8;
+  bool panel_tiles_on = false, panel_tiles_veto = false;
   int tiles_min_blocks = 6, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default (measured faster from N = 768 on)
   int tiles_trsm_min_blocks = 16;                    // ... and the tile triangular solve of the predict path (measured from N = 2560 on)
   int masked_max_blocks = 128;  // GMB_MASKED_MAX_BLOCKS: largest matrix (in 128-blocks) factored with the masked bulk stream
@@ -429,14 +436,14 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
       if (cur_hi >= cur_lo) uni += cur_hi - cur_lo;
       return uni;
     };
-    e->tm.total_gemm_wall_ms += interval_union([](int k) { return k == 0 || k == 7 || k == 2 || k == 3 || k == 4; });
+    e->tm.total_gemm_wall_ms += interval_union([](int k) { return k == 0 || k == 7 || k == 10 || k == 2 || k == 3 || k == 4; });
     e->tm.total_chol_gemm_wall_ms += interval_union([](int k) { return k == 7; });
   }
   for (auto& p : e->evs) {
     float t = 0.f;
     (void)hipEventElapsedTime(&t, p.a, p.b);
     if (trace) fprintf(trace, "%d %d %d %d %d %.5f %.1f\n", p.kind, p.mt, p.nt, p.k, p.flags, t, p.flops / 1e9);
-    if (p.kind == 0 || p.kind == 7 || p.kind == 8 || p.kind == 9 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
+    if (p.kind == 0 || p.kind == 7 || p.kind == 8 || p.kind == 9 || p.kind == 10 || p.kind == 2 || p.kind == 3 || p.kind == 4) {
       e->tm.total_gemm_ms += t;
       e->tm.total_gemm_flops += p.flops;
       e->tm.total_gemm_launches += 1;
@@ -460,6 +467,16 @@ void ev_collect(gmb_engine* e) {  // stream already synchronised
         e->tm.total_eval_tile_launches += 1;
         e->tm.grad_gemm_ms += t;
         e->tm.grad_gemm_flops += p.flops;
+        break;
+      case 10:  // a panel of the recursion's bottom on the tile kernel: in-panel work of the chain, like kind 0
+        e->tm.chol_gemm_ms += t;
+        e->tm.chol_gemm_flops += p.flops;
+        e->tm.chol_gemm_launches += 1;
+        e->tm.total_chol_panel_gemm_ms += t;
+        e->tm.total_chol_panel_gemm_flops += p.flops;
+        e->tm.total_chol_panel_tile_ms += t;
+        e->tm.total_chol_panel_tile_flops += p.flops;
+        e->tm.total_chol_panel_tile_launches += 1;
         break;
       case 0:
       case 7:
@@ -936,8 +953,11 @@ int chol_leaf(gmb_engine* e, int c, int rend) {
                            (int64_t)(rend - c - 1) * TILE, a.A, e->ld, a.dinv16, a.nvalid, 5);
 }
 
+int chol_tiles_panel(gmb_engine* e, int c0, int c1, int rend);
+
 int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
   if (c1 - c0 == 1) return chol_leaf(e, c0, rend);
+  if (e->panel_tiles_on && c1 - c0 <= e->panel_tiles_w) return chol_tiles_panel(e, c0, c1, rend);
   const int mid = c0 + (c1 - c0 + 1) / 2;
   int rc = chol_cols(e, c0, mid, rend);
   if (rc) return rc;
@@ -957,6 +977,27 @@ int chol_cols(gmb_engine* e, int c0, int c1, int rend) {
   rc = launch_gemm(e, g, e->chol_update_kind);
   if (rc) return rc;
   return chol_cols(e, mid, c1, rend);
+}
+
+// The ragged last block of the persistent launches (chol_tiles.hpp: ct_ksum<.., RAG>): the fraction of a tile's contraction that
+// the last block ROW's tasks (rows: the y row included) and the last block COLUMN's solve / inverse tasks still perform
+double ragged_row_frac(const gmb_engine* e) {
+  const int64_t rv = e->N + 1 - (e->Nr - TILE);
+  return rv >= TILE ? 1.0 : (double)((rv + 15) / 16) / 8.0;
+}
+double ragged_col_frac(const gmb_engine* e) {
+  const int64_t cv = e->N - (e->Np - TILE);
+  return cv >= TILE ? 1.0 : (double)((cv + 15) / 16) / 8.0;
+}
+// flops of the tile Cholesky's contractions (2 * 128^3 per k-block of a tile)
+double chol_tiles_flops(const gmb_engine* e, int nct, int nrt) {
+  const double fr = ragged_row_frac(e);
+  double flops = 0.0;
+  for (int j = 1; j < nct; ++j) {
+    const double tiles = nrt - 1 > j ? (double)(nrt - j - 1) + fr : (double)(nrt - j);  // (the diagonal tile is never cut)
+    flops += 2.0 * TILE * TILE * TILE * (double)j * tiles;
+  }
+  return flops;
 }
 
 // ---- persistent tile Cholesky (chol_tiles.hpp): the whole factorisation in one launch --------------------
@@ -997,8 +1038,7 @@ int chol_tiles(gmb_engine* e) {
     HIP_TRY(e, hipMemsetAsync(e->dct_trace, 0, (size_t)ntasks * 4 * sizeof(unsigned long long), e->cur));
     a.dbg = e->dct_trace;
   }
-  double flops = 0.0;
-  for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (double)(nrt - j);
+  const double flops = chol_tiles_flops(e, nct, nrt);
   // eight-wave workgroups, one per compute unit: every phase of the latency chain has the whole compute unit (N = 10k:
   // 6.8 ms against 8.7 ms with four-wave workgroups, two per compute unit -- which stay available to the tuning build)
   int nw = 8;
@@ -1016,6 +1056,51 @@ int chol_tiles(gmb_engine* e) {
   HIP_TRY(e, hipGetLastError());
   e->ct_used = true;
   e->ct_ntasks = ntasks;
+  return GMB_OK;
+}
+
+// Block columns [c0, c1) of the factor with every row below them down to block row `rend`, updated by everything left of
+// c0 already: ONE launch of the tile kernel on that panel (left-looking tile tasks inside it; the rows below the square ride
+// along as in the whole-matrix form).  Replaces, per panel of 8 block columns at C3, 8 leaf + 8 strip + 7 small-product launches
+// (the 64 x 64-tile products that run at 45 TF/s: profiles/r05_bench_c3_kernel_stats.csv).  The control block is the tile
+// Cholesky's; its ABORT word is not cleared between the panels of one factorisation (factorize_enqueue clears it once), so a
+// panel that gave up waiting makes every later one drain and the host sees it at the end.
+int chol_tiles_panel(gmb_engine* e, int c0, int c1, int rend) {
+  const int nct = c1 - c0, nrt = rend - c0;
+  const int ntasks = ct_task_count(nct, nrt);
+  const int64_t words = 4 + (int64_t)nrt * nct + 3 * (int64_t)nct;
+  int rc;
+  if ((rc = ensure(e, &e->dct, &e->cap_ct, std::max<int64_t>(words, 4 + (int64_t)(e->panel_tiles_w + 3) * (e->Nr / TILE))))) return rc;  // (one size for every panel of the matrix)
+  HIP_TRY(e, hipMemsetAsync(e->dct, 0, sizeof(uint32_t), e->cur));                                       // the ticket counter
+  HIP_TRY(e, hipMemsetAsync(e->dct + 2, 0, (size_t)(words - 2) * sizeof(uint32_t), e->cur));            // flags and chain words
+  CholTilesArgs a{};
+  a.A = e->dA + (int64_t)c0 * TILE * (e->ld + 1);
+  a.ld = e->ld;
+  a.nct = nct;
+  a.nrt = nrt;
+  a.N = e->N - (int64_t)c0 * TILE;
+  a.row_base = (int64_t)c0 * TILE;
+  a.dinv16 = e->dDinv16 + (int64_t)c0 * 8 * 256;
+  a.logdet = e->dscal;
+  a.info = e->dinfo;
+  a.ctl = e->dct;
+  a.flags = e->dct + 4;
+  a.half = e->dct + 4 + (int64_t)nrt * nct;
+  a.prog = a.half + 2 * (int64_t)nct;
+  a.ntasks = ntasks;
+  a.timeout_us = 4000000u;
+  a.dbg = nullptr;
+  // flops of the panel's contractions (the last block row of the bordered matrix contracts its real rows only)
+  const double fr = rend == (int)(e->Nr / TILE) ? ragged_row_frac(e) : 1.0;
+  double flops = 0.0;
+  for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (nrt - 1 > j ? (double)(nrt - j - 1) + fr : (double)(nrt - j));
+  const int grid = (int)std::min<long long>(ntasks, e->wg_slots / 2);
+  ev_begin(e, 10, flops, nct, nrt, nct * TILE, 0);
+  hipLaunchKernelGGL(chol_tiles_kernel<8>, dim3(grid), dim3(512), 0, e->cur, a);
+  ev_end(e);
+  HIP_TRY(e, hipGetLastError());
+  e->ct_used = true;  // (the abort word is read back with the factorisation's scalars)
+  e->ct_panels = true;
   return GMB_OK;
 }
 
@@ -1043,7 +1128,8 @@ int trsm_tiles(gmb_engine* e, double* V, int64_t ldv, int ntm, int ev_kind) {
   a.ldv = ldv;
   a.ntm = ntm;
   double flops = 0.0;
-  for (int c = 0; c < nct; ++c) flops += (double)ntm * (2.0 * TILE * TILE * TILE * c + (double)TILE * TILE * TILE);
+  for (int c = 0; c < nct; ++c)
+    flops += (double)ntm * (2.0 * TILE * TILE * TILE * c * (c == nct - 1 ? ragged_col_frac(e) : 1.0) + (double)TILE * TILE * TILE);
   const int grid = (int)std::min<long long>(ntasks, e->wg_slots / 2);
   ev_begin(e, ev_kind, flops, nct, ntm, (int)e->Np, 0);
   hipLaunchKernelGGL(trsm_tiles_kernel<8>, dim3(grid), dim3(512), 0, e->cur, a);
@@ -1150,10 +1236,9 @@ int eval_tiles(gmb_engine* e, bool with_chol) {
   x.vpart = e->dApart + (int64_t)nct * nct * TILE;
   x.scal = e->dscal + 1;
   x.with_v = with_chol ? 1 : 0;  // v = L^-1 y with |v|^2, which gmb_factorize takes with extract_v_kernel
-  double flops = 0.0;
-  if (with_chol)
-    for (int j = 1; j < nct; ++j) flops += 2.0 * TILE * TILE * TILE * (double)j * (double)(nrt - j);
-  for (int c = 0; c < nct; ++c) flops += 2.0 * TILE * TILE * TILE * 0.5 * (double)c * (double)(c + 1);              // INV column c
+  double flops = with_chol ? chol_tiles_flops(e, nct, nrt) : 0.0;
+  for (int c = 0; c < nct; ++c)                                                                                       // INV column c
+    flops += 2.0 * TILE * TILE * TILE * 0.5 * (double)c * (double)(c + 1) * (c == nct - 1 ? ragged_col_frac(e) : 1.0);
   for (int I = 0; I < nct; ++I) flops += 2.0 * TILE * TILE * TILE * (double)(nct - I) * (double)(I + 1);             // ZZ block row I
   const int grid = (int)std::min<long long>(ntasks, nw == 8 ? e->wg_slots / 2 : e->wg_slots);
   ev_begin(e, 9, flops, nct, nrt, (int)e->Np, with_chol ? 1 : 0);
@@ -1964,7 +2049,7 @@ int grad_chain_rule(gmb_engine* e, const std::vector<double>& h, double* grad) {
 }
 
 // -1 = by size (default), 0 = plain recursion, 2 = masked look-ahead streams, 3 = persistent tile kernel
-inline bool chol_scheme_valid(int s) { return s == -1 || s == 0 || s == 2 || s == 3; }
+inline bool chol_scheme_valid(int s) { return s == -1 || s == 0 || s == 2 || s == 3 || s == 4; }
 
 int require_ready(gmb_engine* e, bool need_factor) {
   if (!e) return GMB_EINVAL;
@@ -2051,7 +2136,8 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   };
   // Environment switches of the PRODUCT library: only the ones a test or a documented tools/ A-B uses.
   //   GMB_LEAF_NAIVE=1   the reference diagonal-block kernel (tests/test_gpu_parity.py::test_potrf_leaf_block)
-  //   GMB_CHOL_SCHEME    0 = plain recursion, 2 = masked look-ahead, 3 = persistent tile kernel, for every size
+  //   GMB_CHOL_SCHEME    0 = plain recursion (launches only), 2 = masked look-ahead, 3 = persistent tile kernel, 4 = plain recursion
+  //                      with its bottom panels on the tile kernel (what large matrices take by size), for every size
   //                      (tests/test_gpu_parity.py::test_cholesky_schedules_agree); default: by size
   //   GMB_TRACE_FILE     per-launch event log while profiling (tools/gpu_timeline_run.py)
   //   GMB_GEMM_DMA=0     the 128 x 128 GEMM with register staging instead of the LDS-DMA ring (tools/gpu_ab_gemm_dma.py)
@@ -2063,7 +2149,7 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   if (cs && cs[0]) {
     const int v = atoi(cs);
     if (chol_scheme_valid(v)) e->chol_scheme = v;
-    else fprintf(stderr, "[gumbi_hip] GMB_CHOL_SCHEME=%s ignored: valid schemes are -1 (by size), 0, 2, 3\n", cs);
+    else fprintf(stderr, "[gumbi_hip] GMB_CHOL_SCHEME=%s ignored: valid schemes are -1 (by size), 0, 2, 3, 4\n", cs);
   }
   int part = 32;  // compute units the masked bulk stream leaves to the panel chain
 #ifdef GMB_TUNING
@@ -2408,7 +2494,22 @@ int factorize_enqueue(gmb_engine* e, bool with_grad = false) {
     if ((rc = eval_tiles(e, true))) return rc;
     e->et_fused = true;
   } else {
-    if ((rc = tiles ? chol_tiles(e) : masked ? chol_lookahead_masked(e) : chol_cols(e, 0, nblocks, (int)(e->Nr / TILE)))) return rc;
+    e->ct_panels = false;
+    if (tiles) {
+      rc = chol_tiles(e);
+    } else if (masked) {
+      rc = chol_lookahead_masked(e);
+    } else {
+      // the plain recursion; its bottom panels as launches of the tile kernel (chol_tiles_panel)
+      e->panel_tiles_on = !e->naive_leaf && !e->panel_tiles_veto && e->panel_tiles_w >= 2 && e->chol_scheme != 0;
+      if (e->panel_tiles_on) {
+        if ((rc = ensure(e, &e->dct, &e->cap_ct, 4 + (int64_t)(e->panel_tiles_w + 3) * (e->Nr / TILE)))) return rc;
+        HIP_TRY(e, hipMemsetAsync(e->dct, 0, 4 * sizeof(uint32_t), e->stream));  // (the abort word: once per factorisation)
+      }
+      rc = chol_cols(e, 0, nblocks, (int)(e->Nr / TILE));
+      e->panel_tiles_on = false;
+    }
+    if (rc) return rc;
     // 3. v = L^-1 y is row N of the factor
     hipLaunchKernelGGL(extract_v_kernel, dim3(EXTRACT_V_BLOCKS), dim3(TILE), 0, e->stream, e->dA, e->ld, e->N, e->dv,
                        e->dscal + 1);
@@ -2476,7 +2577,7 @@ static int factorize_retry_after_abort(gmb_engine* e, int rc) {
   if (rc != GMB_EHIP || !e->ct_used || !e->hl || e->hl->abort == 0 || e->ct_injected) return rc;
   fprintf(stderr, "libgumbi_hip: tile Cholesky abandoned after a time-out; refactorising with the plain recursion\n");
   const int scheme = e->chol_scheme;
-  e->chol_scheme = 0;
+  e->chol_scheme = 0;  // (scheme 0 = launches only: no tile kernel anywhere, the recursion's bottom panels included)
   int rc2 = factorize_enqueue(e);
   if (!rc2) rc2 = factorize_finish(e);
   e->chol_scheme = scheme;
@@ -3004,7 +3105,7 @@ int gmb_debug_assume_factored(gmb_engine* e) {
 
 int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme) {
   if (!e) return GMB_EINVAL;
-  if (!chol_scheme_valid(scheme)) return fail(e, GMB_EINVAL, "Cholesky scheme %d: valid are -1 (by size), 0, 2, 3", scheme);
+  if (!chol_scheme_valid(scheme)) return fail(e, GMB_EINVAL, "Cholesky scheme %d: valid are -1 (by size), 0, 2, 3, 4", scheme);
   const int old = e->chol_scheme;
   e->chol_scheme = scheme;
   return old + 1;  // previous scheme + 1: "by size" (-1) comes back as 0, so no valid answer collides with a (negative) status

@@ -255,10 +255,13 @@ __device__ __forceinline__ bool et_ksum(const CholTilesArgs& g, const EtOperand 
 // fragments in registers), three tiles of DMA are in flight across it (raw s_barrier: __syncthreads() would drain them), a
 // DMA has three tile times (~5 us) to land -- 96 KB in flight per compute unit, what 16 GB/s per compute unit needs at the
 // loaded HBM latency -- and no staging registers or ds_writes are left in the loop.
-template <bool NEG>
+// RAG: only the first ncol16 sixteen-column groups of the tile are contracted (the last block column of U: N - 128 c real
+// columns; the others would multiply the padding rows of L's last block row and are zeroed afterwards anyway) -- the computed
+// elements are the same sums in the same order.
+template <bool NEG, bool RAG = false>
 __device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOperand mop_in, const EtOperand nop_in, const uint32_t* mflags,
                                             const uint32_t* nflags, const int kb_lo_in, const int kb_hi_in, double* __restrict__ out,
-                                            const int64_t ldo, ct_lds_double* l3, int* s_i, const int k_last_in = TILE) {
+                                            const int64_t ldo, ct_lds_double* l3, int* s_i, const int k_last_in = TILE, const int ncol16 = 8) {
   constexpr int WGN = 2, WGM = 4;
   constexpr int WTM = TILE / (16 * WGM), WTN = TILE / (16 * WGN);  // 2 x 4 MFMA tiles per wave
   constexpr int KT = 16, NS = 4;
@@ -357,20 +360,29 @@ __device__ __forceinline__ bool et_ksum_dma(const CholTilesArgs& g, const EtOper
 #pragma unroll
     for (int j = 0; j < WTN; ++j) fb[buf][j] = Bs[wn * (16 * WTN) + j * 16];
   };
+  const int ni = RAG ? max(0, min(WTM, et_uni(ncol16) - wm * WTM)) : WTM;  // live MFMA tile columns of this wave
   auto mfmas = [&](const int buf) {
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < WTN; ++j) {
+        if constexpr (RAG) {
+          if (i < ni) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);  // (wave-uniform)
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+        }
+      }
   };
   // one step's issue order: the next step's three fragment reads go out behind the first MFMAs of this one
   auto pin_step = [&]() {
+    if constexpr (!RAG) {  // (the ragged form's MFMAs sit behind scalar branches: nothing to pin)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      for (int q = 0; q < 3; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, WTM * WTN - 3, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, WTM * WTN - 3, 0);
   };
 
   // (k_last < 128: only the first k_last values of the contraction's LAST k-block are non-zero -- the tiles behind them are skipped)
@@ -623,7 +635,14 @@ __device__ __noinline__ bool et_inv_task(const CholTilesArgs g_in, ct_g_double* 
   if (c > r) {
     const EtOperand mop{g.A + (int64_t)c * TILE, g.ld, nullptr, -1};                       // block row c of L
     const EtOperand nop{g.A + (int64_t)r * TILE, g.ld, ud + (int64_t)r * TILE * TILE, r};  // block row r of U
-    if (!et_contract<NW, true>(g, mop, nop, g.flags + (int64_t)c * g.nct, uf + (int64_t)r * g.nct, r, c, ta.B, ta.ldb, l3, s_i)) return false;
+    // (the last block column: N - 128 c real columns of the tile, the rest is padding that is zeroed below)
+    const int ncol16 = ta.nvalid >= TILE ? 8 : (ta.nvalid + 15) / 16;
+    bool ok;
+    if (NW == 8 && ET_DMA && CT_RAGGED && ncol16 < 8)
+      ok = et_ksum_dma<true, true>(g, mop, nop, g.flags + (int64_t)c * g.nct, uf + (int64_t)r * g.nct, r, c, ta.B, ta.ldb, l3, s_i, TILE, ncol16);
+    else
+      ok = et_contract<NW, true>(g, mop, nop, g.flags + (int64_t)c * g.nct, uf + (int64_t)r * g.nct, r, c, ta.B, ta.ldb, l3, s_i);
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) return false;
     if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 1] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own epilogue stores are read back by other lanes
     __syncthreads();
@@ -644,8 +663,12 @@ __device__ __noinline__ bool et_inv_task(const CholTilesArgs g_in, ct_g_double* 
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(s_i[1]) < 0) return false;
   if (g.dbg && wave == 0) g.dbg[4 * (int64_t)t + 2] = wall_clock64();
-  trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
-  if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  if constexpr (NW == 8 && CT_STRIP_LDS) {
+    ct_strip_solve_lds<true>(ta, 16 * wave, X0, l3);
+  } else {
+    trsm_strip_solve_store_pf<true>(ta, 16 * wave, X0);
+    if constexpr (NW == 4) trsm_strip_solve_store_pf<true>(ta, 16 * (wave + 4), X1);
+  }
   if (ta.nvalid < TILE) {
     // last block column of a ragged matrix: columns >= nvalid went through the solve as identity padding and carry the y row's
     // products -- Sigma^-1 = U U^T must not see them

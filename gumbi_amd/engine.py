@@ -107,6 +107,9 @@ class Timings(C.Structure):
         ("total_chol_update_all_flops", C.c_double),
         ("total_chol_update_all_launches", C.c_int64),
         ("predict_gemm_form", C.c_int64),
+        ("total_chol_panel_tile_ms", C.c_double),
+        ("total_chol_panel_tile_flops", C.c_double),
+        ("total_chol_panel_tile_launches", C.c_int64),
     ]
 
     def as_dict(self):
@@ -504,7 +507,7 @@ class Engine:
         return t.as_dict()
 
     #: schedules of the Cholesky (``set_chol_scheme``): by size / plain recursion / masked look-ahead / persistent tile kernel
-    CHOL_BY_SIZE, CHOL_RECURSION, CHOL_LOOKAHEAD, CHOL_TILES = -1, 0, 2, 3
+    CHOL_BY_SIZE, CHOL_RECURSION, CHOL_LOOKAHEAD, CHOL_TILES, CHOL_RECURSION_TILE_PANELS = -1, 0, 2, 3, 4
 
     def set_chol_scheme(self, scheme: int) -> int:
         """Schedule of the following factorisations; returns the previous setting."""

@@ -173,6 +173,11 @@ typedef struct gmb_timings { /* milliseconds on the engine's HIP stream (hipEven
   /* (ABI 10) 1 when the last gmb_predict formed A^T = K(X*, X) L^-T as one GEMM against the inverse factor the fit's last
      gradient evaluation left behind (csrc/predict_form.hpp), 0 when it solved against L (gmb_set_predict_form) */
   int64_t predict_gemm_form;
+  /* (ABI 10) the bottom panels of the large matrices' recursion as launches of the tile kernel (csrc/engine.hip:
+     chol_tiles_panel): durations, contraction flops, launches -- a subset of total_chol_panel_gemm_* */
+  double total_chol_panel_tile_ms;
+  double total_chol_panel_tile_flops;
+  int64_t total_chol_panel_tile_launches;
 } gmb_timings;
 
 typedef struct gmb_engine gmb_engine;
@@ -314,9 +319,12 @@ int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n);
  * transport (garbage numbers, the real launch and collective pattern) and ended with GMB_ENOTPD.  Their results are garbage
  * too.  GMB_EINVAL when no factorisation was attempted since the last gmb_set_theta. */
 int gmb_debug_assume_factored(gmb_engine* e);
-/* Schedule of the Cholesky for the following factorisations: -1 = by size (default), 0 = plain recursion, 2 = masked
- * look-ahead, 3 = persistent tile kernel.  Returns the previous setting PLUS ONE (0 = by size, 1 = recursion, 3, 4), so
- * that no valid answer collides with a negative gmb_status. */
+/* Schedule of the Cholesky for the following factorisations: -1 = by size (default), 0 = plain recursion, launches only,
+ * 2 = masked look-ahead, 3 = persistent tile kernel, 4 = plain recursion whose bottom panels (<= 8 block columns with every
+ * row below them) are single launches of the tile kernel -- what matrices beyond the tile kernel's range (224 block columns)
+ * take by size since ABI 10.  Returns the previous setting PLUS ONE (0 = by size, 1 = recursion, 3, 4, 5), so that no valid
+ * answer collides with a negative gmb_status.
+ * (gmb_debug_assume_factored, ABI 10: GMB_EINVAL unless GUMBI_HIP_DEBUG_DOORS=1 is set in the environment.) */
 int gmb_set_chol_scheme(gmb_engine* e, int32_t scheme);
 /* Schedule of the gradient's inverse and Sigma^-1 for the following evaluations: -1 = by size (default: tile tasks for the
  * matrices the tile Cholesky factors, fused into the factorisation's launch by gmb_evaluate), 0 = the launch tree (recursive

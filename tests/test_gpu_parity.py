@@ -371,6 +371,37 @@ def test_predict_gemm_form_ragged_sizes(gpu, N, M):
     eng.close()
 
 
+@pytest.mark.parametrize("nv", [1, 15, 16, 17, 47, 100, 127, 128])
+def test_ragged_last_block_extents(gpu, nv):
+    """The persistent launches contract only the real part of the ragged last block (sixteen-row groups of
+    the last block ROW -- the y row included -- and sixteen-column groups of the last block COLUMN of the inverse and of the
+    predict solve): every extent class against the oracle, through gmb_factorize + gmb_predict (tile Cholesky, tile solve),
+    gmb_evaluate (fused launch) and the GEMM-form prediction behind it; nv = 128: the y row alone is the last block row."""
+    N, d, M = 128 * 7 + nv, 3, 4200  # (33 row tiles of test points: the tile triangular solve)
+    X, y, ls = O.synthetic_table(N, d, seed=100 + nv)
+    spec = O.make_spec(d, range(d), kind="Matern32")
+    theta = O.pack_theta(spec, ls, 1.2, 0.3)
+    Xs = np.random.default_rng(nv).standard_normal((M, d))
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+    val_r, grad_r = O.nlml_and_grad(spec, theta, X, y)
+    eng = make_engine(spec, theta, X, y)
+    eng.factorize()
+    assert abs(eng.nlml() - val_r) < 1e-10 * abs(val_r)
+    mu, var = eng.predict(Xs)
+    assert eng.timings()["predict_gemm_form"] == 0
+    assert rel(mu, mu_r) < 1e-10 and np.max(np.abs(var - var_r)) < 1e-11
+    L = eng.copy_factor(0, N, 0, N)
+    S = O.sigma_matrix(spec, theta, X)
+    assert np.max(np.abs(np.tril(L) @ np.tril(L).T - S)) < 1e-11 * np.max(np.abs(S))
+    val, grad = eng.evaluate(theta)
+    assert abs(val - val_r) < 1e-10 * abs(val_r) and rel(grad, grad_r) < 1e-8
+    assert rel(eng.copy_alpha(), np.linalg.solve(S, y)) < 1e-8
+    mu2, var2 = eng.predict(Xs)
+    assert eng.timings()["predict_gemm_form"] == 1
+    assert rel(mu2, mu_r) < 1e-10 and np.max(np.abs(var2 - var_r)) < 1e-11
+    eng.close()
+
+
 def test_predict_edge_cases(gpu):
     X, y, ls = O.synthetic_table(200, 3, seed=5)
     spec = O.make_spec(3, range(3))
@@ -648,7 +679,7 @@ def test_cholesky_schedules_agree(gpu, N):
     theta = O.pack_theta(spec, ls, 0.9, 0.2)
     got = {}
     try:
-        for scheme in ("0", "2", "3"):
+        for scheme in ("0", "2", "3", "4"):  # (4: the recursion with its bottom panels on the tile kernel)
             os.environ["GMB_CHOL_SCHEME"] = scheme
             eng = make_engine(spec, theta, X, y)
             eng.factorize()
@@ -661,6 +692,39 @@ def test_cholesky_schedules_agree(gpu, N):
         assert rel(got[scheme][0], L_ref) < 1e-10 and rel(got[scheme][1], v_ref) < 1e-10
     assert rel(got["0"][0], got["2"][0]) < 1e-12 and abs(got["0"][2] - got["2"][2]) < 1e-9 * abs(got["2"][2])
     assert rel(got["0"][0], got["3"][0]) < 1e-12 and abs(got["0"][2] - got["3"][2]) < 1e-9 * abs(got["3"][2])
+    assert rel(got["0"][0], got["4"][0]) < 1e-12 and abs(got["0"][2] - got["4"][2]) < 1e-9 * abs(got["4"][2])
+
+
+@pytest.mark.parametrize("N", [300, 1153, 2304, 2321, 4100])
+def test_recursion_with_tile_panels_matches_oracle(gpu, N):
+    """The large matrices' schedule (plain recursion; panels of <= 8 block columns with every row below them as ONE launch of
+    the tile kernel each, csrc/engine.hip: chol_tiles_panel -- VERDICT r05 item 7), forced at sizes the oracle factors in
+    seconds: factor, v, NLML, gradient and predictions against the oracle; ragged sizes, N % 128 == 0 (the y row alone is the
+    last block row), fewer block columns than one panel; twice = the same bits (the failing row of a matrix that is not
+    positive definite: test_tile_cholesky_reports_the_first_bad_pivot_like_the_recursion)."""
+    d = 3
+    X, y, ls = O.synthetic_table(N, d, seed=31)
+    spec = O.make_spec(d, range(d), kind="Matern52")
+    theta = O.pack_theta(spec, ls, 1.1, 0.25)
+    eng = make_engine(spec, theta, X, y)
+    assert eng.set_chol_scheme(eng.CHOL_RECURSION_TILE_PANELS) == eng.CHOL_BY_SIZE
+    eng.set_profiling(True)
+    eng.factorize()
+    tm = eng.timings()
+    assert tm["total_chol_panel_tile_launches"] >= 1 and tm["total_chol_tile_launches"] == 0
+    L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
+    L = np.tril(eng.copy_factor())
+    assert rel(L, L_ref) < 1e-10 and rel(eng.copy_v(), v_ref) < 1e-10
+    val_r, grad_r = O.nlml_and_grad(spec, theta, X, y)
+    val, grad = eng.nlml(grad=True)
+    assert abs(val - val_r) < 1e-10 * abs(val_r) and rel(grad, grad_r) < 1e-8
+    Xs = np.random.default_rng(N).standard_normal((300, d))
+    mu, var = eng.predict(Xs)
+    mu_r, var_r = O.predict(spec, theta, X, y, Xs, dist_mode="direct")
+    assert rel(mu, mu_r) < 1e-10 and np.max(np.abs(var - var_r)) < 1e-11
+    eng.factorize()
+    assert np.array_equal(np.tril(eng.copy_factor()), L)  # run to run: the same bits
+    eng.close()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -731,7 +795,7 @@ def test_tile_cholesky_reports_the_first_bad_pivot_like_the_recursion(gpu):
     Xbad = X.copy()
     Xbad[777, 0] = np.nan
     rows = {}
-    for scheme in (0, 3):
+    for scheme in (0, 3, 4):  # (4: the recursion's bottom panels on the tile kernel)
         eng = make_engine(spec, theta, Xbad, y)
         eng.set_chol_scheme(scheme)
         with pytest.raises(np.linalg.LinAlgError):
@@ -742,7 +806,7 @@ def test_tile_cholesky_reports_the_first_bad_pivot_like_the_recursion(gpu):
         eng.factorize()
         assert np.isfinite(eng.nlml())
         eng.close()
-    assert rows[0] == rows[3] >= 0
+    assert rows[0] == rows[3] == rows[4] >= 0
 
 
 def test_tile_cholesky_gives_up_on_a_lost_tile_instead_of_hanging(gpu):

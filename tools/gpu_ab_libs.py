@@ -1,5 +1,7 @@
 """Interleaved A/B of two builds of libgumbi_hip.so: ms per gmb_evaluate, gmb_factorize, gmb_predict (10^4 points) and result bits, one process per
-build and round.   python tools/gpu_ab_libs.py LIB_A LIB_B      (AB_SIZES, AB_ROUNDS)"""
+build and round.   python tools/gpu_ab_libs.py LIB_A LIB_B [LIB_C ...]      (AB_SIZES, AB_ROUNDS)
+Builds for an A/B of compile-time switches: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DCT_STRIP_LDS=0 ... gumbi_amd/csrc/engine.hip
+-o gumbi_amd/lib/ab_x.so (tools/build_ab_libs.sh)."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
@@ -27,7 +29,7 @@ for N in [int(v) for v in os.environ.get("AB_SIZES", "2000,5200,10000,20000").sp
           "bits", hashlib.sha1(g.tobytes() + alpha.tobytes() + e.copy_v().tobytes() + mu.tobytes() + var.tobytes()).hexdigest()[:12], flush=True)
     e.close()
 ''' % root
-libs = sys.argv[1:3]
+libs = sys.argv[1:]  # two or more builds
 for _ in range(int(os.environ.get("AB_ROUNDS", "2"))):
     for lib in libs:
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GUMBI_HIP_LIB=os.path.abspath(lib)), capture_output=True, text=True)
