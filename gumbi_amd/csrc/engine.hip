@@ -254,7 +254,10 @@ struct gmb_engine {
   // row below them, are factored by ONE launch of the tile kernel instead of leaf / strip / small-product launches
   // (chol_tiles_panel).  `panel_tiles_on` is raised by factorize_enqueue around the single-engine recursion
   // only: the multi-GPU driver's chains run beside a bulk stream whose workgroups a persistent launch would not fit beside.
-  int panel_tiles_w = 8;
+  // Width by A/B on one box at N = 50k (profiles/r06_panel_tiles_ab.txt): launches only 598 ms; 4: 600, 8: 594.5, 16: 591, 32: 594 --
+  // the panel launch does the in-panel work at the bulk updates' rate (73 TF/s-equivalent, chain included); what it takes away
+  // is the ~500 launch boundaries of the leaves, strips and small products.
+  int panel_tiles_w = 16;
   bool panel_tiles_on = false, panel_tiles_veto = false;
   int tiles_min_blocks = 6, tiles_max_blocks = 224;  // matrices (in 128-blocks) the tile kernel factors by default (measured faster from N = 768 on)
   int tiles_trsm_min_blocks = 16;                    // ... and the tile triangular solve of the predict path (measured from N = 2560 on)
@@ -1061,7 +1064,7 @@ int chol_tiles(gmb_engine* e) {
 
 // Block columns [c0, c1) of the factor with every row below them down to block row `rend`, updated by everything left of
 // c0 already: ONE launch of the tile kernel on that panel (left-looking tile tasks inside it; the rows below the square ride
-// along as in the whole-matrix form).  Replaces, per panel of 8 block columns at C3, 8 leaf + 8 strip + 7 small-product launches
+// along as in the whole-matrix form).  Replaces, per panel of 16 block columns at C3, 16 leaf + 16 strip + 15 product launches
 // (the 64 x 64-tile products that run at 45 TF/s: profiles/r05_bench_c3_kernel_stats.csv).  The control block is the tile
 // Cholesky's; its ABORT word is not cleared between the panels of one factorisation (factorize_enqueue clears it once), so a
 // panel that gave up waiting makes every later one drain and the host sees it at the end.
@@ -2174,6 +2177,7 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   }
   const char* mb = getenv("GMB_MASKED_MAX_BLOCKS");
   if (mb) e->masked_max_blocks = atoi(mb);
+  if (const char* pw = getenv("GMB_PANEL_TILES_W")) e->panel_tiles_w = std::max(0, std::min(64, atoi(pw)));  // (tools/gpu_panel_tiles_ab.py)
   const char* pc = getenv("GMB_PART_CUS");
   if (pc) part = atoi(pc);
 #endif

@@ -320,7 +320,7 @@ int gmb_debug_chol_lose_tickets(gmb_engine* e, int32_t n);
  * too.  GMB_EINVAL when no factorisation was attempted since the last gmb_set_theta. */
 int gmb_debug_assume_factored(gmb_engine* e);
 /* Schedule of the Cholesky for the following factorisations: -1 = by size (default), 0 = plain recursion, launches only,
- * 2 = masked look-ahead, 3 = persistent tile kernel, 4 = plain recursion whose bottom panels (<= 8 block columns with every
+ * 2 = masked look-ahead, 3 = persistent tile kernel, 4 = plain recursion whose bottom panels (<= 16 block columns with every
  * row below them) are single launches of the tile kernel -- what matrices beyond the tile kernel's range (224 block columns)
  * take by size since ABI 10.  Returns the previous setting PLUS ONE (0 = by size, 1 = recursion, 3, 4, 5), so that no valid
  * answer collides with a negative gmb_status.

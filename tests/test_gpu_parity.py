@@ -697,7 +697,7 @@ def test_cholesky_schedules_agree(gpu, N):
 
 @pytest.mark.parametrize("N", [300, 1153, 2304, 2321, 4100])
 def test_recursion_with_tile_panels_matches_oracle(gpu, N):
-    """The large matrices' schedule (plain recursion; panels of <= 8 block columns with every row below them as ONE launch of
+    """The large matrices' schedule (plain recursion; panels of <= 16 block columns with every row below them as ONE launch of
     the tile kernel each, csrc/engine.hip: chol_tiles_panel -- VERDICT r05 item 7), forced at sizes the oracle factors in
     seconds: factor, v, NLML, gradient and predictions against the oracle; ragged sizes, N % 128 == 0 (the y row alone is the
     last block row), fewer block columns than one panel; twice = the same bits (the failing row of a matrix that is not
