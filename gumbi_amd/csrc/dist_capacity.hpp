@@ -69,21 +69,23 @@ int cap_copy2d(gmb_engine* e, hipStream_t st, double* dst, int64_t ldd, const do
 // Everybody's block rows [lo, hi) of the block columns [c0, c1) of L, from the owners' packed rows into `panel` (all ranks
 // take part; a rank in trouble passes ok = false and only issues the collective).
 int cap_gather_panel(gmb_engine* e, const gmb_comm* comm, hipStream_t st, double* panel, int c0, int c1, int lo, int hi, bool ok,
-                     DistProbe* probe) {
+                     DistProbe* probe, double* snd = nullptr, double* rcv = nullptr) {
   const int G = comm->world, rank = comm->rank;
+  if (!snd) snd = e->dsend;  // (the factorisation's TAILs bring a staging pair of their own)
+  if (!rcv) rcv = e->drecv;
   int first, count;
   dist_owned(rank, G, lo, hi, &first, &count);
   const int maxcount = dist_max_owned(G, lo, hi);
   const int64_t W = (int64_t)(c1 - c0) * TILE, ldp = (int64_t)maxcount * TILE, elems = ldp * W;
   int rc = GMB_OK;
   if (ok && count > 0)
-    rc = cap_copy2d(e, st, e->dsend, ldp, e->dAown + (int64_t)cap_packed(first, rank, G) * TILE + (int64_t)c0 * TILE * e->ld_own, e->ld_own,
+    rc = cap_copy2d(e, st, snd, ldp, e->dAown + (int64_t)cap_packed(first, rank, G) * TILE + (int64_t)c0 * TILE * e->ld_own, e->ld_own,
                     (int64_t)count * TILE, W);
-  const int rc2 = dist_all_gather(e, comm, st, e->dsend, e->drecv, elems, probe);
+  const int rc2 = dist_all_gather(e, comm, st, snd, rcv, elems, probe);
   if (rc) return rc;
   if (rc2) return rc2;
   if (!ok) return GMB_OK;
-  return dist_pack(e, st, panel, e->ld, e->drecv, ldp, elems, (int)W, false, G, 0, 0, G, lo, hi, maxcount);
+  return dist_pack(e, st, panel, e->ld, rcv, ldp, elems, (int)W, false, G, 0, 0, G, lo, hi, maxcount);
 }
 
 // staging large enough for every all-gather of the capacity passes at panel width w (block columns)
@@ -111,6 +113,10 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       if (s.op == DIST_SQUARE) wmax = std::max(wmax, s.c1 - s.c0);
     const int cwg = cap_chunk((int)(e->Np / TILE));  // (the gradient pass keeps THREE chunk-wide buffers: allocated here already)
     if (!(rc = cap_ensure(e, G, rank, std::max(2 * wmax, 3 * cwg)))) rc = cap_staging(e, G, std::max(wmax, cwg));
+    int64_t need_tail = 0;  // (the TAILs travel on the communication stream while the next chain uses dsend / drecv)
+    for (const gmb_dist_step& s : plan)
+      if (s.op == DIST_TAIL) need_tail = std::max(need_tail, s.elems);
+    if (!rc && need_tail > 0 && !(rc = ensure(e, &e->dsend2, &e->cap_send2, need_tail))) rc = ensure(e, &e->drecv2, &e->cap_recv2, need_tail * G);
   }
   e->coll_count = e->coll_hash = 0;
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_factorize (set-up)"))) return rc;
@@ -125,13 +131,14 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   tm.chol_leaf_ms = tm.chol_trsm_ms = 0.0;
   tm.chol_gemm_launches = 0;
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
-  hipStream_t mainS = e->stream, bulkS = e->aux[2];
+  hipStream_t mainS = e->stream, bulkS = e->aux[2], commS = e->aux[0];
   e->sync_next = 0;
   e->time_next = 0;
   e->cur = mainS;
   e->chol_update_kind = 0;
   DistDeferred bad;
   DistProbe probe;
+  bool tail_in_flight = false;  // a TAIL has been issued on the communication stream since the last FORK
   {
     hipError_t st = hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream);
     if (st == hipSuccess) st = hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream);
@@ -152,12 +159,18 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   PhaseTimer* tc = nullptr;
   for (const gmb_dist_step& s : plan) {
     const int64_t W = (int64_t)(s.c1 - s.c0) * TILE;
-    const bool has_collective = s.op == DIST_SQUARE || s.op == DIST_PANEL;
+    const bool has_collective = s.op == DIST_SQUARE || s.op == DIST_PANEL || s.op == DIST_TAIL;
     bool gathered = false;
     rc = GMB_OK;
     if (s.op == DIST_SQUARE) {
       ++probe.group;
       ++panel_idx;
+    }
+    // the TAILs' staging pair is free once the previous TAIL has been unpacked; this one leaves once the main stream has solved
+    // the rows (both orders are issued whatever this rank's state)
+    if (s.op == DIST_TAIL) {
+      bad.note(e, order_after(e, commS, mainS));
+      bad.note(e, order_after(e, mainS, commS));
     }
     double* panel = e->dPanel + (int64_t)((s.op == DIST_UPDATE ? panel_of(s.c0) : std::max(panel_idx, 0)) & 1) * panel_elems;
     if (!bad.rc) switch (s.op) {
@@ -202,14 +215,25 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
         }
         break;
       }
-      case DIST_PANEL: {  // my rows below the square: solved in place in dAown, then everybody's into the panel buffer
+      case DIST_SOLVE: {  // my rows below the square: solved in place in dAown, and copied into the panel buffer (U1 reads them there
+                          // before the TAIL has delivered everybody's)
+        if (s.count <= 0) break;
         CapVirtual v(e, panel, s.c0);
         e->cur = mainS;
-        if (s.count > 0 &&
-            (rc = trsm_cols(e, e->dAown + (int64_t)cap_packed(s.first, rank, G) * TILE, e->ld_own, s.count, s.c0, s.c1, 2, 5)))
-          break;
+        if ((rc = trsm_cols(e, e->dAown + (int64_t)cap_packed(s.first, rank, G) * TILE, e->ld_own, s.count, s.c0, s.c1, 2, 5))) break;
+        rc = dist_pack(e, mainS, panel, e->ld, e->dAown + (int64_t)cap_packed(s.first, rank, G) * TILE + (int64_t)s.c0 * TILE * e->ld_own, e->ld_own, 0,
+                       (int)W, false, 0, s.first, s.count, G, 0, 0, s.maxcount);
+        break;
+      }
+      case DIST_PANEL: {  // the head of the panel column: everybody's solved rows [lo, hi) into the panel buffer (main stream)
         gathered = true;
         rc = cap_gather_panel(e, comm, mainS, panel, s.c0, s.c1, s.lo, s.hi, true, &probe);
+        break;
+      }
+      case DIST_TAIL: {  // ... and the rest of it, on the communication stream with a staging pair of its own
+        gathered = true;
+        rc = cap_gather_panel(e, comm, commS, panel, s.c0, s.c1, s.lo, s.hi, true, &probe, e->dsend2, e->drecv2);
+        tail_in_flight = true;
         break;
       }
       case DIST_UPDATE: {  // my rows of the trailing columns [lo, hi) -= (my rows of the panel) (the panel's rows lo .. hi)^T
@@ -236,16 +260,25 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
         e->cur = mainS;
         break;
       }
-      case DIST_FORK: rc = dist_wait(e, mainS, bulkS, &probe, 1); break;
+      case DIST_FORK:  // U2 reads the whole panel column: the chain's part (main stream) and the TAIL (communication stream)
+        rc = dist_wait(e, mainS, bulkS, &probe, 1);
+        if (!rc && tail_in_flight) rc = dist_wait(e, commS, bulkS, &probe, 1);
+        tail_in_flight = false;
+        break;
       case DIST_JOIN: rc = dist_wait(e, bulkS, mainS, &probe, 0); break;
     }
     bad.note(e, rc);
-    if (has_collective && !gathered) bad.note(e, dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems));
-    // v = L^-1 y is row N of the factor: its entries for this panel's columns are complete once the rows below the square
-    // (or, for the last panel, the square itself) are in the panel buffer
-    if (!bad.rc && ((s.op == DIST_PANEL) || (s.op == DIST_SQUARE && s.hi >= nrt))) {
+    if (has_collective && !gathered) {
+      if (s.op == DIST_TAIL) bad.note(e, dist_all_gather(e, comm, commS, e->dsend2, e->drecv2, s.elems));
+      else bad.note(e, dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems));
+    }
+    // v = L^-1 y is row N of the factor: its entries for this panel's columns are complete once the piece of the panel column
+    // that holds the last block row (or, for the last panel, the square itself) is in the panel buffer -- copied on that
+    // piece's stream (the main stream waits for the communication stream before anybody reads v)
+    if (!bad.rc && (((s.op == DIST_PANEL || s.op == DIST_TAIL) && s.hi >= nrt) || (s.op == DIST_SQUARE && s.hi >= nrt))) {
       const hipError_t st = hipMemcpy2DAsync(e->dv + (int64_t)s.c0 * TILE, sizeof(double), panel + e->N, (size_t)e->ld * sizeof(double),
-                                             sizeof(double), (size_t)std::min<int64_t>(W, e->N - (int64_t)s.c0 * TILE), hipMemcpyDeviceToDevice, mainS);
+                                             sizeof(double), (size_t)std::min<int64_t>(W, e->N - (int64_t)s.c0 * TILE), hipMemcpyDeviceToDevice,
+                                             s.op == DIST_TAIL ? commS : mainS);
       if (st != hipSuccess) bad.note(e, fail(e, GMB_EHIP, "hipMemcpy2DAsync failed: %s", hipGetErrorString(st)));
     }
     if (s.op == DIST_KBUILD) {
@@ -253,6 +286,7 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       tc = new PhaseTimer(e);
     }
   }
+  bad.note(e, order_after(e, commS, mainS));  // the last TAIL (the y row travels in it)
   e->cur = mainS;
   double hs[2] = {0.0, 0.0};
   int32_t info = 0;
@@ -286,10 +320,17 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   ev_collect(e);
   tm.dist_world = G;
   tm.dist_chol_collectives = (int64_t)probe.colls.size();
-  tm.dist_chol_comm_bytes = tm.dist_chol_comm_ms = 0.0;
-  for (const DistProbe::Coll& c : probe.colls) {
-    tm.dist_chol_comm_bytes += c.bytes;
-    tm.dist_chol_comm_ms += dist_ms(c.a, c.b);
+  tm.dist_chol_comm_bytes = tm.dist_chol_comm_ms = tm.dist_chol_comm_exposed_ms = 0.0;
+  tm.dist_chol_main_wait_ms = tm.dist_chol_bulk_wait_ms = 0.0;
+  {
+    std::vector<double> chain_comm((size_t)probe.group + 2, 0.0);
+    for (const DistProbe::Coll& c : probe.colls) {
+      const double t = dist_ms(c.a, c.b);
+      tm.dist_chol_comm_bytes += c.bytes;
+      tm.dist_chol_comm_ms += t;
+      if (c.group >= 0) chain_comm[(size_t)c.group] += t;
+    }
+    tm.dist_chol_comm_exposed_ms += dist_exposed_from_probes(probe, chain_comm, &tm.dist_chol_main_wait_ms, &tm.dist_chol_bulk_wait_ms);
   }
   if (info != 0) {
     e->notpd = (int64_t)info - 1;

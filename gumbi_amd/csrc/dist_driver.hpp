@@ -12,23 +12,27 @@
 // communication.  Every rank keeps a FULL-size factor buffer (80 GB at N = 1e5 of 288 GB) and ends with the
 // complete factor, so prediction shards over the test points with no further exchange.
 //
-// Right-looking over panels [c0, c1) of `w` block columns, ONE collective type (all-gather), two per panel:
+// Right-looking over panels [c0, c1) of `w` block columns, ONE collective type (all-gather), three per panel -- two small ones
+// on the chain (SQUARE, PANEL = the head of the panel column), one large one beside it (TAIL; round 6):
 //   SQUARE  the panel's diagonal square is spread over the ranks (block row i belongs to rank i mod G):
 //           all-gather its block rows (w x w blocks, <= a few MB), then EVERY rank factors the square itself
 //           with the single-GPU chain (redundant ~w^3 128^3 / 3 flops, but no broadcast hop, no owner
 //           bottleneck, and log-det / failure index come out identical on all ranks with no reduction);
-//   PANEL   every rank solves ITS block rows below the square against it (packed, trsm_cols) and one
-//           all-gather delivers the finished panel column to all ranks -- the north star's "panel
-//           broadcast": with one sender per block row an all-gather is what drives all 7 xGMI links of
-//           every GPU at once;
+//   SOLVE   every rank solves ITS block rows below the square against it (packed, trsm_cols; no communication);
+//   PANEL   all-gather of the panel column's HEAD: its first w block rows = the rows of the next panel's square, all that
+//           U1, the next SQUARE and the next SOLVE need from the other ranks (main stream: on the chain, but small);
+//   TAIL    all-gather of the rest of the panel column on the COMMUNICATION stream, beside the next chain; only U2 reads it.
+//           PANEL + TAIL are the north star's "panel broadcast": with one sender per block row an all-gather is what drives
+//           all 7 xGMI links of every GPU at once;
 //   UPDATE  the trailing update is purely local: rank g updates its own block rows (strided n index of the
 //           MFMA GEMM) with the panel everybody now holds.
 // Look-ahead: the update by panel p is split into U1 (the columns of panel p+1, main stream) and U2 (the
 // rest, bulk stream = the CU-masked stream when available, so the chain's small kernels and RCCL's
 // workgroups find free compute units); SQUARE / PANEL of p+1 run on the main stream beside U2(p).
 //
-//   main :  SQUARE(0) PANEL(0) | U1(0) SQUARE(1) PANEL(1) | wait U2(0); U1(1) SQUARE(2) PANEL(2) | ...
-//   bulk :                     | U2(0) ........................| U2(1) ..........................| ...
+//   main :  SQUARE(0) SOLVE(0) PANEL(0) | U1(0) SQUARE(1) SOLVE(1) PANEL(1) | wait U2(0); U1(1) SQUARE(2) ... | ...
+//   comm :                               | TAIL(0) ...........              | TAIL(1) ...........              | ...
+//   bulk :                               |         wait TAIL(0); U2(0) ...........| wait TAIL(1); U2(1) ............| ...
 //
 // The schedule is built as a PLAN first (dist_build_plan: host-only, pure integer arithmetic, exported as
 // gmb_dist_plan) and then executed; the CPU tests replay the same plan with numpy blocks over gloo.
@@ -46,7 +50,7 @@
 
 namespace {
 
-enum DistOp : int32_t { DIST_KBUILD = 0, DIST_SQUARE = 1, DIST_PANEL = 2, DIST_UPDATE = 3, DIST_FORK = 4, DIST_JOIN = 5 };
+enum DistOp : int32_t { DIST_KBUILD = 0, DIST_SQUARE = 1, DIST_PANEL = 2, DIST_UPDATE = 3, DIST_FORK = 4, DIST_JOIN = 5, DIST_SOLVE = 6, DIST_TAIL = 7 };
 
 // block rows of [lo, hi) owned by `rank`: first + t * G, t < count
 inline void dist_owned(int rank, int G, int lo, int hi, int* first, int* count) {
@@ -82,13 +86,22 @@ std::vector<gmb_dist_step> dist_build_plan(int64_t N, int rank, int G, int w) {
     dist_owned(rank, G, lo, hi, &s.first, &s.count);
     if (op == DIST_UPDATE) dist_owned(rank, G, lo, nrt, &s.first, &s.count);  // rows run to the end
     s.maxcount = dist_max_owned(G, lo, hi);
-    s.elems = (op == DIST_SQUARE || op == DIST_PANEL) ? (int64_t)s.maxcount * TILE * (int64_t)(c1 - c0) * TILE : 0;
+    s.elems = (op == DIST_SQUARE || op == DIST_PANEL || op == DIST_TAIL) ? (int64_t)s.maxcount * TILE * (int64_t)(c1 - c0) * TILE : 0;
     plan.push_back(s);
   };
   push(DIST_KBUILD, 0, nct, 0, nrt, 0);
+  // The panel column travels in TWO pieces (round 6): PANEL = its first w block rows -- the rows of the next panel's square, all
+  // that U1, the next SQUARE and the next SOLVE need from the other ranks: a small message on the main stream, i.e. on the chain
+  // -- and TAIL = everything below, which only U2 reads: the large message, on the communication stream, beside the next chain.
+  // (Before: one all-gather of the whole column on the chain -- 4.8 of the ~5 ms a chain spends in collectives at N = 100k, G = 8.)
   auto chain = [&](int c0, int c1) {
     push(DIST_SQUARE, c0, c1, c0, c1, 0);
-    if (nrt > c1) push(DIST_PANEL, c0, c1, c1, nrt, 0);
+    if (nrt > c1) {
+      const int head_hi = std::min(c1 + w, nrt);
+      push(DIST_SOLVE, c0, c1, c1, nrt, 0);
+      push(DIST_PANEL, c0, c1, c1, head_hi, 0);
+      if (nrt > head_hi) push(DIST_TAIL, c0, c1, head_hi, nrt, 2);
+    }
   };
   chain(0, std::min(w, nct));
   for (int c0 = 0; c0 < nct; c0 += w) {
@@ -196,6 +209,34 @@ int dist_wait(gmb_engine* e, hipStream_t other, hipStream_t waiter, DistProbe* p
   return order_after(e, other, waiter);
 }
 
+double dist_ms(hipEvent_t a, hipEvent_t b);
+
+// Exposed collective time of a factorisation from its probes: per panel chain, min(what the bulk stream waited at the chain's
+// FORK -- for the main stream and, since round 6, for the communication stream's TAIL --, what the chain's collectives took);
+// chains with no update behind them (a matrix of a single panel) count in full: nothing could hide their collectives.
+double dist_exposed_from_probes(const DistProbe& probe, const std::vector<double>& chain_comm, double* main_wait_ms, double* bulk_wait_ms) {
+  std::vector<double> bulk_wait(chain_comm.size(), 0.0);
+  std::vector<bool> seen(chain_comm.size(), false);
+  for (const DistProbe::Wait& w : probe.waits) {
+    const double t = dist_ms(w.arrive, w.release);
+    if (w.kind == 0) {
+      *main_wait_ms += t;
+    } else if (w.kind == 1) {
+      if (w.group < 0) *bulk_wait_ms += t;
+      if (w.group >= 0) {
+        bulk_wait[(size_t)w.group] = std::max(bulk_wait[(size_t)w.group], t);  // (both waits of a FORK start when the bulk stream arrives)
+        seen[(size_t)w.group] = true;
+      }
+    }
+  }
+  double exposed = 0.0;
+  for (size_t g = 0; g < chain_comm.size(); ++g) {
+    *bulk_wait_ms += bulk_wait[g];
+    exposed += seen[g] ? std::min(bulk_wait[g], chain_comm[g]) : chain_comm[g];
+  }
+  return exposed;
+}
+
 double dist_ms(hipEvent_t a, hipEvent_t b) {
   float t = 0.f;
   if (hipEventElapsedTime(&t, a, b) != hipSuccess) {
@@ -301,9 +342,14 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   if (!rc) rc = ensure_factor_buffer(e);
   if (!rc) {
     plan = dist_build_plan(e->N, rank, G, panel_blocks > 0 ? panel_blocks : (e->panel_auto ? 0 : e->panel_blocks));
-    int64_t need = 0;
-    for (const gmb_dist_step& s : plan) need = std::max(need, s.elems);
+    int64_t need = 0, need_tail = 0;
+    for (const gmb_dist_step& s : plan) {
+      if (s.op == DIST_TAIL) need_tail = std::max(need_tail, s.elems);
+      else need = std::max(need, std::max(s.elems, s.op == DIST_SOLVE ? (int64_t)s.maxcount * TILE * (int64_t)(s.c1 - s.c0) * TILE : 0));
+    }
     if (!(rc = ensure(e, &e->dsend, &e->cap_send, need))) rc = ensure(e, &e->drecv, &e->cap_recv, need * G);
+    // (the TAIL travels on the communication stream while the next chain uses dsend / drecv: a staging pair of its own)
+    if (!rc && need_tail > 0 && !(rc = ensure(e, &e->dsend2, &e->cap_send2, need_tail))) rc = ensure(e, &e->drecv2, &e->cap_recv2, need_tail * G);
   }
   e->coll_count = e->coll_hash = 0;  // the issue log covers this call: its closing agreement compares the ranks' sequences
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_factorize (set-up)"))) return rc;
@@ -316,13 +362,14 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   tm.chol_leaf_ms = tm.chol_trsm_ms = 0.0;
   tm.chol_gemm_launches = 0;
   const int nct = (int)(e->Np / TILE), nrt = (int)(e->Nr / TILE);
-  hipStream_t mainS = e->stream, bulkS = e->aux[2];
+  hipStream_t mainS = e->stream, bulkS = e->aux[2], commS = e->aux[0];
   e->sync_next = 0;
   e->time_next = 0;
   e->cur = mainS;
   e->chol_update_kind = 0;  // chol_cols factors the panels' squares: in-panel products
   DistDeferred bad;
   DistProbe probe;
+  bool tail_in_flight = false;  // a TAIL has been issued on the communication stream since the last FORK
   {
     hipError_t st = hipMemsetAsync(e->dscal, 0, 64 * sizeof(double), e->stream);
     if (st == hipSuccess) st = hipMemsetAsync(e->dinfo, 0, sizeof(int32_t), e->stream);
@@ -332,10 +379,15 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
   PhaseTimer* tc = nullptr;
   for (const gmb_dist_step& s : plan) {
     const int64_t W = (int64_t)(s.c1 - s.c0) * TILE;
-    const bool has_collective = s.op == DIST_SQUARE || s.op == DIST_PANEL;
+    const bool has_collective = s.op == DIST_SQUARE || s.op == DIST_PANEL || s.op == DIST_TAIL;
     bool gathered = false;
     rc = GMB_OK;
     if (s.op == DIST_SQUARE) ++probe.group;
+    if (s.op == DIST_TAIL) {
+      // the staging pair of the TAILs is free once the previous TAIL has been unpacked; this one may leave once the main stream
+      // has solved the rows (both orders are issued whatever this rank's state: the peers' streams do the same)
+      bad.note(e, order_after(e, commS, mainS));
+    }
     if (!bad.rc) switch (s.op) {
       case DIST_KBUILD: {  // this rank's block rows of the lower triangle, y row and padding included
         CovTileArgs a{};
@@ -372,17 +424,31 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
         rc = chol_cols(e, s.c0, s.c1, s.c1);  // the square only: rows below are PANEL's
         break;
       }
-      case DIST_PANEL: {
+      case DIST_SOLVE: {  // my rows below the square, solved in the packed staging buffer and put back: no communication
         double* cols = e->dA + (int64_t)s.c0 * TILE * e->ld;
         const int64_t ldp = (int64_t)s.maxcount * TILE;
+        if (s.count <= 0) break;
         if ((rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, true, 0, s.first, s.count, G, 0, 0, s.maxcount))) break;
         e->cur = mainS;
-        if (s.count > 0 &&
-            (rc = trsm_cols(e, e->dsend - (int64_t)s.c0 * TILE * ldp, ldp, s.count, s.c0, s.c1, 2, 5)))
-          break;
+        if ((rc = trsm_cols(e, e->dsend - (int64_t)s.c0 * TILE * ldp, ldp, s.count, s.c0, s.c1, 2, 5))) break;
+        rc = dist_pack(e, mainS, cols, e->ld, e->dsend, ldp, 0, (int)W, false, 0, s.first, s.count, G, 0, 0, s.maxcount);
+        break;
+      }
+      case DIST_PANEL:   // the head of the panel column (main stream) ...
+      case DIST_TAIL: {  // ... and the rest of it (communication stream, staging of its own): everybody's solved rows [lo, hi)
+        double* cols = e->dA + (int64_t)s.c0 * TILE * e->ld;
+        const int64_t ldp = (int64_t)s.maxcount * TILE;
+        const bool tail = s.op == DIST_TAIL;
+        hipStream_t st = tail ? commS : mainS;
+        double* snd = tail ? e->dsend2 : e->dsend;
+        double* rcv = tail ? e->drecv2 : e->drecv;
+        if ((rc = dist_pack(e, mainS, cols, e->ld, snd, ldp, 0, (int)W, true, 0, s.first, s.count, G, 0, 0, s.maxcount))) break;
+        if (tail && (rc = order_after(e, mainS, commS))) break;
         gathered = true;
-        if ((rc = dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems, &probe))) break;
-        rc = dist_pack(e, mainS, cols, e->ld, e->drecv, ldp, s.elems, (int)W, false, G, 0, 0, G, s.lo, s.hi, s.maxcount);
+        if ((rc = dist_all_gather(e, comm, st, snd, rcv, s.elems, &probe))) break;
+        // (the rank's own rows are rewritten with the values they hold: U1 may be reading them on the main stream meanwhile)
+        rc = dist_pack(e, st, cols, e->ld, rcv, ldp, s.elems, (int)W, false, G, 0, 0, G, s.lo, s.hi, s.maxcount);
+        if (tail) tail_in_flight = true;
         break;
       }
       case DIST_UPDATE: {
@@ -407,17 +473,29 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
         e->cur = mainS;
         break;
       }
-      case DIST_FORK: rc = dist_wait(e, mainS, bulkS, &probe, 1); break;
+      case DIST_FORK:  // U2 reads the whole panel column: the chain's part (main stream) and the TAIL (communication stream)
+        rc = dist_wait(e, mainS, bulkS, &probe, 1);
+        if (!rc && tail_in_flight) rc = dist_wait(e, commS, bulkS, &probe, 1);
+        tail_in_flight = false;
+        break;
       case DIST_JOIN: rc = dist_wait(e, bulkS, mainS, &probe, 0); break;
     }
     bad.note(e, rc);
     // a rank in trouble keeps its place in the collective sequence: its peers are waiting in this all-gather
-    if (has_collective && !gathered) bad.note(e, dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems));
+    if (has_collective && !gathered) {
+      if (s.op == DIST_TAIL) {
+        bad.note(e, order_after(e, mainS, commS));
+        bad.note(e, dist_all_gather(e, comm, commS, e->dsend2, e->drecv2, s.elems));
+      } else {
+        bad.note(e, dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems));
+      }
+    }
     if (s.op == DIST_KBUILD) {
       tk.stop();
       tc = new PhaseTimer(e);
     }
   }
+  bad.note(e, order_after(e, commS, mainS));  // the last TAIL (the y row travels in it)
   e->cur = mainS;
   // v = L^-1 y is row N of the (now complete, replicated) factor
   double hs[2] = {0.0, 0.0};
@@ -467,22 +545,7 @@ int dist_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       tm.dist_chol_comm_ms += t;
       if (c.group >= 0) chain_comm[(size_t)c.group] += t;
     }
-    std::vector<bool> seen(chain_comm.size(), false);
-    for (const DistProbe::Wait& w : probe.waits) {
-      const double t = dist_ms(w.arrive, w.release);
-      if (w.kind == 0) {
-        tm.dist_chol_main_wait_ms += t;
-      } else {
-        tm.dist_chol_bulk_wait_ms += t;
-        if (w.group >= 0) {
-          tm.dist_chol_comm_exposed_ms += std::min(t, chain_comm[(size_t)w.group]);
-          seen[(size_t)w.group] = true;
-        }
-      }
-    }
-    // chains with no update behind them (a matrix of a single panel): nothing could hide their collectives
-    for (size_t g = 0; g < chain_comm.size(); ++g)
-      if (!seen[g]) tm.dist_chol_comm_exposed_ms += chain_comm[g];
+    tm.dist_chol_comm_exposed_ms += dist_exposed_from_probes(probe, chain_comm, &tm.dist_chol_main_wait_ms, &tm.dist_chol_bulk_wait_ms);
   }
   // every rank factored every diagonal square itself: log-det and the failure index are already global and
   // identical on all ranks (same kernels on the same bits) -- no reduction

@@ -273,6 +273,9 @@ struct gmb_engine {
   double* dsend = nullptr;
   double* drecv = nullptr;
   int64_t cap_send = 0, cap_recv = 0;
+  double* dsend2 = nullptr;  // ... and of the panel columns' TAILs, which travel on the communication stream beside the next chain
+  double* drecv2 = nullptr;
+  int64_t cap_send2 = 0, cap_recv2 = 0;
   int panel_blocks = 8;
   bool panel_auto = true;  // panel width grows with the matrix (GMB_PANEL_BLOCKS pins it)
   // every device buffer obtained through ensure / alloc, with its size (gmb_resident_bytes)
@@ -2258,7 +2261,7 @@ void gmb_destroy(gmb_engine* e) {
   void* ptrs[] = {e->dct, e->dct_trace, e->dstat, e->dDiagSave, e->dsend, e->drecv, e->dplan_gemm, e->dplan_tr, e->dDinv16, e->dX, e->dy, e->dA, e->xs, e->xl, e->cat, e->dtabs,
                   e->dnoise, e->dscal, e->dv, e->dV, e->dXs, e->txs, e->txl,
                   e->tcat, e->dkss, e->dpart, e->dmean, e->dvar, e->dW, e->dalpha, e->dgred, e->dgbig, e->det_tasks, e->dUdiag, e->dApart,
-                  e->dAown, e->dPanel, e->dV2};
+                  e->dAown, e->dPanel, e->dV2, e->dsend2, e->drecv2};
   if (e->cap_A == 0) ptrs[11] = nullptr;  // (e->dA may be a virtual base of the capacity driver: nothing of ours to free)
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -208,7 +208,7 @@ class DistStep(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in ("op", "c0", "c1", "lo", "hi", "first", "count", "maxcount", "stream")] + [
         ("elems", C.c_int64)]
-    OPS = ("KBUILD", "SQUARE", "PANEL", "UPDATE", "FORK", "JOIN")
+    OPS = ("KBUILD", "SQUARE", "PANEL", "UPDATE", "FORK", "JOIN", "SOLVE", "TAIL")
 
     def as_dict(self):
         d = {n: int(getattr(self, n)) for n, _ in self._fields_}

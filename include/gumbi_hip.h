@@ -403,10 +403,15 @@ const char* gmb_rccl_last_error(void);
  *   0 KBUILD  covariance tiles of the rank's block rows
  *   1 SQUARE  all-gather the block rows [lo, hi) = [c0, c1) of the panel's diagonal square (`elems` doubles
  *             per rank: maxcount * 128 rows x (c1 - c0) * 128 columns), then factor it locally
- *   2 PANEL   solve the rank's block rows in [lo, hi) = [c1, nrt) of the panel, all-gather them
+ *   6 SOLVE   solve the rank's block rows in [lo, hi) = [c1, nrt) of the panel against the square (no communication)
+ *   2 PANEL   all-gather the HEAD of the solved panel column: block rows [lo, hi) = [c1, min(c1 + w, nrt)) -- the rows of the next
+ *             panel's square, all the chain needs from the other ranks -- on the main stream (`elems` as for SQUARE)
+ *   7 TAIL    all-gather the rest of the panel column, block rows [lo, hi) = [c1 + w, nrt), on the communication stream
+ *             (`stream` = 2) beside the next panel's chain; only the bulk update reads it          (6, 7: since ABI 10)
  *   3 UPDATE  A[rows, lo:hi] -= L[rows, c0:c1] L[lo:hi, c0:c1]^T on the rank's block rows >= lo, on stream
  *             `stream` (0 main, 1 bulk)
- *   4 FORK    the bulk stream waits for everything issued on the main stream so far;  5 JOIN  the reverse
+ *   4 FORK    the bulk stream waits for everything issued on the main stream so far (and for the TAIL issued since the last
+ *             FORK);  5 JOIN  the main stream waits for the bulk stream
  * (first, count): the rank's block rows first, first + world, ... of the step's row range. */
 typedef struct gmb_dist_step {
   int32_t op, c0, c1, lo, hi, first, count, maxcount, stream;

@@ -34,7 +34,7 @@ def test_plan_is_consistent_across_ranks(N, world, w):
     the rows named by SQUARE / PANEL / UPDATE steps partition their ranges; panels tile the columns."""
     plans = [E.dist_plan(N, r, world, w) for r in range(world)]
     nct, nrt = -(-N // BLK), -(-(N + 1) // BLK)
-    coll = [[(s["op"], s["c0"], s["c1"], s["lo"], s["hi"], s["elems"]) for s in p if s["op"] in ("SQUARE", "PANEL")]
+    coll = [[(s["op"], s["c0"], s["c1"], s["lo"], s["hi"], s["elems"], s["stream"]) for s in p if s["op"] in ("SQUARE", "PANEL", "TAIL")]
             for p in plans]
     assert all(c == coll[0] for c in coll)
     assert [len(p) for p in plans] == [len(plans[0])] * world
@@ -45,13 +45,32 @@ def test_plan_is_consistent_across_ranks(N, world, w):
         steps = [p[i] for p in plans]
         assert len({s["op"] for s in steps}) == 1
         op = step0["op"]
-        if op in ("SQUARE", "PANEL", "UPDATE", "KBUILD"):
+        if op in ("SQUARE", "PANEL", "TAIL", "SOLVE", "UPDATE", "KBUILD"):
             hi = nrt if op in ("UPDATE", "KBUILD") else step0["hi"]
             rows = sorted(s["first"] + t * world for s in steps for t in range(s["count"]))
             assert rows == list(range(step0["lo"], hi))
-        if op in ("SQUARE", "PANEL"):
+        if op in ("SQUARE", "PANEL", "TAIL"):
             assert step0["elems"] == step0["maxcount"] * BLK * (step0["c1"] - step0["c0"]) * BLK
             assert step0["maxcount"] == max(s["count"] for s in steps)
+            assert step0["stream"] == (2 if op == "TAIL" else 0)  # the large piece of a panel column travels beside the chain
+        if op == "SOLVE":
+            assert step0["elems"] == 0 and step0["hi"] == nrt  # no communication; every row below the square
+    # a panel column = SOLVE of all rows below the square, then its HEAD (the next square's rows: all the chain needs) and TAIL
+    p0 = plans[0]
+    for i, st in enumerate(p0):
+        if st["op"] == "SOLVE":
+            head = p0[i + 1]
+            assert head["op"] == "PANEL" and (head["c0"], head["c1"], head["lo"]) == (st["c0"], st["c1"], st["lo"])
+            width = max(q["c1"] - q["c0"] for q in p0 if q["op"] == "SQUARE")
+            assert head["hi"] == min(st["lo"] + width, nrt)
+            if head["hi"] < nrt:
+                tail = p0[i + 2]
+                assert tail["op"] == "TAIL" and (tail["lo"], tail["hi"]) == (head["hi"], nrt)
+            else:
+                assert i + 2 >= len(p0) or p0[i + 2]["op"] != "TAIL"
+            # U1 of this panel reads rows [c1, c2) of the column from the other ranks: inside the HEAD
+            u1 = [q for q in p0 if q["op"] == "UPDATE" and (q["c0"], q["c1"]) == (st["c0"], st["c1"]) and q["stream"] == 0]
+            assert all(head["lo"] <= q["lo"] and q["hi"] <= head["hi"] for q in u1)
     # every trailing block (i, j), j <= i, receives the update of every earlier panel exactly once
     ups = [s for s in plans[0] if s["op"] == "UPDATE"]
     for c0, c1 in {(s["c0"], s["c1"]) for s in ups}:
@@ -75,6 +94,7 @@ class NumpyRank:
         self._sigma = np.tril(S)
         self.A = np.full((self.Nr, self.Np), np.nan)  # poison: rows this rank never built / received stay NaN
         self.logdet = 0.0
+        self.pending = []  # TAILs issued and not yet waited for
 
     def rows(self, s):
         return [s["first"] + t * self.G for t in range(s["count"])]
@@ -84,24 +104,36 @@ class NumpyRank:
             ncols = min(i + 1, self.Np // BLK) * BLK
             self.A[i * BLK:(i + 1) * BLK, :ncols] = self._sigma[i * BLK:(i + 1) * BLK, :ncols]
 
-    def _exchange(self, s, dist, torch, solve=None):
+    def _exchange(self, s, dist, torch):
         c0, c1, G = s["c0"] * BLK, s["c1"] * BLK, self.G
         W, mc = c1 - c0, s["maxcount"]
         send = np.zeros((mc, BLK, W))
         for t, i in enumerate(self.rows(s)):
             send[t] = np.nan_to_num(self.A[i * BLK:(i + 1) * BLK, c0:c1])
-        if solve is not None:
-            send[:s["count"]] = solve(send[:s["count"]])
         assert send.size == s["elems"]
         t_in = torch.from_numpy(send.ravel().copy())
         t_out = torch.empty(send.size * G, dtype=torch.float64)
         dist.all_gather_into_tensor(t_out, t_in)
         recv = t_out.numpy().reshape(G, mc, BLK, W)
-        for q in range(G):
-            first, cnt = owned_blocks(q, G, s["lo"], s["hi"])
-            for t in range(cnt):
-                i = first + t * G
-                self.A[i * BLK:(i + 1) * BLK, c0:c1] = recv[q, t]
+
+        def deliver():
+            for q in range(G):
+                first, cnt = owned_blocks(q, G, s["lo"], s["hi"])
+                for t in range(cnt):
+                    i = first + t * G
+                    self.A[i * BLK:(i + 1) * BLK, c0:c1] = recv[q, t]
+
+        # a TAIL travels on the communication stream: nothing of it may be assumed to have arrived before the next FORK (the
+        # bulk stream's wait) -- the replay delivers it only then, so a main-stream step that read it would see the poison
+        if s["op"] == "TAIL":
+            self.pending.append(deliver)
+        else:
+            deliver()
+
+    def fork(self):
+        for deliver in self.pending:
+            deliver()
+        self.pending = []
 
     def square(self, s, dist, torch):
         self._exchange(s, dist, torch)
@@ -114,17 +146,18 @@ class NumpyRank:
             blk[nv:, :nv] = np.linalg.solve(L11, blk[nv:, :nv].T).T
         self.logdet += float(np.sum(np.log(np.diag(L11))))
 
-    def panel(self, s, dist, torch):
+    def solve(self, s):
+        """SOLVE: this rank's rows below the square against it, in place (no communication)."""
         c0, c1 = s["c0"] * BLK, s["c1"] * BLK
         nv = min(c1, self.N) - c0
         L11 = np.tril(self.A[c0:c0 + nv, c0:c0 + nv])
+        for i in self.rows(s):
+            rows = slice(i * BLK, (i + 1) * BLK)
+            self.A[rows, c0:c0 + nv] = np.linalg.solve(L11, self.A[rows, c0:c0 + nv].T).T
 
-        def solve(rows):  # rows: (cnt, 128, W)
-            out = rows.copy()
-            out[:, :, :nv] = np.linalg.solve(L11, rows[:, :, :nv].reshape(-1, nv).T).T.reshape(rows.shape[0], BLK, nv)
-            return out
-
-        self._exchange(s, dist, torch, solve)
+    def panel(self, s, dist, torch):
+        """PANEL (the head of the panel column) and TAIL (the rest): everybody's solved rows [lo, hi)."""
+        self._exchange(s, dist, torch)
 
     def update(self, s):
         c0, c1, lo, hi = s["c0"] * BLK, s["c1"] * BLK, s["lo"], s["hi"]
@@ -171,11 +204,20 @@ class NumpyRankCapacity(NumpyRank):
         dist.all_gather_into_tensor(t_out, torch.from_numpy(send.ravel().copy()))
         recv = t_out.numpy().reshape(G, mc, BLK, W)
         buf = self._panel_of(s["c0"])
-        for q in range(G):
-            first, cnt = owned_blocks(q, G, s["lo"], s["hi"])
-            for t in range(cnt):
-                i = first + t * G
-                buf[i * BLK:(i + 1) * BLK] = recv[q, t]
+
+        def deliver():
+            for q in range(G):
+                first, cnt = owned_blocks(q, G, s["lo"], s["hi"])
+                for t in range(cnt):
+                    i = first + t * G
+                    buf[i * BLK:(i + 1) * BLK] = recv[q, t]
+            if s["hi"] * BLK >= self.Nr:  # the piece that holds the last block row brings the y row
+                self.v[s["c0"] * BLK:s["c1"] * BLK] = buf[self.N]
+
+        if s["op"] == "TAIL":
+            self.pending.append(deliver)
+        else:
+            deliver()
 
     def square(self, s, dist, torch):
         self.npanel += 1
@@ -196,15 +238,17 @@ class NumpyRankCapacity(NumpyRank):
         if s["hi"] * BLK >= self.Nr:
             self.v[c0:c1] = self.pan[k][self.N]
 
-    def panel(self, s, dist, torch):
+    def solve(self, s):
         c0, c1 = s["c0"] * BLK, s["c1"] * BLK
         nv = min(c1, self.N) - c0
         buf = self._panel_of(s["c0"])
         L11 = np.tril(buf[c0:c0 + nv, :nv])
         for i in self.rows(s):
             self.own[i][:, c0:c0 + nv] = np.linalg.solve(L11, self.own[i][:, c0:c0 + nv].T).T
+            buf[i * BLK:(i + 1) * BLK] = self.own[i][:, c0:c1]  # (U1 reads this rank's rows in the panel buffer before the TAIL arrives)
+
+    def panel(self, s, dist, torch):
         self._exchange(s, dist, torch)
-        self.v[c0:c1] = buf[self.N]
 
     def update(self, s):
         c0, c1, lo, hi = s["c0"] * BLK, s["c1"] * BLK, s["lo"], s["hi"]
@@ -236,10 +280,15 @@ def _worker(rank, world, port, N, d, w, out, capacity=False):
                 me.kbuild(s)
             elif s["op"] == "SQUARE":
                 me.square(s, dist, torch)
-            elif s["op"] == "PANEL":
+            elif s["op"] == "SOLVE":
+                me.solve(s)
+            elif s["op"] in ("PANEL", "TAIL"):
                 me.panel(s, dist, torch)
             elif s["op"] == "UPDATE":
                 me.update(s)
+            elif s["op"] == "FORK":
+                me.fork()
+        me.fork()  # (the last TAIL: the driver's closing wait for the communication stream)
         L_ref, v_ref = O.factorize(spec, theta, X, y, dist_mode="direct")
         if capacity:  # every rank holds its own block rows only: collect them (test only) and look at the whole
             rows = [None] * world

@@ -176,11 +176,11 @@ def _oracle_task(rank, world, group, out, N, d, M, model, panel):
     eng.set_theta(theta)
     eng.factorize()
     tm = eng.timings()
-    # communication probes of the factorisation: one all-gather per SQUARE / PANEL step of this rank's plan, the
+    # communication probes of the factorisation: one all-gather per SQUARE / PANEL / TAIL step of this rank's plan, the
     # bytes it received, and an exposed part that cannot exceed the total
     plan = dist_plan(len(y), rank, world, panel)
-    n_coll = sum(1 for st in plan if st["op"] in ("SQUARE", "PANEL"))
-    recv = 8.0 * (world - 1) * sum(st["elems"] for st in plan if st["op"] in ("SQUARE", "PANEL"))
+    n_coll = sum(1 for st in plan if st["op"] in ("SQUARE", "PANEL", "TAIL"))
+    recv = 8.0 * (world - 1) * sum(st["elems"] for st in plan if st["op"] in ("SQUARE", "PANEL", "TAIL"))
     probes_ok = (tm["dist_world"] == world and tm["dist_chol_collectives"] == n_coll and tm["dist_chol_comm_bytes"] == recv
                  and 0.0 < tm["dist_chol_comm_ms"] and 0.0 <= tm["dist_chol_comm_exposed_ms"] <= tm["dist_chol_comm_ms"] * (1 + 1e-9)
                  and tm["dist_chol_main_wait_ms"] >= 0.0 and tm["dist_chol_bulk_wait_ms"] >= 0.0)
