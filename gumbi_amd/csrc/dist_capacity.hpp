@@ -113,10 +113,13 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       if (s.op == DIST_SQUARE) wmax = std::max(wmax, s.c1 - s.c0);
     const int cwg = cap_chunk((int)(e->Np / TILE));  // (the gradient pass keeps THREE chunk-wide buffers: allocated here already)
     if (!(rc = cap_ensure(e, G, rank, std::max(2 * wmax, 3 * cwg)))) rc = cap_staging(e, G, std::max(wmax, cwg));
-    int64_t need_tail = 0;  // (the TAILs travel on the communication stream while the next chain uses dsend / drecv)
+    // The TAILs travel on the communication stream while the next chain gathers its square and the head of its panel column: two
+    // staging pairs.  The full-height pair (dsend / drecv: the gradient and prediction passes need it anyway) serves the TAILs,
+    // a small second pair the chain's two short messages -- capacity mode is about memory.
+    int64_t need_chain = 0;
     for (const gmb_dist_step& s : plan)
-      if (s.op == DIST_TAIL) need_tail = std::max(need_tail, s.elems);
-    if (!rc && need_tail > 0 && !(rc = ensure(e, &e->dsend2, &e->cap_send2, need_tail))) rc = ensure(e, &e->drecv2, &e->cap_recv2, need_tail * G);
+      if (s.op == DIST_SQUARE || s.op == DIST_PANEL) need_chain = std::max(need_chain, s.elems);
+    if (!rc && need_chain > 0 && !(rc = ensure(e, &e->dsend2, &e->cap_send2, need_chain))) rc = ensure(e, &e->drecv2, &e->cap_recv2, need_chain * G);
   }
   e->coll_count = e->coll_hash = 0;
   if ((rc = dist_agree(e, comm, rc, "gmb_dist_factorize (set-up)"))) return rc;
@@ -166,8 +169,8 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       ++probe.group;
       ++panel_idx;
     }
-    // the TAILs' staging pair is free once the previous TAIL has been unpacked; this one leaves once the main stream has solved
-    // the rows (both orders are issued whatever this rank's state)
+    // the TAILs' staging pair (dsend / drecv) is free once the previous TAIL has been unpacked; this one leaves once the main stream
+    // has solved the rows (both orders are issued whatever this rank's state)
     if (s.op == DIST_TAIL) {
       bad.note(e, order_after(e, commS, mainS));
       bad.note(e, order_after(e, mainS, commS));
@@ -201,7 +204,7 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       }
       case DIST_SQUARE: {  // the diagonal square's block rows from their owners, then every rank factors it
         gathered = true;
-        if ((rc = cap_gather_panel(e, comm, mainS, panel, s.c0, s.c1, s.lo, s.hi, true, &probe))) break;
+        if ((rc = cap_gather_panel(e, comm, mainS, panel, s.c0, s.c1, s.lo, s.hi, true, &probe, e->dsend2, e->drecv2))) break;
         CapVirtual v(e, panel, s.c0);
         e->cur = mainS;
         rc = chol_cols(e, s.c0, s.c1, s.c1);
@@ -227,12 +230,12 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
       }
       case DIST_PANEL: {  // the head of the panel column: everybody's solved rows [lo, hi) into the panel buffer (main stream)
         gathered = true;
-        rc = cap_gather_panel(e, comm, mainS, panel, s.c0, s.c1, s.lo, s.hi, true, &probe);
+        rc = cap_gather_panel(e, comm, mainS, panel, s.c0, s.c1, s.lo, s.hi, true, &probe, e->dsend2, e->drecv2);
         break;
       }
-      case DIST_TAIL: {  // ... and the rest of it, on the communication stream with a staging pair of its own
+      case DIST_TAIL: {  // ... and the rest of it, on the communication stream through the full-height staging pair
         gathered = true;
-        rc = cap_gather_panel(e, comm, commS, panel, s.c0, s.c1, s.lo, s.hi, true, &probe, e->dsend2, e->drecv2);
+        rc = cap_gather_panel(e, comm, commS, panel, s.c0, s.c1, s.lo, s.hi, true, &probe);
         tail_in_flight = true;
         break;
       }
@@ -269,8 +272,8 @@ int cap_factorize(gmb_engine* e, const gmb_comm* comm, int panel_blocks) {
     }
     bad.note(e, rc);
     if (has_collective && !gathered) {
-      if (s.op == DIST_TAIL) bad.note(e, dist_all_gather(e, comm, commS, e->dsend2, e->drecv2, s.elems));
-      else bad.note(e, dist_all_gather(e, comm, mainS, e->dsend, e->drecv, s.elems));
+      if (s.op == DIST_TAIL) bad.note(e, dist_all_gather(e, comm, commS, e->dsend, e->drecv, s.elems));
+      else bad.note(e, dist_all_gather(e, comm, mainS, e->dsend2, e->drecv2, s.elems));
     }
     // v = L^-1 y is row N of the factor: its entries for this panel's columns are complete once the piece of the panel column
     // that holds the last block row (or, for the last panel, the square itself) is in the panel buffer -- copied on that
