@@ -315,3 +315,53 @@ def test_c4_host_baseline_counts_the_gpu_lines_flops():
     n = int(r["sample"].split("at N=")[1].split(" ")[0])
     assert abs(r["value"] - bench.c4_step_flops(n, 2, 2 * 64, 1, 0) / r["seconds"] / 1e9) / r["value"] < 0.02
     assert r["executed_stacked_system_gflops"] > 2.0 * r["value"] and "SAME algorithmic flops" in r["note"]
+
+
+def test_host_c2_fit_is_capped_and_extrapolated_when_the_budget_is_short(monkeypatch):
+    """VERDICT r05 item 3: under the driver's command the host's whole C2 fit (~3 minutes) does not fit the time budget any more;
+    a fit capped at C2_HOST_CAPPED_EVALS evaluations is measured instead and the whole fit is reported as a labelled extrapolation."""
+    import json
+    import subprocess
+    import types
+
+    bench = load_bench()
+    monkeypatch.setattr(bench, "cpu_baseline", lambda cfg, target_seconds=20.0: {
+        "seconds": 9.8, "evaluation_seconds": 5.9, "predict_seconds": 3.9, "sample": "fake"})
+    calls = []
+
+    def fake_run(cmd, **kw):
+        calls.append(kw["env"]["GUMBI_BENCH_CPU_FIT_MAXEVAL"])
+        n = 6 if kw["env"]["GUMBI_BENCH_CPU_FIT_MAXEVAL"] != "200" else 29
+        return types.SimpleNamespace(returncode=0, stderr="", stdout=json.dumps(
+            {"fit_predict_seconds": 6.0 * n + 4.0, "fit_seconds": 6.0 * n, "predict_seconds": 4.0, "n_eval": n, "nlml_final": 1.0}) + "\n")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "cpu_dpotrf_seconds", lambda N: {"c3_cholesky_seconds": 44.0, "c3_cholesky": {"N": N}})
+
+    class B:
+        def __init__(self, left):
+            self.left = left
+
+        def allows(self, est):
+            return est <= self.left
+
+        def skipped(self, est):
+            return {"skipped": f"needs ~{est:.0f} s"}
+
+    # plenty of time: the whole fit is measured
+    out = bench.cpu_config_size_sections(B(1000.0), {"n_eval": 29})
+    assert calls == ["200"] and out["c2_seconds"] == 6.0 * 29 + 4.0 and "c2_seconds_extrapolated" not in out and out["c3_cholesky_seconds"] == 44.0
+    # ~100 s left: the capped fit, the extrapolation says what it is; no dpotrf of 75 s... the budget object here allows it (est 75 <= 100)
+    calls.clear()
+    out = bench.cpu_config_size_sections(B(100.0), {"n_eval": 29})
+    assert calls == [str(bench.C2_HOST_CAPPED_EVALS)] and out["c2_seconds"] is None and "skipped" in out["c2_fit"]
+    assert abs(out["c2_seconds_extrapolated"] - (6.0 * 29 + 4.0)) < 1e-9 and "EXTRAPOLATION" in out["c2_seconds_extrapolated_note"]
+    assert out["c2_fit_capped"]["n_eval"] == 6 and out["c2_seconds_estimate"] == round(29 * 5.9 + 3.9, 1)
+    # 30 s left: one evaluation only, everything else skipped and saying so
+    calls.clear()
+    out = bench.cpu_config_size_sections(B(30.0), {"n_eval": 29})
+    assert calls == [] and out["c2_seconds"] is None and "skipped" in out["c2_fit"] and out["c3_cholesky_seconds"] is None
+    assert out["c2_one_evaluation_seconds"] == 5.9
+    # nothing left
+    out = bench.cpu_config_size_sections(B(5.0), None)
+    assert out["c2_seconds"] is None and "skipped" in out["c2_fit"] and "c2_one_evaluation_seconds" not in out
