@@ -171,6 +171,7 @@ struct gmb_engine {
   const double* plan_A = nullptr;
   bool batch_inverse = true;
   bool lpt_order = true;
+  long long lpt_max_tiles = 16384;  // launches with more 128 x 128 tiles than this keep the L2-aware strip order (GMB_LPT_MAX_TILES)
   int cov_strip = 0;   // GMB_COV_STRIP: tiles per workgroup of the covariance build (0 = by size)
   int tile_strip = 8;  // GMB_TILE_STRIP: m-tiles per strip of the L2-aware tile order (0 = row-major runs)
 
@@ -590,8 +591,11 @@ int launch_gemm(gmb_engine* e, const GemmArgs& g_in, int ev_kind) {
   g.mt = g_in.mt * TILE / bm;
   g.nt = g_in.nt * TILE / bn;
   // triangular operand: dispatch the longest contractions first (see GemmArgs::order)
+  // ... unless the launch is so large that a late long tile is a per cent of it at worst, and the L2-aware strips below -- which
+  // the longest-first order gives up -- are worth more (round 6, one box, N = 50k: evaluation 1788 -> 1771 ms with the strips for
+  // every product of more than lpt_max_tiles tiles; tools/gpu_grad_order_ab.py)
   g.order = 0;
-  if (e->lpt_order && g.nblk_stride == 1 && g.tri_off >= 0 && !g.klo_m && (g.klo_n != 0) != (g.khi_n != 0))
+  if (e->lpt_order && nact <= e->lpt_max_tiles && g.nblk_stride == 1 && g.tri_off >= 0 && !g.klo_m && (g.klo_n != 0) != (g.khi_n != 0))
     g.order = g.klo_n ? 1 : 2;
   // L2-aware rasterisation of the XCD runs for launches that are several patches large (GemmArgs::strip)
   g.strip = (g.order == 0 && e->tile_strip > 0 && g.mt >= 2 && !in_place && !g.klo_m) ? e->tile_strip : 0;
@@ -2167,6 +2171,7 @@ int gmb_create_impl(gmb_engine** out, int32_t device, void* stream, const gmb_en
   }
   e->lookahead = flag("GMB_LOOKAHEAD", true);
   e->lpt_order = flag("GMB_LPT_ORDER", true);
+  if (const char* lm = getenv("GMB_LPT_MAX_TILES")) e->lpt_max_tiles = atoll(lm);
   const char* ts = getenv("GMB_TILE_STRIP");
   if (ts) e->tile_strip = std::max(0, atoi(ts));
   const char* cst = getenv("GMB_COV_STRIP");
