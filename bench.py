@@ -1081,6 +1081,9 @@ def comm_block(tm, eng, transport, clock):
                                                                   tm["dist_chol_comm_ms"], tm["dist_grad_comm_ms"]])
     return {
         "transport": transport, "rccl_ranks": ranks, "world": int(tm["dist_world"]),
+        # RCCL runs ONE communicator's collectives in issue order whatever their streams: the transport keeps a second one (split off
+        # the first) for the collectives of the communication stream -- None for other transports
+        "rccl_two_communicators": bool(comm.two_communicators) if hasattr(comm, "two_communicators") else None,
         "comm_ms_total": round(tm["dist_chol_comm_ms"] + tm["dist_grad_comm_ms"], 3),
         "comm_ms_exposed": round(tm["dist_chol_comm_exposed_ms"] + tm["dist_grad_comm_exposed_ms"], 3),
         "per": "one factorisation + one gradient evaluation (the last of the run), rank 0; *_max = maximum over the ranks",

@@ -766,6 +766,7 @@ struct RcclApi {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommSplit) CommSplit = nullptr;  // optional (RCCL >= 2.18)
 };
 
 std::string g_rccl_error;
@@ -791,6 +792,7 @@ RcclApi* rccl_api(const char* path) {
   a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
   a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
+  a.CommSplit = (decltype(a.CommSplit))dlsym(lib, "ncclCommSplit");
   if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather) {
     g_rccl_error = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
     return nullptr;
@@ -799,14 +801,30 @@ RcclApi* rccl_api(const char* path) {
   return &api;
 }
 
+// Collectives of ONE communicator are executed in issue order whatever streams they were enqueued on (RCCL serialises a communicator's
+// kernels through a stream of its own): a panel column's TAIL on the communication stream would hold up the next chain's SQUARE and
+// PANEL gathers on the main stream -- the overlap the driver's plan is built for would exist in the emulation only.  The transport
+// therefore keeps TWO communicators over the same ranks (the second split off the first, ncclCommSplit: no second unique id to hand
+// round): the stream of the transport's first collective -- the engine's main stream: every gmb_dist_* call opens with the ranks'
+// agreement on it -- uses the first, every other stream the second.  Each communicator sees the same sequence on every rank (the
+// plan's), so neither can pair the wrong buffers.  Without ncclCommSplit (or if it fails) there is one communicator and the
+// collectives serialise: correct, slower.
 struct RcclCtx {
   RcclApi* api;
   ncclComm_t comm;
+  ncclComm_t comm2 = nullptr;   // collectives issued on any stream but the first one's
+  void* first_stream = nullptr;
+  bool have_first = false;
 };
 
 int32_t rccl_all_gather(void* ctx, const void* send, void* recv, int64_t count, void* stream) {
   RcclCtx* c = (RcclCtx*)ctx;
-  const ncclResult_t r = c->api->AllGather(send, recv, (size_t)count, ncclFloat64, c->comm, (hipStream_t)stream);
+  if (!c->have_first) {
+    c->first_stream = stream;
+    c->have_first = true;
+  }
+  ncclComm_t comm = (stream == c->first_stream || !c->comm2) ? c->comm : c->comm2;
+  const ncclResult_t r = c->api->AllGather(send, recv, (size_t)count, ncclFloat64, comm, (hipStream_t)stream);
   if (r != ncclSuccess) {
     g_rccl_error = std::string("ncclAllGather: ") + (c->api->GetErrorString ? c->api->GetErrorString(r) : "error");
     return (int32_t)r;
@@ -860,13 +878,28 @@ int gmb_rccl_comm_create(gmb_comm** out, const char* librccl_path, const void* i
     g_rccl_error = std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "error");
     return GMB_EHIP;
   }
+  RcclCtx* ctx = new RcclCtx();
+  ctx->api = api;
+  ctx->comm = comm;
+  if (api->CommSplit && !getenv("GUMBI_RCCL_ONE_COMM")) {
+    // (collective over the parent: every rank is here; same colour, rank order kept)
+    ncclComm_t second = nullptr;
+    const ncclResult_t r2 = api->CommSplit(comm, 0, rank, &second, nullptr);
+    if (r2 == ncclSuccess && second) ctx->comm2 = second;
+    else g_rccl_error = std::string("ncclCommSplit failed (") + (api->GetErrorString ? api->GetErrorString(r2) : "error") + "): one communicator, collectives of different streams serialise";
+  }
   gmb_comm* c = new gmb_comm();
   c->rank = rank;
   c->world = world;
-  c->ctx = new RcclCtx{api, comm};
+  c->ctx = ctx;
   c->all_gather = rccl_all_gather;
   *out = c;
   return GMB_OK;
+}
+
+int gmb_rccl_comm_split(const gmb_comm* c) {  // 1: two communicators (collectives of different streams overlap), 0: one
+  if (!c || !c->ctx || c->all_gather != rccl_all_gather) return GMB_EINVAL;
+  return ((const RcclCtx*)c->ctx)->comm2 ? 1 : 0;
 }
 
 int gmb_rccl_comm_ranks(const gmb_comm* c) {
@@ -881,6 +914,7 @@ void gmb_rccl_comm_destroy(gmb_comm* c) {
   if (!c) return;
   RcclCtx* ctx = (RcclCtx*)c->ctx;
   if (ctx) {
+    if (ctx->comm2) (void)ctx->api->CommDestroy(ctx->comm2);
     if (ctx->comm) (void)ctx->api->CommDestroy(ctx->comm);
     delete ctx;
   }

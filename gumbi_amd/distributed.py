@@ -98,6 +98,12 @@ class RcclComm:
         """``ncclCommCount`` of the communicator: the rank count RCCL itself reports."""
         return int(self._lib.gmb_rccl_comm_ranks(self._comm))
 
+    @property
+    def two_communicators(self) -> bool:
+        """True when the transport holds a second communicator (``ncclCommSplit``) for the collectives the driver issues off its main
+        stream -- RCCL runs one communicator's collectives in issue order whatever their streams (``gmb_rccl_comm_split``)."""
+        return int(self._lib.gmb_rccl_comm_split(self._comm)) == 1
+
     def close(self):
         if getattr(self, "_comm", None):
             self._lib.gmb_rccl_comm_destroy(self._comm)

@@ -250,6 +250,7 @@ _SIGNATURES = {
                                        C.c_int32]),
     "gmb_rccl_comm_destroy": (None, [C.POINTER(GmbComm)]),
     "gmb_rccl_comm_ranks": (C.c_int, [C.POINTER(GmbComm)]),
+    "gmb_rccl_comm_split": (C.c_int, [C.POINTER(GmbComm)]),
     "gmb_rccl_last_error": (C.c_char_p, []),
     "gmb_dist_plan": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(DistStep), C.c_int64]),
     "gmb_dist_factorize": (C.c_int, [C.c_void_p, C.POINTER(GmbComm), C.c_int32]),

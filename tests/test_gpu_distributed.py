@@ -674,6 +674,9 @@ def _rccl_worker(out):
         eng = DistributedEngine(0, panel_blocks=2)
         kind = eng.comm.kind
         assert eng.comm.ranks == 1  # ncclCommCount of the library's own communicator
+        # the collectives of the communication stream (a panel column's TAIL, the gradient's chunks) get a communicator of their own,
+        # split off the first: RCCL runs ONE communicator's collectives in issue order whatever their streams
+        assert eng.comm.two_communicators is True
         eng.set_data(X, y)
         eng.set_kernel(KernelSpec(D=d, idx_cont=list(range(d))))
         eng.set_theta(theta)
