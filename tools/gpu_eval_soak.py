@@ -28,5 +28,23 @@ for N, d, kind in cases:
         if i % 7 == 0 and e.copy_alpha().tobytes() != a0.tobytes():
             bad += 1
     print(f"N={N} d={d} {kind}: {n} evaluations in {time.time() - t0:.1f} s, {bad} differing results", flush=True)
+    # the other two persistent launches (tile Cholesky alone, tile solve of a prediction with no fit before it) and the GEMM-form
+    # prediction behind an evaluation: the same bits every time
+    Xs = np.random.default_rng(N).standard_normal((4200, d))
+    e.factorize()
+    mu0, var0 = e.predict(Xs)
+    L0 = e.copy_factor(max(0, N - 300), min(300, N), 0, min(300, N)).tobytes()
+    e.evaluate(theta)
+    mug0, varg0 = e.predict(Xs)
+    bad2, m = 0, max(5, n // 6)
+    for i in range(m):
+        e.factorize()
+        mu, var = e.predict(Xs)
+        bad2 += int(mu.tobytes() != mu0.tobytes() or var.tobytes() != var0.tobytes() or e.copy_factor(max(0, N - 300), min(300, N), 0, min(300, N)).tobytes() != L0)
+        e.evaluate(theta)
+        mug, varg = e.predict(Xs)
+        bad2 += int(mug.tobytes() != mug0.tobytes() or varg.tobytes() != varg0.tobytes())
+    print(f"    factorize + predict (solve form) and evaluate + predict (GEMM form): {m} rounds, {bad2} differing results; forms agree to "
+          f"{np.max(np.abs(mug0 - mu0)) / np.max(np.abs(mu0)):.1e} (mean) / {np.max(np.abs(varg0 - var0)):.1e} (variance)", flush=True)
     e.close()
 print(f"soak done in {time.time() - t_all:.0f} s")
