@@ -244,6 +244,8 @@ struct PrepArgs {
   int64_t zero_words[2];
 };
 
+__device__ __forceinline__ void prep_one_point(const PrepArgs& a, const int64_t i);
+
 __global__ void prep_points_kernel(PrepArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
@@ -251,6 +253,11 @@ __global__ void prep_points_kernel(PrepArgs a) {
     if (a.zero[z])
       for (int64_t w = i; w < a.zero_words[z]; w += (int64_t)gridDim.x * blockDim.x) a.zero[z][w] = 0ull;
   if (i >= a.npad) return;
+  prep_one_point(a, i);
+}
+
+// prepared coordinates of point i (i < npad): scaled continuous dims + |x / ls|^2, centred linear dims, table indices
+__device__ __forceinline__ void prep_one_point(const PrepArgs& a, const int64_t i) {
   const bool real = i < a.n;
   const double* row = a.X + i * a.ldx;
   double nrm = 0.0;
@@ -307,6 +314,12 @@ struct CovTileArgs {
   // of its columns -- a direct-loop tile is a serial chain of 16 entry groups per thread (~30 us whatever the matrix), and a
   // matrix of four block columns has ten tiles for 256 compute units.  1 = off.
   int32_t gsplit;
+  // Small evaluations (gmb_evaluate below 4096 rows; round 6): the covariance build prepares the points itself -- every workgroup
+  // the rows and the columns of ITS strip, redundantly, before it stages them (the values are a function of X and theta only, so
+  // equal writes from different workgroups are harmless) -- and workgroup 0 clears what prep_points_kernel would have cleared:
+  // one launch and one launch boundary (~10 us of a 205 us evaluation at N = 392) less.
+  int32_t inline_prep;
+  PrepArgs prep;
 };
 
 // row of `out` where the tile row that starts at global row gi0 begins
@@ -625,9 +638,24 @@ __global__ __launch_bounds__(256, 2) void cov_tile_kernel(CovTileArgs a) {
   // tile -- take ~30 us each whatever the matrix, and in ascending order the last of them STARTED when everything else was done.
   long long b = (long long)(blockIdx.x / (unsigned)gs);
   if (a.tri_grid) b = (long long)(gridDim.x / (unsigned)gs) - 1 - b;
+  if (a.inline_prep && blockIdx.x == 0) {
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+      if (a.prep.zero[z])
+        for (int64_t w = threadIdx.x; w < a.prep.zero_words[z]; w += 256) a.prep.zero[z][w] = 0ull;
+  }
   if (!cov_decode_block(a.ti, a.tj, a.strip, a.tri_grid, a.row_first, a.row_stride,
                         a.mode == COV_TRAIN && a.lower_only, b, &tix, &tj_lo, &tj_hi))
     return;
+  if (a.inline_prep) {
+    const int64_t gi0 = a.i0 + (int64_t)tix * TILE, gj0 = a.j0 + (int64_t)tj_lo * TILE;
+    const int ncols = (tj_hi - tj_lo) * TILE;
+    for (int q = threadIdx.x; q < TILE + ncols; q += 256) {
+      const int64_t i = q < TILE ? gi0 + q : gj0 + (q - TILE);
+      if (i < a.prep.npad) prep_one_point(a.prep, i);
+    }
+    __syncthreads();  // (workgroup-scope fence + barrier: the staging below reads what this workgroup has just written)
+  }
   int tj_gen = tj_lo;  // first tile of the strip that goes through the direct loop
 #ifndef GMB_KBUILD_DIRECT
   // Interior tiles: stationary term only, every row and column real and -- for the training matrix -- the tile

@@ -233,6 +233,10 @@ struct gmb_engine {
   unsigned long long* prep_zero[2] = {nullptr, nullptr};  // what the NEXT prep_points launch clears besides its own work
   int64_t prep_zero_words[2] = {0, 0};
   bool prezeroed = false;     // gmb_evaluate's prep_points launch has cleared the scalar block and the tile launch's words
+  bool prep_deferred = false; // small gmb_evaluate: the points are prepared (and those words cleared) by the covariance build itself
+                              // (CovTileArgs::inline_prep) -- raised by gmb_set_theta, consumed by build_sigma, flushed by gmb_evaluate
+                              // if the build was never reached
+  int inline_prep_max_rows = 4096;
   bool fe_recorded = false;   // fe[] belong to the factorisation in flight
   // persistent evaluation launch (eval_tiles.hpp): L^-T by rows and Sigma^-1 as tile tasks, fused with the tile Cholesky
   // when the caller asks for the gradient together with the factorisation (gmb_evaluate)
@@ -884,8 +888,8 @@ int apply_theta(gmb_engine* e) {
   return GMB_OK;
 }
 
-int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int64_t npad, double* xs,
-                double* xl, int32_t* cat, const PrepArgs* proto = nullptr) {
+PrepArgs prep_args(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int64_t npad, double* xs, double* xl, int32_t* cat,
+                   const PrepArgs* proto) {
   PrepArgs a = proto ? *proto : e->prep_proto;
   for (int z = 0; z < 2; ++z) {  // (one shot: gmb_set_theta inside gmb_evaluate)
     a.zero[z] = e->prep_zero[z];
@@ -899,9 +903,22 @@ int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int6
   a.xs = xs;
   a.xl = xl;
   a.cat = cat;
+  return a;
+}
+
+int prep_points(gmb_engine* e, const double* dXraw, int64_t n, int64_t ldx, int64_t npad, double* xs,
+                double* xl, int32_t* cat, const PrepArgs* proto = nullptr) {
+  const PrepArgs a = prep_args(e, dXraw, n, ldx, npad, xs, xl, cat, proto);
   hipLaunchKernelGGL(prep_points_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, e->stream, a);
   HIP_TRY(e, hipGetLastError());
   return GMB_OK;
+}
+
+// the training points' preparation that a small gmb_evaluate left to its covariance build, if that build was never reached
+int flush_deferred_prep(gmb_engine* e) {
+  if (!e->prep_deferred) return GMB_OK;
+  e->prep_deferred = false;
+  return prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat);
 }
 
 PointSet train_set(const gmb_engine* e) { return PointSet{e->xs, e->xl, e->cat, e->N, e->Nr}; }
@@ -929,6 +946,11 @@ int build_sigma(gmb_engine* e, double* out, int64_t ldo) {
   a.lower_only = 1;
   a.tri_grid = 1;
   a.y = e->dy;
+  if (e->prep_deferred) {  // small gmb_evaluate: this launch prepares the points it stages (and clears prep_points_kernel's words)
+    e->prep_deferred = false;
+    a.inline_prep = 1;
+    a.prep = prep_args(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat, nullptr);
+  }
   if ((rc = launch_cov(e, a))) return rc;
   // additive models: the other terms add their covariance to the real entries, one pass each
   for (size_t t = 1; t < e->terms.size(); ++t) {
@@ -2407,8 +2429,9 @@ int gmb_set_theta(gmb_engine* e, const double* theta, int32_t n) {
     e->prep_zero_words[1] = (words + 1) / 2;
     e->prezeroed = true;
   }
-  rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat);
-  if (rc) return rc;
+  // small evaluations: the covariance build of this same gmb_evaluate prepares the points itself (one launch less)
+  e->prep_deferred = e->prezeroed && e->terms.size() == 1 && e->Nr <= e->inline_prep_max_rows && !e->naive_leaf;
+  if (!e->prep_deferred && (rc = prep_points(e, e->dX, e->N, e->D, e->Nr, e->xs, e->xl, e->cat))) return rc;
   e->have_theta = true;
   return GMB_OK;
 }
@@ -2425,6 +2448,10 @@ int gmb_set_profiling(gmb_engine* e, int32_t on) {
     e->tm.total_chol_panel_gemm_ms = e->tm.total_chol_panel_gemm_flops = 0.0;
     e->tm.total_chol_tile_ms = e->tm.total_chol_tile_flops = 0.0;
     e->tm.total_chol_tile_launches = 0;
+    e->tm.total_chol_update_all_ms = e->tm.total_chol_update_all_flops = 0.0;
+    e->tm.total_chol_update_all_launches = 0;
+    e->tm.total_chol_panel_tile_ms = e->tm.total_chol_panel_tile_flops = 0.0;
+    e->tm.total_chol_panel_tile_launches = 0;
     e->tm.masked_cus = e->aux_shared ? e->wg_slots / 2 - e->part_cus : 0;
     e->tm.total_gemm_launches = 0;
     e->tm.total_kbuild_ms = e->tm.total_kbuild_bytes = 0.0;
@@ -2613,6 +2640,10 @@ int gmb_evaluate(gmb_engine* e, const double* theta, int32_t n, double* nlml, do
   rc = factorize_enqueue(e, grad != nullptr);
   e->eval_call = false;
   e->prezeroed = false;
+  if (e->prep_deferred) {  // the covariance build was not reached (an allocation failed): the points are prepared now
+    const int rc2 = flush_deferred_prep(e);
+    if (!rc) rc = rc2;
+  }
   if (rc) {
     e->light = false;
     return rc;
