@@ -246,10 +246,13 @@ double dist_ms(hipEvent_t a, hipEvent_t b) {
   return t > 0.f ? (double)t : 0.0;
 }
 
+void rccl_note_main_stream(const gmb_comm* comm, hipStream_t main_stream);  // (the library's own transport: see RcclCtx below)
+
 int dist_check_comm(gmb_engine* e, const gmb_comm* comm) {
   if (!comm || !comm->all_gather || comm->world < 1 || comm->world > DIST_MAX_WORLD || comm->rank < 0 ||
       comm->rank >= comm->world)
     return fail(e, GMB_EINVAL, "bad communicator (1 <= world <= %d)", DIST_MAX_WORLD);
+  rccl_note_main_stream(comm, e->stream);  // collectives on this stream and on any other one use different communicators
   return GMB_OK;
 }
 
@@ -805,31 +808,34 @@ RcclApi* rccl_api(const char* path) {
 // kernels through a stream of its own): a panel column's TAIL on the communication stream would hold up the next chain's SQUARE and
 // PANEL gathers on the main stream -- the overlap the driver's plan is built for would exist in the emulation only.  The transport
 // therefore keeps TWO communicators over the same ranks (the second split off the first, ncclCommSplit: no second unique id to hand
-// round): the stream of the transport's first collective -- the engine's main stream: every gmb_dist_* call opens with the ranks'
-// agreement on it -- uses the first, every other stream the second.  Each communicator sees the same sequence on every rank (the
-// plan's), so neither can pair the wrong buffers.  Without ncclCommSplit (or if it fails) there is one communicator and the
-// collectives serialise: correct, slower.
+// round): the engine's main stream -- every gmb_dist_* call declares it (dist_check_comm) before its first collective -- uses the
+// first, every other stream the second; before any engine has declared one (the Python side's handshake) everything uses the
+// first.  Each communicator sees the same sequence on every rank (the plan's), so neither can pair the wrong buffers.  Without
+// ncclCommSplit (or if it fails) there is one communicator and the collectives serialise: correct, slower.
 struct RcclCtx {
   RcclApi* api;
   ncclComm_t comm;
-  ncclComm_t comm2 = nullptr;   // collectives issued on any stream but the first one's
-  void* first_stream = nullptr;
-  bool have_first = false;
+  ncclComm_t comm2 = nullptr;   // collectives issued on any stream but the engine's main one
+  void* main_stream = nullptr;
+  bool have_main = false;
 };
 
 int32_t rccl_all_gather(void* ctx, const void* send, void* recv, int64_t count, void* stream) {
   RcclCtx* c = (RcclCtx*)ctx;
-  if (!c->have_first) {
-    c->first_stream = stream;
-    c->have_first = true;
-  }
-  ncclComm_t comm = (stream == c->first_stream || !c->comm2) ? c->comm : c->comm2;
+  ncclComm_t comm = (!c->have_main || stream == c->main_stream || !c->comm2) ? c->comm : c->comm2;
   const ncclResult_t r = c->api->AllGather(send, recv, (size_t)count, ncclFloat64, comm, (hipStream_t)stream);
   if (r != ncclSuccess) {
     g_rccl_error = std::string("ncclAllGather: ") + (c->api->GetErrorString ? c->api->GetErrorString(r) : "error");
     return (int32_t)r;
   }
   return 0;
+}
+
+void rccl_note_main_stream(const gmb_comm* comm, hipStream_t main_stream) {
+  if (!comm || !comm->ctx || comm->all_gather != rccl_all_gather) return;  // (any other transport: its own business)
+  RcclCtx* c = (RcclCtx*)comm->ctx;
+  c->main_stream = (void*)main_stream;
+  c->have_main = true;
 }
 
 }  // namespace

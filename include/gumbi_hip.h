@@ -404,8 +404,8 @@ void gmb_rccl_comm_destroy(gmb_comm* c);
 int gmb_rccl_comm_ranks(const gmb_comm* c); /* ncclCommCount of the communicator (what RCCL itself reports) */
 /* (ABI 10) 1 when the transport holds TWO communicators over the same ranks (the second split off the first with ncclCommSplit):
  * RCCL executes the collectives of one communicator in issue order whatever their streams, so the driver's collectives on the
- * communication stream (a panel column's TAIL, the gradient's chunks) would hold up the main stream's; with two, each stream class
- * has its own.  0: one communicator (ncclCommSplit missing or failed, or GUMBI_RCCL_ONE_COMM set): correct, serialised. */
+ * communication stream (a panel column's TAIL, the gradient's chunks) would hold up the main stream's; with two, the engine's main
+ * stream (declared by every gmb_dist_* call) and every other stream have their own.  0: one communicator (ncclCommSplit missing or failed, or GUMBI_RCCL_ONE_COMM set): correct, serialised. */
 int gmb_rccl_comm_split(const gmb_comm* c);
 const char* gmb_rccl_last_error(void);
 
