@@ -313,7 +313,8 @@ def test_c4_host_baseline_counts_the_gpu_lines_flops():
     cfg = dict(bench.CONFIGS["c4"], N=256, res=8)
     r = bench.cpu_baseline_c4(cfg, target_seconds=0.01)
     n = int(r["sample"].split("at N=")[1].split(" ")[0])
-    assert abs(r["value"] - bench.c4_step_flops(n, 2, 2 * 64, 1, 0) / r["seconds"] / 1e9) / r["value"] < 0.02
+    # (value and seconds are rounded to two decimals in the report: at this toy size that alone is a few per cent)
+    assert abs(r["value"] - bench.c4_step_flops(n, 2, 2 * 64, 1, 0) / r["seconds"] / 1e9) <= 0.011 + 0.05 * r["value"]
     assert r["executed_stacked_system_gflops"] > 2.0 * r["value"] and "SAME algorithmic flops" in r["note"]
 
 
